@@ -1,0 +1,171 @@
+"""OFF-forward benchmark (BASELINE.json metric: OFF-forward clips/sec, 7-seg 224x224).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the OFF sub-network forward (liboffk: nine OFF units, fusion
+@28/@14/@7, three heads) over one batch of synthetic BN-Inception feature maps already
+resident in HBM.  N = 1 is BASELINE config 2 (RGB_OFF, B = 64 clips x 7 segments).  N > 1
+is config 4: every rank owns 64 clips (weak scaling, no data-path collective), takes the
+SegmentConsensus average per clip and the per-clip scores are exchanged once per step with
+one RCCL all-gather over xGMI.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import offk_amd  # noqa: E402,F401
+from offk_amd import runtime, spec, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA peak
+
+
+def cpu_baseline(feats_np, weights, length, variant, clips):
+    """The oracle (a port of the reference's op sequence, bit-exact against it in the dev
+    container) timed on this box's host cores -- reported beside the GPU number only."""
+    from oracle import off_oracle as orc
+    w = orc.to_torch_weights(weights)
+    x = [torch.from_numpy(f[:clips * length]) for f in feats_np]
+    times = []
+    with torch.no_grad():
+        for i in range(2 + 5):
+            t0 = time.perf_counter()
+            orc.off_forward(x, w, clips, length, variant, orc.SLICE_FLAT)
+            if i >= 2:
+                times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": clips / med, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/off_oracle.py (torch CPU ops) on the first %d clips x %d segments of the same "
+                      "synthetic maps, 2 warm-ups, median of 5" % (clips, length),
+            "cpu_model": model, "host_logical_cpus": os.cpu_count(), "sec_per_forward": med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--length", type=int, default=7)
+    ap.add_argument("--variant", choices=("rgb", "flow"), default="rgb")
+    ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    variant = spec.VARIANT_RGB if args.variant == "rgb" else spec.VARIANT_FLOW
+    B, L = args.batch, args.length
+    consensus = (variant == spec.VARIANT_FLOW) or world > 1
+    weights = synth.make_weights(variant)
+    feats_np = synth.make_features(B, L, config_id=2, clip_offset=rank * B)
+    feats = [torch.from_numpy(f).to(dev) for f in feats_np]
+    h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, consensus, device=dev)
+    h.load_state_dict(weights)
+    arr = h._feat_array(feats)
+    rows = h.out_rows()
+    out = [torch.empty(rows, spec.NUM_CLASSES, device=dev) for _ in range(3)]
+    gathered = torch.empty(world, 3, rows, spec.NUM_CLASSES, device=dev) if world > 1 else None   # [rank][head][clip][class]
+    local = torch.empty(3, rows, spec.NUM_CLASSES, device=dev) if world > 1 else None
+
+    def step():
+        if world > 1:
+            h.forward_into(arr, local[0], local[1], local[2])
+            # config 4: the only exchange on the path -- per-clip consensus scores, one collective
+            dist.all_gather_into_tensor(gathered.view(world * 3 * rows, -1), local.view(3 * rows, -1))
+        else:
+            h.forward_into(arr, out[0], out[1], out[2])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    h.set_profiling(True)
+    h.stage_times(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    stages = h.stage_times(reset=True)
+    h.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        clips_s = world * B * args.steps / dt
+        k2_ms, k2_calls = stages["sobel_tdiff"]
+        k2_avg_s = k2_ms / max(k2_calls, 1) * 1e-3
+        algo_bytes = spec.algorithmic_bytes_sobel_tdiff(B, L)
+        achieved = algo_bytes / k2_avg_s / 1e9 if k2_avg_s > 0 else 0.0
+        unit_f, fus_f = spec.flops_per_clip(L)
+        stage_ms = dict((k, v[0] / max(v[1], 1)) for k, v in stages.items())
+        gpu_ms = sum(stage_ms.values())
+        res = {
+            "metric": "OFF-forward clips/sec (7-seg 224x224)", "value": clips_s, "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (portable counter-based generator: ReLU-like non-negative BN-Inception "
+                    "feature maps, fan-in-scaled uniform weights; features resident in HBM)",
+            "config": {"workload": "%s_OFF forward, batch=%d clips/GPU x %d segments, nine 224x224-geometry "
+                                   "feature maps%s" % (args.variant.upper(), B, L,
+                                                        " + SegmentConsensus avg + RCCL all-gather of per-clip scores"
+                                                        if world > 1 else ""),
+                       "global_batch": world * B, "segments": L, "parallelism": "clip-shard x%d" % world,
+                       "slice_mode": "reference_flat"},
+            "roofline": {"bound": "hbm", "kernel": "sobel_tdiff_kernel (K2, all nine sites, one launch)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": k2_avg_s * 1e6},
+            "stage_ms": stage_ms,
+            "mfma": {"flops_per_step": (unit_f + fus_f) * B, "achieved_tflops": (unit_f + fus_f) * B / (gpu_ms * 1e-3) / 1e12
+                     if gpu_ms > 0 else 0.0, "peak_tflops": MFMA_F32_PEAK_TFLOPS},
+        }
+        if world == 1 and args.cpu_clips > 0:
+            res["cpu_baseline"] = cpu_baseline(feats_np, weights, L, variant, min(args.cpu_clips, B))
+            res["gpu_over_cpu"] = clips_s / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * offk.h -- C ABI of liboffk.so: the MI355X-native OFF sub-network forward.
+ *
+ * The reference (JoeHEZHAO/Optical-Flow-Guided-Feature-Pytorch) has NO plugin /
+ * operator / FFI boundary for this path: the OFF sub-network is inline Python inside
+ * BNInception_OFF.RGB_OFF_forward (RGB_OFF.py:360-860, OFF part :596-847) and
+ * BNInception_OFF.forward (Flow_OFF.py:370-887, OFF part :606-876).  The cut this
+ * library replaces is therefore the set of nine local tensors
+ * inception_{3a,3b,3c,4a,4b,4c,4d,5a,5b}_output_out (RGB_OFF.py:395,418,435,458,481,
+ * 504,527,567,590) on the way in and fc_action_motion{,_14,_28} (RGB_OFF.py:787,793,
+ * 847) on the way out.  Each entry point below cites the reference lines it stands for.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 (OFFK_OK) or a negative error code
+ *    and never throws; offk_last_error() gives the message.
+ *  - the caller owns every data buffer (device pointers, e.g. torch tensor.data_ptr());
+ *    the library owns the handle and its packed weight copies only.
+ *  - all work is enqueued asynchronously on the hipStream_t passed as `void* stream`
+ *    (NULL = default stream); there is no implicit synchronisation.
+ *  - a handle is not thread-safe; distinct handles are independent.
+ *  - fp32 everywhere.  Boundary tensors are NCHW contiguous exactly as the reference
+ *    backbone produces them; INTERNAL activations (workspace, stage entry points) are
+ *    channels-last: [rows = image*H*W + y*W + x][channels], see DESIGN.md.
+ */
+#ifndef OFFK_H_
+#define OFFK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFFK_ABI_VERSION 1
+#define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
+
+enum offk_status {
+  OFFK_OK = 0,
+  OFFK_ERR_INVALID = -1,        /* bad argument / shape */
+  OFFK_ERR_HIP = -2,            /* a HIP runtime call failed */
+  OFFK_ERR_MISSING_WEIGHT = -3, /* forward called before every weight was set */
+  OFFK_ERR_UNKNOWN_KEY = -4,    /* state_dict key not part of the OFF sub-network */
+  OFFK_ERR_NO_DEVICE = -5       /* no gfx950 device visible */
+};
+
+enum offk_variant {
+  OFFK_VARIANT_RGB_LEARNED_DW = 0, /* RGB_OFF.py: learned depthwise 3x3 + bias (:268,611) */
+  OFFK_VARIANT_DIAG_SOBEL = 1      /* Flow_OFF.py:51,622 / RGB_OFF_v2.py:58: util.SobelFilter_Diagonal */
+};
+enum offk_slice_mode {
+  OFFK_SLICE_REFERENCE_FLAT = 0, /* spatial branch = X[:B*(L-1)] on the flat frame axis (RGB_OFF.py:609) */
+  OFFK_SLICE_PER_CLIP = 1        /* drop each clip's last frame (what the comment at :608 says) */
+};
+enum offk_consensus {
+  OFFK_CONSENSUS_NONE = 0, /* RGB_OFF.py:849-860: per-pair logits [B*(L-1), classes] */
+  OFFK_CONSENSUS_AVG = 1   /* Flow_OFF.py:867-876 / basic_ops.py:19-21: mean over L-1 -> [B, classes] */
+};
+enum offk_feat_layout {
+  OFFK_FEAT_NCHW = 0, /* what the reference backbone's torch.cat produces */
+  OFFK_FEAT_NHWC = 1  /* channels_last physical layout of the same logical tensor */
+};
+
+typedef struct offk_config {
+  int32_t batch;       /* B clips            (BNInception_OFF.batch,  RGB_OFF.py:35) */
+  int32_t length;      /* L segments / clip  (BNInception_OFF.length, RGB_OFF.py:36), >= 2 */
+  int32_t variant;     /* enum offk_variant */
+  int32_t slice_mode;  /* enum offk_slice_mode */
+  int32_t consensus;   /* enum offk_consensus */
+  int32_t num_classes; /* 101 (RGB_OFF.py:332-334) */
+  int32_t feat_layout; /* enum offk_feat_layout */
+  int32_t device;      /* HIP device ordinal the handle lives on */
+} offk_config;
+
+typedef struct offk_handle offk_handle;
+
+int offk_abi_version(void);
+
+/* Message for the last error on `h` (or, with h == NULL, the last error of a failed
+ * offk_create / handle-less call on this thread).  Never NULL. */
+const char* offk_last_error(const offk_handle* h);
+
+/* Replaces: BNInception_OFF.__init__ motion_* declarations (RGB_OFF.py:265-358). */
+int offk_create(const offk_config* cfg, offk_handle** out);
+int offk_destroy(offk_handle* h);
+
+/* Replaces: load_state_dict for the motion_*, fc_action_motion* and sobel_edge_diagonal
+ * keys (model_utils.py:188-216, Flow_OFF.py:1398-1413).  `key` is the reference
+ * state_dict key (an optional "module." prefix is ignored, test_flow_off.py:52-58);
+ * `data` may be a host or a device pointer; shape is checked against the reference's.
+ * The library keeps its own packed device copy. */
+int offk_set_weight(offk_handle* h, const char* key, const float* data, const int64_t* shape, int ndim);
+/* Number of weights still unset (0 = ready); if buf != NULL the first missing key is copied there. */
+int offk_missing_weights(const offk_handle* h, char* buf, size_t buflen);
+
+/* Bytes of caller-provided device scratch offk_forward needs for this (B, L). */
+size_t offk_workspace_bytes(const offk_handle* h);
+
+/* Replaces: RGB_OFF.py:596-847 / Flow_OFF.py:606-876 (nine OFF units, fusion @28/@14/@7,
+ * three heads, optional SegmentConsensus).
+ *   feats[i]: site i feature map, [B*L, C_i, H_i, H_i] fp32 (layout per cfg.feat_layout)
+ *   out7/out14/out28: [rows, num_classes] fp32, rows = B*(L-1) (consensus none) or B (avg);
+ *   out28 may be NULL (the reference computes it but never returns it, RGB_OFF.py:860). */
+int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES],
+                 float* out7, float* out14, float* out28, void* workspace);
+
+/* Named regions of the workspace after offk_forward (for stage-level parity tests):
+ * "G_<site>", "D_<site>", "fusion_28", "fusion_14", "fusion_7", "sum_7".  All channels-last. */
+int offk_workspace_region(const offk_handle* h, const char* name, size_t* offset_bytes, size_t* nbytes);
+
+/* Per-stage device timing.  When enabled, offk_forward brackets each stage with HIP
+ * events on the caller's stream; offk_stage_times synchronises those events and
+ * returns accumulated milliseconds + launch counts since the last reset.
+ * Stage order: 0 pw_reduce (K1), 1 sobel_tdiff (K2), 2 fusion_28, 3 fusion_14,
+ * 4 fusion_7, 5 heads+consensus. */
+#define OFFK_NUM_STAGES 6
+int offk_set_profiling(offk_handle* h, int enable);
+int offk_stage_times(offk_handle* h, double ms[OFFK_NUM_STAGES], int64_t calls[OFFK_NUM_STAGES], int reset);
+
+/* ---- stage entry points (the same kernels offk_forward launches) ------------------ */
+
+/* K1. Replaces motion_conv_gen_<s> + motion_relu_gen_<s> on all N frames and
+ * motion_spatial_down_<s> on the sliced frames (RGB_OFF.py:597-598, 609-610), stacked so
+ * the map is read once.  G: [N*HW, 128] (post-ReLU), D: [P*HW, 32] channels-last. */
+int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, float* G, float* D);
+
+/* K2. Replaces the temporal subtraction (RGB_OFF.py:599-604), the depthwise 3x3 /
+ * diagonal Sobel (RGB_OFF.py:611; Flow_OFF.py:622 + util.py:52-77) and the concats
+ * (RGB_OFF.py:616,656,760,832): writes [spatial 32 | temporal 128] into channels
+ * [m_coff, m_coff+160) of M, a channels-last buffer with m_cstride channels per pixel.
+ * algo: 0 = register rotation over t (default), 1 = t across lanes + wavefront shuffle. */
+int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, const float* D,
+                     float* M, int m_cstride, int m_coff, int algo);
+
+/* K1+K2 for all nine sites into the workspace fusion buffers (two grouped launches). */
+int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace);
+
+/* K4. Generic channels-last convolution (the fusion convs, RGB_OFF.py:657-685,762-780,
+ * 833-841): y = post( pre(conv(in(x)) + bias) + res ).  x,y,res are channel-sliced views
+ * (ptr, channels-per-pixel stride, first channel).  w is [Co][KH][KW][Ci] (see
+ * offk_pack_conv_weight).  Requires Ci % 32 == 0, Co % 32 == 0, strides/offsets % 4 == 0. */
+enum offk_conv_flags { OFFK_CONV_RELU_IN = 1, OFFK_CONV_RELU_PRE = 2, OFFK_CONV_RELU_POST = 4 };
+int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci,
+                const float* w, const float* bias, int Co, int KH, int KW, int stride, int pad,
+                const float* res, int res_cstride, int res_coff, int flags,
+                float* y, int y_cstride, int y_coff);
+/* [Co][Ci][KH][KW] (PyTorch) -> [Co][KH][KW][Ci]; both device pointers. */
+int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_ohwi);
+
+/* K5. Replaces motion_pool_trans_28 / global_pool / squeeze / fc_action_motion*
+ * (RGB_OFF.py:782-787, 789-793, 843-847): optional MaxPool(3,2,ceil) then global
+ * average over the (pooled) map then Linear.  x: channel slice [x_coff, x_coff+C) of a
+ * channels-last buffer with x_cstride channels per pixel. */
+int offk_head(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int C,
+              int maxpool, const float* fc_w, const float* fc_b, int num_classes, float* out);
+
+/* K6. Replaces ConsensusModule('avg') (basic_ops.py:12-46) as applied in
+ * Flow_OFF.py:867-876: x [B, T, C] -> mean over T -> [B, C]. */
+int offk_segment_consensus(void* stream, const float* x, int B, int T, int C, float* out);
+
+/* NCHW <-> channels-last helpers (device pointers), used by tests and by callers that
+ * want a reference-layout view of an internal buffer. */
+int offk_nchw_to_nhwc(void* stream, const float* src, int n_img, int C, int HW, float* dst);
+int offk_nhwc_to_nchw(void* stream, const float* src, int cstride, int coff, int n_img, int C, int HW, float* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFFK_H_ */

@@ -1,0 +1,80 @@
+"""ctypes binding of liboffk.so (include/offk.h).  No fallback: if the library is missing
+or a call fails, this raises -- the product path never runs without the HIP extension."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboffk.so")
+NUM_SITES = 9
+NUM_STAGES = 6
+STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7", "heads")
+
+CONV_RELU_IN, CONV_RELU_PRE, CONV_RELU_POST = 1, 2, 4
+
+
+class OffkError(RuntimeError):
+    pass
+
+
+class OffkConfig(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("length", ctypes.c_int32), ("variant", ctypes.c_int32),
+                ("slice_mode", ctypes.c_int32), ("consensus", ctypes.c_int32),
+                ("num_classes", ctypes.c_int32), ("feat_layout", ctypes.c_int32),
+                ("device", ctypes.c_int32)]
+
+
+_c = ctypes
+_P = ctypes.c_void_p
+_F = ctypes.c_void_p       # float* passed as integer address (tensor.data_ptr())
+_I = ctypes.c_int
+
+# name -> (restype, argtypes); every symbol include/offk.h declares
+SIGNATURES = {
+    "offk_abi_version": (_I, []),
+    "offk_last_error": (_c.c_char_p, [_P]),
+    "offk_create": (_I, [_c.POINTER(OffkConfig), _c.POINTER(_P)]),
+    "offk_destroy": (_I, [_P]),
+    "offk_set_weight": (_I, [_P, _c.c_char_p, _F, _c.POINTER(_c.c_int64), _I]),
+    "offk_missing_weights": (_I, [_P, _c.c_char_p, _c.c_size_t]),
+    "offk_workspace_bytes": (_c.c_size_t, [_P]),
+    "offk_forward": (_I, [_P, _P, _c.POINTER(_F), _F, _F, _F, _P]),
+    "offk_workspace_region": (_I, [_P, _c.c_char_p, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
+    "offk_set_profiling": (_I, [_P, _I]),
+    "offk_stage_times": (_I, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _I]),
+    "offk_pw_reduce": (_I, [_P, _P, _I, _F, _F, _F]),
+    "offk_sobel_tdiff": (_I, [_P, _P, _I, _F, _F, _F, _I, _I, _I]),
+    "offk_off_units": (_I, [_P, _P, _c.POINTER(_F), _P]),
+    "offk_conv2d": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I]),
+    "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
+    "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),
+    "offk_segment_consensus": (_I, [_P, _F, _I, _I, _I, _F]),
+    "offk_nchw_to_nhwc": (_I, [_P, _F, _I, _I, _I, _F]),
+    "offk_nhwc_to_nchw": (_I, [_P, _F, _I, _I, _I, _I, _I, _F]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liboffk.so (once).  Raises OffkError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OffkError("liboffk.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or optical-flow-guided-feature-pytorch_amd/build.py); there is no fallback path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.offk_abi_version() != 1:
+        raise OffkError("liboffk.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().offk_last_error(handle)
+        raise OffkError("liboffk error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,123 @@
+// K5 / K6 and the NCHW <-> channels-last helpers.
+//
+// K5 stands for the three classifier heads (reference RGB_OFF.py):
+//   28-head :782-787  MaxPool2d(3,2,ceil_mode) (:353) -> AvgPool2d(7) (:262) -> squeeze -> Linear(256,101)
+//   14-head :789-793  AvgPool2d(7) -> squeeze -> Linear(512,101)
+//   7-head  :843-847  AvgPool2d(7) -> squeeze -> Linear(1024,101)
+// (dropout is the identity in eval).  One block per pair: the pooled [C] vector is
+// built in LDS with channel-coalesced reads of the channels-last map, then each wave
+// takes output classes round-robin, lanes along C, and reduces with wavefront shuffles.
+// K6 stands for SegmentConsensus 'avg' (basic_ops.py:19-21) as used at Flow_OFF.py:867-876.
+#include "offk_common.h"
+#include "offk_internal.h"
+
+namespace offk {
+
+constexpr int HEAD_MAX_C = 1024;
+
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int cs, int coff, int H, int W, int C, int maxpool,
+                                                   const float* __restrict__ fw, const float* __restrict__ fb,
+                                                   int ncls, float* __restrict__ out) {
+  __shared__ float pooled[HEAD_MAX_C];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float* xi = x + (size_t)img * H * W * cs + coff;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    if (maxpool) {
+      // MaxPool2d(kernel 3, stride 2, pad 0, ceil_mode=True): windows clipped at the border
+      const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          float m = -INFINITY;
+          for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+              int y = 2 * oy + dy, xx = 2 * ox + dx;
+              if (y < H && xx < W) m = fmaxf(m, xi[(size_t)(y * W + xx) * cs + c]);
+            }
+          s += m;
+        }
+      s /= (float)(Ho * Wo);
+    } else {
+      for (int q = 0; q < H * W; ++q) s += xi[(size_t)q * cs + c];
+      s /= (float)(H * W);
+    }
+    pooled[c] = s;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int o = wave; o < ncls; o += 4) {
+    const float* wr = fw + (size_t)o * C;
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(wr[c], pooled[c], a);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) out[(size_t)img * ncls + o] = a + fb[o];
+  }
+}
+
+hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, const float* fw,
+                       const float* fb, int ncls, float* out, hipStream_t st, const char** why) {
+  *why = nullptr;
+  if (C > HEAD_MAX_C || C <= 0 || n_img <= 0) { *why = "head: C must be in 1..1024"; return hipErrorInvalidValue; }
+  if (maxpool && (H < 3 || W < 3)) { *why = "head: maxpool needs H,W >= 3"; return hipErrorInvalidValue; }
+  hipLaunchKernelGGL(head_kernel, dim3(n_img), dim3(256), 0, st, x, x_cs, x_coff, H, W, C, maxpool, fw, fb, ncls, out);
+  return hipGetLastError();
+}
+
+__global__ void consensus_kernel(const float* __restrict__ x, int T, int C, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[((size_t)b * T + t) * C + c];
+    out[(size_t)b * C + c] = s / (float)T;
+  }
+}
+hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(consensus_kernel, dim3(B), dim3(128), 0, st, x, T, C, out);
+  return hipGetLastError();
+}
+
+// [n][C][HW] -> [n*HW][C], tiled through LDS so both sides are coalesced
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int HW, float* __restrict__ dst) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int c = c0 + r, q = q0 + tx;
+    t[r][tx] = (c < C && q < HW) ? src[((size_t)n * C + c) * HW + q] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int q = q0 + r, c = c0 + tx;
+    if (c < C && q < HW) dst[((size_t)n * HW + q) * C + c] = t[tx][r];
+  }
+}
+hipError_t nchw_to_nhwc_launch(const float* src, int n_img, int C, int HW, float* dst, hipStream_t st) {
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, n_img);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, st, src, C, HW, dst);
+  return hipGetLastError();
+}
+
+// channel slice [coff, coff+C) of a channels-last buffer with cs channels/pixel -> [n][C][HW]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, int cs, int coff, int C, int HW,
+                                                           float* __restrict__ dst) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int q = q0 + r, c = c0 + tx;
+    t[r][tx] = (c < C && q < HW) ? src[((size_t)n * HW + q) * cs + coff + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int c = c0 + r, q = q0 + tx;
+    if (c < C && q < HW) dst[((size_t)n * C + c) * HW + q] = t[tx][r];
+  }
+}
+hipError_t nhwc_to_nchw_launch(const float* src, int cs, int coff, int n_img, int C, int HW, float* dst, hipStream_t st) {
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, n_img);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, src, cs, coff, C, HW, dst);
+  return hipGetLastError();
+}
+
+}  // namespace offk

@@ -1,0 +1,647 @@
+// liboffk C ABI: handle, weight registry/packing, workspace plan, forward orchestration.
+// See include/offk.h for the contract and the reference lines each entry point stands for.
+#include "../../include/offk.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "offk_internal.h"
+
+using namespace offk;
+
+namespace {
+
+struct SiteSpec { const char* name; int C, H; };
+// reference RGB_OFF.py:395..590 (tap sites) and the view() literals at :600..817
+const SiteSpec kSites[kNumSites] = {{"3a", 256, 28}, {"3b", 320, 28}, {"3c", 576, 14}, {"4a", 576, 14}, {"4b", 576, 14},
+                                    {"4c", 608, 14}, {"4d", 608, 14}, {"5a", 1024, 7}, {"5b", 1024, 7}};
+// launch order of the grouped K1 grid: longest K first so the tail is made of short blocks
+const int kPwOrder[kNumSites] = {7, 8, 5, 6, 2, 3, 4, 1, 0};
+// fusion buffer of each site and its channel offset there (RGB_OFF.py:656, :760, :832)
+const int kSiteFusion[kNumSites] = {0, 0, 1, 1, 1, 1, 1, 2, 2};
+const int kSiteCoff[kNumSites] = {0, 160, 0, 160, 320, 480, 640, 0, 160};
+const int kFusionC[3] = {320, 1056, 832};
+
+struct ConvSpec { const char* key; int Co, Ci, K, stride, pad; };
+enum ConvId {
+  C_T28, C1_28A, C2_28A, C3_28A, CB_28A, C1_28B, C2_28B, C3_28B, C1_28C, C2_28C, C3_28C,
+  C_T14, C1_14A, C2_14A, C3_14A, CE_14A, C1_14B, C2_14B, C3_14B,
+  C_T7, C1_7, C2_7, C3_7, CB_7, kNumConvs
+};
+// reference RGB_OFF.py:278-290, 308-316, 326-330
+const ConvSpec kConvs[kNumConvs] = {
+    {"motion_conv_trans_28", 64, 320, 7, 2, 3},      {"motion_conv1_trans_28a", 64, 64, 1, 1, 0},
+    {"motion_conv2_trans_28a", 64, 64, 3, 1, 1},     {"motion_conv3_trans_28a", 256, 64, 1, 1, 0},
+    {"motion_conv_branch_28a", 256, 64, 1, 1, 0},    {"motion_conv1_trans_28b", 64, 256, 1, 1, 0},
+    {"motion_conv2_trans_28b", 64, 64, 3, 1, 1},     {"motion_conv3_trans_28b", 256, 64, 1, 1, 0},
+    {"motion_conv1_trans_28c", 64, 256, 1, 1, 0},    {"motion_conv2_trans_28c", 64, 64, 3, 1, 1},
+    {"motion_conv3_trans_28c", 256, 64, 1, 1, 0},    {"motion_conv_trans_14", 128, 1056, 5, 2, 2},
+    {"motion_conv1_trans_14a", 128, 128, 1, 1, 0},   {"motion_conv2_trans_14a", 128, 128, 3, 1, 1},
+    {"motion_conv3_trans_14a", 512, 128, 1, 1, 0},   {"motion_conv_expand_trans_14a", 512, 128, 1, 1, 0},
+    {"motion_conv1_trans_14b", 128, 512, 1, 1, 0},   {"motion_conv2_trans_14b", 128, 128, 3, 1, 1},
+    {"motion_conv3_trans_14b", 512, 128, 3, 1, 1},   {"motion_conv_trans", 256, 832, 3, 1, 1},
+    {"motion_conv1_trans", 256, 256, 1, 1, 0},       {"motion_conv2_trans", 256, 256, 3, 1, 1},
+    {"motion_conv3_trans", 1024, 256, 1, 1, 0},      {"motion_conv_branch_trans", 1024, 256, 1, 1, 0}};
+struct HeadSpec { const char* key; int C; };
+const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
+const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
+
+enum SlotKind { SK_GEN_W, SK_GEN_B, SK_DOWN_W, SK_DOWN_B, SK_DW_W, SK_DW_B, SK_SOBEL, SK_CONV_W, SK_CONV_B, SK_FC_W, SK_FC_B };
+struct Slot {
+  std::string key;
+  std::vector<int64_t> shape;
+  SlotKind kind;
+  int idx;
+  bool set = false;
+};
+
+thread_local std::string g_err;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct offk_handle {
+  offk_config cfg;
+  int N = 0, P = 0;
+  std::vector<Slot> slots;
+  std::map<std::string, int> index;
+  // packed device weights
+  float* pw_w[kNumSites] = {};   // [160][C]
+  float* pw_b[kNumSites] = {};   // [160]
+  float* dw_w[kNumSites] = {};   // [9][32]
+  float* dw_b[kNumSites] = {};   // [32] or null
+  float* sobel_w = nullptr;      // shared [9][32] (diag variant)
+  float* conv_w[kNumConvs] = {};
+  float* conv_b[kNumConvs] = {};
+  float* fc_w[3] = {};
+  float* fc_b[3] = {};
+  std::vector<void*> allocs;
+  // workspace plan
+  std::map<std::string, std::pair<size_t, size_t>> regions;
+  size_t ws_bytes = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> events;   // groups of OFFK_NUM_STAGES + 1
+  size_t ev_used = 0;
+  mutable std::string err;
+};
+
+namespace {
+
+int fail(offk_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_err = msg;
+  return code;
+}
+int fail_hip(offk_handle* h, hipError_t e, const char* what) {
+  return fail(h, OFFK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(h, expr)                                   \
+  do {                                                     \
+    hipError_t e__ = (expr);                               \
+    if (e__ != hipSuccess) return fail_hip(h, e__, #expr); \
+  } while (0)
+
+int dev_alloc(offk_handle* h, float** p, size_t nfloats) {
+  void* q = nullptr;
+  HIP_TRY(h, hipMalloc(&q, nfloats * sizeof(float)));
+  HIP_TRY(h, hipMemset(q, 0, nfloats * sizeof(float)));
+  h->allocs.push_back(q);
+  *p = static_cast<float*>(q);
+  return OFFK_OK;
+}
+
+void add_slot(offk_handle* h, const std::string& key, std::vector<int64_t> shape, SlotKind kind, int idx) {
+  Slot s;
+  s.key = key; s.shape = std::move(shape); s.kind = kind; s.idx = idx;
+  h->index[key] = (int)h->slots.size();
+  h->slots.push_back(std::move(s));
+}
+
+void add_region(offk_handle* h, const std::string& name, size_t nfloats) {
+  size_t off = align_up(h->ws_bytes, 256);
+  h->regions[name] = std::make_pair(off, nfloats * sizeof(float));
+  h->ws_bytes = off + nfloats * sizeof(float);
+}
+
+float* region(const offk_handle* h, void* ws, const char* name) {
+  auto it = h->regions.find(name);
+  return reinterpret_cast<float*>(static_cast<char*>(ws) + it->second.first);
+}
+
+void plan_workspace(offk_handle* h) {
+  const size_t N = h->N, P = h->P;
+  for (int s = 0; s < kNumSites; ++s) {
+    size_t hw = (size_t)kSites[s].H * kSites[s].H;
+    add_region(h, std::string("G_") + kSites[s].name, N * hw * kGenCh);
+    add_region(h, std::string("D_") + kSites[s].name, P * hw * kDownCh);
+  }
+  add_region(h, "fusion_28", P * 784 * 320);
+  add_region(h, "fusion_14", P * 196 * 1056);
+  add_region(h, "fusion_7", P * 49 * 832);
+  // fusion@28 temporaries, 14x14 maps
+  add_region(h, "x0_28", P * 196 * 64);
+  add_region(h, "t1_28", P * 196 * 64);
+  add_region(h, "t2_28", P * 196 * 64);
+  add_region(h, "br_28", P * 196 * 256);
+  add_region(h, "sa_28", P * 196 * 256);
+  add_region(h, "sb_28", P * 196 * 256);
+  // fusion@14 temporaries, 7x7 maps
+  add_region(h, "x1_14", P * 49 * 128);
+  add_region(h, "u1_14", P * 49 * 128);
+  add_region(h, "u2_14", P * 49 * 128);
+  add_region(h, "ex_14", P * 49 * 512);
+  add_region(h, "sa_14", P * 49 * 512);
+  // fusion@7
+  add_region(h, "x2_7", P * 49 * 256);
+  add_region(h, "v1_7", P * 49 * 256);
+  add_region(h, "v2_7", P * 49 * 256);
+  add_region(h, "br_7", P * 49 * 1024);
+  add_region(h, "sum_7", P * 49 * 1024);
+  // per-pair logits when consensus averages them afterwards
+  add_region(h, "logit_7", P * (size_t)h->cfg.num_classes);
+  add_region(h, "logit_14", P * (size_t)h->cfg.num_classes);
+  add_region(h, "logit_28", P * (size_t)h->cfg.num_classes);
+  h->ws_bytes = align_up(h->ws_bytes, 256);
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int want) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != want) changed = hipSetDevice(want) == hipSuccess;
+  }
+  ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+
+int check_ready(offk_handle* h) {
+  for (const Slot& s : h->slots)
+    if (!s.set) return fail(h, OFFK_ERR_MISSING_WEIGHT, "weight not set: " + s.key);
+  return OFFK_OK;
+}
+
+bool slot_set(const offk_handle* h, const std::string& key) {
+  auto it = h->index.find(key);
+  return it != h->index.end() && h->slots[it->second].set;
+}
+
+int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
+  const std::string n = kSites[site].name;
+  if (need_pw)
+    for (const char* k : {"motion_conv_gen_", "motion_spatial_down_"})
+      for (const char* sfx : {".weight", ".bias"})
+        if (!slot_set(h, std::string(k) + n + sfx)) return fail(h, OFFK_ERR_MISSING_WEIGHT, std::string("weight not set: ") + k + n + sfx);
+  if (need_dw) {
+    if (h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL) {
+      if (!slot_set(h, kSobelKey)) return fail(h, OFFK_ERR_MISSING_WEIGHT, std::string("weight not set: ") + kSobelKey);
+    } else {
+      for (const char* sfx : {".weight", ".bias"})
+        if (!slot_set(h, "motion_spatial_grad_" + n + sfx)) return fail(h, OFFK_ERR_MISSING_WEIGHT, "weight not set: motion_spatial_grad_" + n + sfx);
+    }
+  }
+  return OFFK_OK;
+}
+
+void fill_pw_site(const offk_handle* h, int site, const float* feat, float* G, float* D, PwSite* o) {
+  o->x = feat; o->w = h->pw_w[site]; o->bias = h->pw_b[site]; o->G = G; o->D = D;
+  o->C = kSites[site].C; o->HW = kSites[site].H * kSites[site].H; o->M = h->N * o->HW;
+  o->blk_begin = 0;
+}
+void fill_st_site(const offk_handle* h, int site, const float* G, const float* D, float* M, int m_cs, int m_coff, StSite* o) {
+  o->G = G; o->D = D;
+  o->dw = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? h->sobel_w : h->dw_w[site];
+  o->db = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? nullptr : h->dw_b[site];
+  o->M = M; o->H = kSites[site].H; o->m_cs = m_cs; o->m_coff = m_coff;
+  st_plan(o->H, &o->strips, &o->rows);
+  o->blk_begin = 0;
+}
+
+int run_off_units(offk_handle* h, hipStream_t st, const float* const feats[], void* ws, hipEvent_t* ev) {
+  PwParams pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.nsites = kNumSites; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
+  pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
+  int blk = 0;
+  for (int i = 0; i < kNumSites; ++i) {
+    int s = kPwOrder[i];
+    fill_pw_site(h, s, feats[s], region(h, ws, (std::string("G_") + kSites[s].name).c_str()),
+                 region(h, ws, (std::string("D_") + kSites[s].name).c_str()), &pp.s[i]);
+    pp.s[i].blk_begin = blk;
+    blk += pw_blocks_for(pp.s[i].M);
+  }
+  pp.total_blocks = blk;
+  if (ev) HIP_TRY(h, hipEventRecord(ev[0], st));
+  HIP_TRY(h, pw_reduce_launch(pp, st));
+  if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
+
+  StParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.nsites = kNumSites; sp.B = h->cfg.batch; sp.L = h->cfg.length;
+  const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
+  blk = 0;
+  for (int s = 0; s < kNumSites; ++s) {
+    fill_st_site(h, s, region(h, ws, (std::string("G_") + kSites[s].name).c_str()),
+                 region(h, ws, (std::string("D_") + kSites[s].name).c_str()), region(h, ws, fus[kSiteFusion[s]]),
+                 kFusionC[kSiteFusion[s]], kSiteCoff[s], &sp.s[s]);
+    sp.s[s].blk_begin = blk;
+    blk += h->cfg.batch * sp.s[s].strips;
+  }
+  sp.total_blocks = blk;
+  HIP_TRY(h, sobel_tdiff_launch(sp, 0, st));
+  if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
+  return OFFK_OK;
+}
+
+struct View { const float* p; int cs, coff; };
+
+int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, const float* res, int res_cs, int res_coff,
+         int flags, float* y, int y_cs, int y_coff) {
+  const ConvSpec& c = kConvs[id];
+  ConvDesc d;
+  d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.n_img = n_img; d.H = H; d.W = H; d.Ci = c.Ci;
+  d.w = h->conv_w[id]; d.bias = h->conv_b[id]; d.Co = c.Co; d.KH = c.K; d.KW = c.K; d.stride = c.stride; d.pad = c.pad;
+  d.res = res; d.res_cs = res_cs; d.res_coff = res_coff; d.flags = flags;
+  d.y = y; d.y_cs = y_cs; d.y_coff = y_coff;
+  const char* why = nullptr;
+  hipError_t e = conv2d_launch(d, st, &why);
+  if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + ": " + (why ? why : hipGetErrorString(e)));
+  return OFFK_OK;
+}
+#define TRY(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != OFFK_OK) return rc__; \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int offk_abi_version(void) { return OFFK_ABI_VERSION; }
+
+const char* offk_last_error(const offk_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int offk_create(const offk_config* cfg, offk_handle** out) {
+  if (!cfg || !out) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: null argument");
+  *out = nullptr;
+  if (cfg->batch < 1 || cfg->length < 2) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: need batch >= 1 and length >= 2");
+  if (cfg->variant != OFFK_VARIANT_RGB_LEARNED_DW && cfg->variant != OFFK_VARIANT_DIAG_SOBEL) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad variant");
+  if (cfg->slice_mode != OFFK_SLICE_REFERENCE_FLAT && cfg->slice_mode != OFFK_SLICE_PER_CLIP) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad slice_mode");
+  if (cfg->consensus != OFFK_CONSENSUS_NONE && cfg->consensus != OFFK_CONSENSUS_AVG) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad consensus");
+  if (cfg->feat_layout != OFFK_FEAT_NCHW && cfg->feat_layout != OFFK_FEAT_NHWC) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad feat_layout");
+  if (cfg->num_classes < 1 || cfg->num_classes > 4096) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad num_classes");
+  if ((long long)cfg->batch * cfg->length * 784 * 320 > 0x7fffffffLL) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: batch*length too large for one call; shard the clips");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, OFFK_ERR_NO_DEVICE, "offk_create: HIP device not available");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || !strstr(prop.gcnArchName, "gfx950"))
+    return fail(nullptr, OFFK_ERR_NO_DEVICE, "offk_create: device is not gfx950 (MI355X); this library has no other code path");
+
+  offk_handle* h = new offk_handle();
+  h->cfg = *cfg;
+  h->N = cfg->batch * cfg->length;
+  h->P = cfg->batch * (cfg->length - 1);
+  DeviceGuard guard(cfg->device);
+  int rc = OFFK_OK;
+  for (int s = 0; s < kNumSites && rc == OFFK_OK; ++s) {
+    const std::string n = kSites[s].name;
+    const int C = kSites[s].C;
+    add_slot(h, "motion_conv_gen_" + n + ".weight", {kGenCh, C, 1, 1}, SK_GEN_W, s);
+    add_slot(h, "motion_conv_gen_" + n + ".bias", {kGenCh}, SK_GEN_B, s);
+    add_slot(h, "motion_spatial_down_" + n + ".weight", {kDownCh, C, 1, 1}, SK_DOWN_W, s);
+    add_slot(h, "motion_spatial_down_" + n + ".bias", {kDownCh}, SK_DOWN_B, s);
+    rc = dev_alloc(h, &h->pw_w[s], (size_t)kUnitCh * C);
+    if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
+    if (cfg->variant == OFFK_VARIANT_RGB_LEARNED_DW && rc == OFFK_OK) {
+      add_slot(h, "motion_spatial_grad_" + n + ".weight", {kDownCh, 1, 3, 3}, SK_DW_W, s);
+      add_slot(h, "motion_spatial_grad_" + n + ".bias", {kDownCh}, SK_DW_B, s);
+      rc = dev_alloc(h, &h->dw_w[s], 9 * kDownCh);
+      if (rc == OFFK_OK) rc = dev_alloc(h, &h->dw_b[s], kDownCh);
+    }
+  }
+  if (cfg->variant == OFFK_VARIANT_DIAG_SOBEL && rc == OFFK_OK) {
+    add_slot(h, kSobelKey, {kDownCh, 1, 3, 3}, SK_SOBEL, 0);
+    rc = dev_alloc(h, &h->sobel_w, 9 * kDownCh);
+  }
+  for (int c = 0; c < kNumConvs && rc == OFFK_OK; ++c) {
+    const ConvSpec& cs = kConvs[c];
+    add_slot(h, std::string(cs.key) + ".weight", {cs.Co, cs.Ci, cs.K, cs.K}, SK_CONV_W, c);
+    add_slot(h, std::string(cs.key) + ".bias", {cs.Co}, SK_CONV_B, c);
+    rc = dev_alloc(h, &h->conv_w[c], (size_t)cs.Co * cs.Ci * cs.K * cs.K);
+    if (rc == OFFK_OK) rc = dev_alloc(h, &h->conv_b[c], cs.Co);
+  }
+  for (int k = 0; k < 3 && rc == OFFK_OK; ++k) {
+    add_slot(h, std::string(kHeads[k].key) + ".weight", {cfg->num_classes, kHeads[k].C}, SK_FC_W, k);
+    add_slot(h, std::string(kHeads[k].key) + ".bias", {cfg->num_classes}, SK_FC_B, k);
+    rc = dev_alloc(h, &h->fc_w[k], (size_t)cfg->num_classes * kHeads[k].C);
+    if (rc == OFFK_OK) rc = dev_alloc(h, &h->fc_b[k], cfg->num_classes);
+  }
+  if (rc != OFFK_OK) {
+    g_err = h->err;
+    offk_destroy(h);
+    return rc;
+  }
+  plan_workspace(h);
+  *out = h;
+  return OFFK_OK;
+}
+
+int offk_destroy(offk_handle* h) {
+  if (!h) return OFFK_OK;
+  DeviceGuard guard(h->cfg.device);
+  for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return OFFK_OK;
+}
+
+int offk_set_weight(offk_handle* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!h || !key || !data || !shape) return fail(h, OFFK_ERR_INVALID, "offk_set_weight: null argument");
+  std::string k(key);
+  if (k.compare(0, 7, "module.") == 0) k = k.substr(7);
+  auto it = h->index.find(k);
+  if (it == h->index.end()) return fail(h, OFFK_ERR_UNKNOWN_KEY, "offk_set_weight: not an OFF sub-network key for this variant: " + k);
+  Slot& s = h->slots[it->second];
+  bool ok = ndim == (int)s.shape.size();
+  size_t n = 1;
+  for (int i = 0; ok && i < ndim; ++i) { ok = shape[i] == s.shape[i]; n *= (size_t)s.shape[i]; }
+  if (!ok) return fail(h, OFFK_ERR_INVALID, "offk_set_weight: shape mismatch for " + k);
+  DeviceGuard guard(h->cfg.device);
+  const size_t bytes = n * sizeof(float);
+  auto copy = [&](float* dst) -> int {
+    HIP_TRY(h, hipMemcpy(dst, data, bytes, hipMemcpyDefault));
+    return OFFK_OK;
+  };
+  auto staged = [&](auto&& pack) -> int {   // copy to a temp device buffer, then run a packing kernel
+    void* tmp = nullptr;
+    HIP_TRY(h, hipMalloc(&tmp, bytes));
+    hipError_t e = hipMemcpy(tmp, data, bytes, hipMemcpyDefault);
+    if (e == hipSuccess) e = pack(static_cast<const float*>(tmp));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail_hip(h, e, "offk_set_weight pack");
+    return OFFK_OK;
+  };
+  int rc = OFFK_OK;
+  const int i = s.idx;
+  switch (s.kind) {
+    case SK_GEN_W: rc = copy(h->pw_w[i]); break;
+    case SK_DOWN_W: rc = copy(h->pw_w[i] + (size_t)kGenCh * kSites[i].C); break;
+    case SK_GEN_B: rc = copy(h->pw_b[i]); break;
+    case SK_DOWN_B: rc = copy(h->pw_b[i] + kGenCh); break;
+    case SK_DW_W: rc = staged([&](const float* t) { return repack_dw_launch(t, h->dw_w[i], nullptr); }); break;
+    case SK_DW_B: rc = copy(h->dw_b[i]); break;
+    case SK_SOBEL: rc = staged([&](const float* t) { return repack_dw_launch(t, h->sobel_w, nullptr); }); break;
+    case SK_CONV_W:
+      if (kConvs[i].K == 1) rc = copy(h->conv_w[i]);
+      else rc = staged([&](const float* t) { return pack_conv_weight_launch(t, kConvs[i].Co, kConvs[i].Ci, kConvs[i].K, kConvs[i].K, h->conv_w[i], nullptr); });
+      break;
+    case SK_CONV_B: rc = copy(h->conv_b[i]); break;
+    case SK_FC_W: rc = copy(h->fc_w[i]); break;
+    case SK_FC_B: rc = copy(h->fc_b[i]); break;
+  }
+  if (rc == OFFK_OK) s.set = true;
+  return rc;
+}
+
+int offk_missing_weights(const offk_handle* h, char* buf, size_t buflen) {
+  if (!h) return OFFK_ERR_INVALID;
+  int missing = 0;
+  for (const Slot& s : h->slots)
+    if (!s.set) {
+      if (missing == 0 && buf && buflen) snprintf(buf, buflen, "%s", s.key.c_str());
+      ++missing;
+    }
+  return missing;
+}
+
+size_t offk_workspace_bytes(const offk_handle* h) { return h ? h->ws_bytes : 0; }
+
+int offk_workspace_region(const offk_handle* h, const char* name, size_t* offset_bytes, size_t* nbytes) {
+  if (!h || !name) return OFFK_ERR_INVALID;
+  auto it = h->regions.find(name);
+  if (it == h->regions.end()) { h->err = std::string("unknown workspace region: ") + name; return OFFK_ERR_INVALID; }
+  if (offset_bytes) *offset_bytes = it->second.first;
+  if (nbytes) *nbytes = it->second.second;
+  return OFFK_OK;
+}
+
+int offk_set_profiling(offk_handle* h, int enable) {
+  if (!h) return OFFK_ERR_INVALID;
+  h->profiling = enable != 0;
+  return OFFK_OK;
+}
+
+int offk_stage_times(offk_handle* h, double ms[OFFK_NUM_STAGES], int64_t calls[OFFK_NUM_STAGES], int reset) {
+  if (!h || !ms || !calls) return fail(h, OFFK_ERR_INVALID, "offk_stage_times: null argument");
+  DeviceGuard guard(h->cfg.device);
+  const size_t per = OFFK_NUM_STAGES + 1;
+  for (int s = 0; s < OFFK_NUM_STAGES; ++s) { ms[s] = 0.0; calls[s] = 0; }
+  for (size_t g = 0; g < h->ev_used; ++g) {
+    hipEvent_t* ev = &h->events[g * per];
+    HIP_TRY(h, hipEventSynchronize(ev[OFFK_NUM_STAGES]));
+    for (int s = 0; s < OFFK_NUM_STAGES; ++s) {
+      float t = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&t, ev[s], ev[s + 1]));
+      ms[s] += t;
+      calls[s] += 1;
+    }
+  }
+  if (reset) h->ev_used = 0;
+  return OFFK_OK;
+}
+
+int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, float* G, float* D) {
+  if (!h || site < 0 || site >= kNumSites || !feat || !G || !D) return fail(h, OFFK_ERR_INVALID, "offk_pw_reduce: bad argument");
+  TRY(site_weights_ready(h, site, true, false));
+  DeviceGuard guard(h->cfg.device);
+  PwParams pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.nsites = 1; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
+  pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
+  fill_pw_site(h, site, feat, G, D, &pp.s[0]);
+  pp.total_blocks = pw_blocks_for(pp.s[0].M);
+  HIP_TRY(h, pw_reduce_launch(pp, static_cast<hipStream_t>(stream)));
+  return OFFK_OK;
+}
+
+int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, const float* D, float* M, int m_cstride,
+                     int m_coff, int algo) {
+  if (!h || site < 0 || site >= kNumSites || !G || !D || !M) return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: bad argument");
+  if (m_cstride % 4 || m_coff % 4 || m_coff < 0 || m_coff + kUnitCh > m_cstride || (algo != 0 && algo != 1))
+    return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: need 16-byte aligned channel slice of 160 channels inside m_cstride, algo in {0,1}");
+  TRY(site_weights_ready(h, site, false, true));
+  DeviceGuard guard(h->cfg.device);
+  StParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.nsites = 1; sp.B = h->cfg.batch; sp.L = h->cfg.length;
+  fill_st_site(h, site, G, D, M, m_cstride, m_coff, &sp.s[0]);
+  sp.total_blocks = h->cfg.batch * sp.s[0].strips;
+  HIP_TRY(h, sobel_tdiff_launch(sp, algo, static_cast<hipStream_t>(stream)));
+  return OFFK_OK;
+}
+
+int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace) {
+  if (!h || !feats || !workspace) return fail(h, OFFK_ERR_INVALID, "offk_off_units: null argument");
+  for (int s = 0; s < kNumSites; ++s) {
+    if (!feats[s]) return fail(h, OFFK_ERR_INVALID, "offk_off_units: null feature map");
+    TRY(site_weights_ready(h, s, true, true));
+  }
+  DeviceGuard guard(h->cfg.device);
+  return run_off_units(h, static_cast<hipStream_t>(stream), feats, workspace, nullptr);
+}
+
+int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], float* out7, float* out14,
+                 float* out28, void* workspace) {
+  if (!h || !feats || !out7 || !out14 || !workspace) return fail(h, OFFK_ERR_INVALID, "offk_forward: null argument");
+  for (int s = 0; s < kNumSites; ++s)
+    if (!feats[s]) return fail(h, OFFK_ERR_INVALID, "offk_forward: null feature map");
+  TRY(check_ready(h));
+  DeviceGuard guard(h->cfg.device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  void* ws = workspace;
+  const int P = h->P, ncls = h->cfg.num_classes;
+
+  hipEvent_t* ev = nullptr;
+  if (h->profiling) {
+    const size_t per = OFFK_NUM_STAGES + 1;
+    if ((h->ev_used + 1) * per > h->events.size() && h->events.size() < 4096 * per) {
+      for (size_t i = 0; i < per; ++i) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->events.push_back(e);
+      }
+    }
+    if ((h->ev_used + 1) * per <= h->events.size()) ev = &h->events[h->ev_used++ * per];
+  }
+
+  TRY(run_off_units(h, st, feats, ws, ev));
+
+  float* F28 = region(h, ws, "fusion_28");
+  float* F14 = region(h, ws, "fusion_14");
+  float* F7 = region(h, ws, "fusion_7");
+  const int RI = OFFK_CONV_RELU_IN_, RP = OFFK_CONV_RELU_PRE_, RO = OFFK_CONV_RELU_POST_;
+
+  // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
+  float *x0 = region(h, ws, "x0_28"), *t1 = region(h, ws, "t1_28"), *t2 = region(h, ws, "t2_28");
+  float *br = region(h, ws, "br_28"), *sa = region(h, ws, "sa_28"), *sb = region(h, ws, "sb_28");
+  TRY(conv(h, st, C_T28, P, 28, View{F28, 320, 0}, nullptr, 0, 0, 0, x0, 64, 0));              // :657 (pre-ReLU kept for the branch)
+  TRY(conv(h, st, C1_28A, P, 14, View{x0, 64, 0}, nullptr, 0, 0, RI | RP, t1, 64, 0));          // :658-660
+  TRY(conv(h, st, C2_28A, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, t2, 64, 0));               // :661-662
+  TRY(conv(h, st, CB_28A, P, 14, View{x0, 64, 0}, nullptr, 0, 0, 0, br, 256, 0));               // :665
+  TRY(conv(h, st, C3_28A, P, 14, View{t2, 64, 0}, br, 256, 0, RO, sa, 256, 0));                 // :663,666-667
+  TRY(conv(h, st, C1_28B, P, 14, View{sa, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));              // :670-671
+  TRY(conv(h, st, C2_28B, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, t2, 64, 0));               // :672-673
+  TRY(conv(h, st, C3_28B, P, 14, View{t2, 64, 0}, sa, 256, 0, RO, sb, 256, 0));                 // :674-676
+  TRY(conv(h, st, C1_28C, P, 14, View{sb, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));              // :679-680
+  TRY(conv(h, st, C2_28C, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, t2, 64, 0));               // :681-682
+  TRY(conv(h, st, C3_28C, P, 14, View{t2, 64, 0}, sb, 256, 0, RO, F14, 1056, 800));             // :683-685 -> cat at :760
+  if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
+
+  // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
+  float *x1 = region(h, ws, "x1_14"), *u1 = region(h, ws, "u1_14"), *u2 = region(h, ws, "u2_14");
+  float *ex = region(h, ws, "ex_14"), *s14 = region(h, ws, "sa_14");
+  TRY(conv(h, st, C_T14, P, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, x1, 128, 0));            // :762-763
+  TRY(conv(h, st, C1_14A, P, 7, View{x1, 128, 0}, nullptr, 0, 0, RP, u1, 128, 0));              // :764-765
+  TRY(conv(h, st, C2_14A, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, u2, 128, 0));              // :766-767
+  TRY(conv(h, st, CE_14A, P, 7, View{x1, 128, 0}, nullptr, 0, 0, 0, ex, 512, 0));               // :769
+  TRY(conv(h, st, C3_14A, P, 7, View{u2, 128, 0}, ex, 512, 0, RO, s14, 512, 0));                // :768,770-771
+  TRY(conv(h, st, C1_14B, P, 7, View{s14, 512, 0}, nullptr, 0, 0, RP, u1, 128, 0));             // :773-774
+  TRY(conv(h, st, C2_14B, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, u2, 128, 0));              // :775-776
+  TRY(conv(h, st, C3_14B, P, 7, View{u2, 128, 0}, s14, 512, 0, RP | RO, F7, 832, 320));         // :777-780 -> cat at :832
+  if (ev) HIP_TRY(h, hipEventRecord(ev[4], st));
+
+  // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
+  float *x2 = region(h, ws, "x2_7"), *v1 = region(h, ws, "v1_7"), *v2 = region(h, ws, "v2_7");
+  float *b7 = region(h, ws, "br_7"), *s7 = region(h, ws, "sum_7");
+  TRY(conv(h, st, C_T7, P, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, x2, 256, 0));                // :833-834
+  TRY(conv(h, st, C1_7, P, 7, View{x2, 256, 0}, nullptr, 0, 0, RP, v1, 256, 0));                // :835-836
+  TRY(conv(h, st, C2_7, P, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, v2, 256, 0));                // :837-838
+  TRY(conv(h, st, CB_7, P, 7, View{x2, 256, 0}, nullptr, 0, 0, 0, b7, 1024, 0));                // :840
+  TRY(conv(h, st, C3_7, P, 7, View{v2, 256, 0}, b7, 1024, 0, 0, s7, 1024, 0));                  // :839,841 (no ReLU)
+  if (ev) HIP_TRY(h, hipEventRecord(ev[5], st));
+
+  // ---- heads (+ consensus) ------------------------------------------------------------
+  const bool cons = h->cfg.consensus == OFFK_CONSENSUS_AVG;
+  float* l7 = cons ? region(h, ws, "logit_7") : out7;
+  float* l14 = cons ? region(h, ws, "logit_14") : out14;
+  float* l28 = cons ? region(h, ws, "logit_28") : out28;
+  const char* why = nullptr;
+  hipError_t e;
+  e = head_launch(s7, 1024, 0, P, 7, 7, 1024, 0, h->fc_w[0], h->fc_b[0], ncls, l7, st, &why);   // :843-847
+  if (e != hipSuccess) return fail_hip(h, e, "head 7");
+  e = head_launch(F7, 832, 320, P, 7, 7, 512, 0, h->fc_w[2], h->fc_b[2], ncls, l14, st, &why);  // :789-793
+  if (e != hipSuccess) return fail_hip(h, e, "head 14");
+  if (out28) {
+    e = head_launch(F14, 1056, 800, P, 14, 14, 256, 1, h->fc_w[1], h->fc_b[1], ncls, l28, st, &why);  // :782-787
+    if (e != hipSuccess) return fail_hip(h, e, "head 28");
+  }
+  if (cons) {
+    const int B = h->cfg.batch, T = h->cfg.length - 1;
+    HIP_TRY(h, consensus_launch(l7, B, T, ncls, out7, st));                                       // Flow_OFF.py:874
+    HIP_TRY(h, consensus_launch(l14, B, T, ncls, out14, st));                                     // Flow_OFF.py:876
+    if (out28) HIP_TRY(h, consensus_launch(l28, B, T, ncls, out28, st));                          // Flow_OFF.py:875
+  }
+  if (ev) HIP_TRY(h, hipEventRecord(ev[6], st));
+  return OFFK_OK;
+}
+
+int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci, const float* w,
+                const float* bias, int Co, int KH, int KW, int stride, int pad, const float* res, int res_cstride,
+                int res_coff, int flags, float* y, int y_cstride, int y_coff) {
+  if (!x || !w || !y || n_img < 1 || H < 1 || W < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_conv2d: bad argument");
+  ConvDesc d;
+  d.x = x; d.x_cs = x_cstride; d.x_coff = x_coff; d.n_img = n_img; d.H = H; d.W = W; d.Ci = Ci;
+  d.w = w; d.bias = bias; d.Co = Co; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad;
+  d.res = res; d.res_cs = res_cstride; d.res_coff = res_coff; d.flags = flags; d.y = y; d.y_cs = y_cstride; d.y_coff = y_coff;
+  const char* why = nullptr;
+  hipError_t e = conv2d_launch(d, static_cast<hipStream_t>(stream), &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  return OFFK_OK;
+}
+
+int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_ohwi) {
+  if (!w_oihw || !w_ohwi || Co < 1 || Ci < 1 || KH < 1 || KW < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_pack_conv_weight: bad argument");
+  hipError_t e = pack_conv_weight_launch(w_oihw, Co, Ci, KH, KW, w_ohwi, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_pack_conv_weight");
+  return OFFK_OK;
+}
+
+int offk_head(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int C, int maxpool,
+              const float* fc_w, const float* fc_b, int num_classes, float* out) {
+  if (!x || !fc_w || !fc_b || !out) return fail(nullptr, OFFK_ERR_INVALID, "offk_head: null argument");
+  const char* why = nullptr;
+  hipError_t e = head_launch(x, x_cstride, x_coff, n_img, H, W, C, maxpool, fc_w, fc_b, num_classes, out,
+                             static_cast<hipStream_t>(stream), &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  return OFFK_OK;
+}
+
+int offk_segment_consensus(void* stream, const float* x, int B, int T, int C, float* out) {
+  if (!x || !out || B < 1 || T < 1 || C < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_segment_consensus: bad argument");
+  hipError_t e = consensus_launch(x, B, T, C, out, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_segment_consensus");
+  return OFFK_OK;
+}
+
+int offk_nchw_to_nhwc(void* stream, const float* src, int n_img, int C, int HW, float* dst) {
+  if (!src || !dst || n_img < 1 || n_img > 65535 || C < 1 || HW < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_nchw_to_nhwc: bad argument");
+  hipError_t e = nchw_to_nhwc_launch(src, n_img, C, HW, dst, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_nchw_to_nhwc");
+  return OFFK_OK;
+}
+
+int offk_nhwc_to_nchw(void* stream, const float* src, int cstride, int coff, int n_img, int C, int HW, float* dst) {
+  if (!src || !dst || n_img < 1 || n_img > 65535 || C < 1 || HW < 1 || coff < 0 || coff + C > cstride)
+    return fail(nullptr, OFFK_ERR_INVALID, "offk_nhwc_to_nchw: bad argument");
+  hipError_t e = nhwc_to_nchw_launch(src, cstride, coff, n_img, C, HW, dst, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_nhwc_to_nchw");
+  return OFFK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Shared device-side building blocks for liboffk (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace offk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------
+// fp32 MFMA tile core.
+//
+// v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// D[i][j] lives in lane (j + 32*((i>>2)&1)), register (i&3) + 4*(i>>3).
+// Both LDS tiles are stored row-major [row][k] with a row stride of LDS_K floats
+// (BK = 32 plus 4 pad words): every global->LDS store and LDS->register load is 16 B
+// wide, and the 36-word stride makes the ds_read_b128 of 16 consecutive rows
+// conflict-free (36*i mod 64 takes 16 distinct multiples of 4).  A lane reads FOUR
+// consecutive k of its row at once; MFMA step e of group g therefore multiplies
+// k = 8g+e (lanes 0-31) and k = 8g+4+e (lanes 32-63).  A and B use the same
+// permutation of k, so the contraction is unchanged (only the fp32 summation order
+// differs from a k-ascending loop).
+// ---------------------------------------------------------------------------------
+constexpr int BK = 32;
+constexpr int LDS_K = BK + 4;
+
+template <int TM, int TN>
+struct WaveAcc {
+  f32x16 acc[TM][TN];
+
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
+
+  // As / Bs: first LDS row of this wave's A / B slab.
+  __device__ __forceinline__ void mma_ktile(const float* As, const float* Bs, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+        a[t] = *reinterpret_cast<const float4*>(As + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        b[t] = *reinterpret_cast<const float4*>(Bs + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+        }
+    }
+  }
+};
+
+// row (M index) of accumulator register `reg` for a lane in half `h` (lane>>5)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+
+}  // namespace offk

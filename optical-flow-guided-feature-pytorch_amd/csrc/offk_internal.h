@@ -1,0 +1,71 @@
+// Host-side declarations shared by the liboffk translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace offk {
+
+constexpr int OFFK_CONV_RELU_IN_ = 1, OFFK_CONV_RELU_PRE_ = 2, OFFK_CONV_RELU_POST_ = 4;
+constexpr int kNumSites = 9;
+constexpr int kGenCh = 128, kDownCh = 32, kUnitCh = 160;
+
+// ---- K4 ------------------------------------------------------------------------
+struct ConvDesc {
+  const float* x; int x_cs, x_coff;
+  int n_img, H, W, Ci;
+  const float* w; const float* bias;
+  int Co, KH, KW, stride, pad;
+  const float* res; int res_cs, res_coff;
+  int flags;
+  float* y; int y_cs, y_coff;
+};
+hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
+hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st);
+
+// ---- K1 ------------------------------------------------------------------------
+struct PwSite {
+  const float* x;     // feature map, NCHW [N][C][HW] or NHWC [N*HW][C]
+  const float* w;     // stacked [160][C]: rows 0-127 motion_conv_gen, 128-159 motion_spatial_down
+  const float* bias;  // [160]
+  float* G;           // [N*HW][128]
+  float* D;           // [P*HW][32]
+  int C, HW, M;       // M = N*HW rows
+  int blk_begin;      // first block of this site in the grouped grid
+};
+struct PwParams {
+  PwSite s[kNumSites];
+  int nsites, total_blocks;
+  int L, P, slice_mode, nhwc;
+};
+int pw_blocks_for(int M);
+hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st);
+
+// ---- K2 ------------------------------------------------------------------------
+struct StSite {
+  const float* G;     // [N*HW][128]
+  const float* D;     // [P*HW][32]
+  const float* dw;    // [9][32] tap-major depthwise weights
+  const float* db;    // [32] bias or nullptr
+  float* M;           // fusion buffer, channels-last
+  int H, m_cs, m_coff;
+  int strips, rows;   // strips per plane, rows per strip
+  int blk_begin;
+};
+struct StParams {
+  StSite s[kNumSites];
+  int nsites, total_blocks;
+  int B, L;
+};
+void st_plan(int H, int* strips, int* rows);
+hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st);
+
+// ---- K5 / K6 / layout helpers ----------------------------------------------------
+hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, const float* fw,
+                       const float* fb, int ncls, float* out, hipStream_t st, const char** why);
+hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hipStream_t st);
+hipError_t nchw_to_nhwc_launch(const float* src, int n_img, int C, int HW, float* dst, hipStream_t st);
+hipError_t nhwc_to_nchw_launch(const float* src, int cs, int coff, int n_img, int C, int HW, float* dst, hipStream_t st);
+hipError_t repack_dw_launch(const float* w_c33, float* w_tap_c, hipStream_t st);  // [32][1][3][3] -> [9][32]
+
+}  // namespace offk

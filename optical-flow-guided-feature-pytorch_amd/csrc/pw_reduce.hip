@@ -1,0 +1,199 @@
+// K1: the OFF units' two 1x1 "reduce" convolutions, stacked and grouped.
+//
+// Stands for, per tap site s (reference RGB_OFF.py, site 3a lines; the other eight are
+// identical up to names):
+//   G = relu(motion_conv_gen_s(X))            :597-598  on all N = B*L frames
+//   D = motion_spatial_down_s(X[:B*(L-1)])    :609-610  on the sliced frames (quirk Q1)
+// Both are C -> {128, 32} pointwise contractions of the same feature map, so their
+// weights are stacked into one [160][C] matrix and X is read from HBM once.  All nine
+// sites run in ONE grouped launch (a block looks its site up in a 9-entry table), so the
+// 7x7 sites (172 blocks at B=64) fill the chip together with the 28x28 ones.
+//
+// GEMM view: rows m = (frame, pixel) flattened, K = C, N = 160.  X is NCHW at the
+// boundary ([frame][c][pixel]: for one k the rows are contiguous), so the loader reads
+// 4 k-rows x 4 pixels per thread with 16-B loads and transposes in registers into the
+// [row][k] LDS image the MFMA core wants.  Outputs are channels-last:
+//   G [N*HW][128] (post-ReLU), D [P*HW][32] (row = output pair index).
+#include "offk_common.h"
+#include "offk_internal.h"
+
+namespace offk {
+
+constexpr int PW_BM = 128, PW_BN = 160, PW_TN = 5;
+
+int pw_blocks_for(int M) { return (M + PW_BM - 1) / PW_BM; }
+
+// output-pair row of frame f for the spatial branch, or -1 (see spatial_frames in the oracle)
+__device__ __forceinline__ int down_row(int f, int L, int P, int slice_mode) {
+  if (slice_mode == 0) return f < P ? f : -1;
+  int b = f / L, t = f - b * L;
+  return t < L - 1 ? b * (L - 1) + t : -1;
+}
+
+template <int NT>
+__device__ __forceinline__ void pw_mma(f32x16 (&acc)[PW_TN], const float* As, const float* Bs, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll 1
+  for (int g = 0; g < BK / 8; ++g) {
+    float4 a = *reinterpret_cast<const float4*>(As + r * LDS_K + 8 * g + 4 * h);
+    float4 b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
+  __shared__ __attribute__((aligned(16))) float As[PW_BM * LDS_K];
+  __shared__ __attribute__((aligned(16))) float Bs[PW_BN * LDS_K];
+
+  // block -> site: field-wise scalar select chain over the (few) table entries; indexing
+  // the by-value kernarg array with a runtime index (or copying a whole entry) goes
+  // through scratch memory
+  PwSite S;
+  S.x = p.s[0].x; S.w = p.s[0].w; S.bias = p.s[0].bias; S.G = p.s[0].G; S.D = p.s[0].D;
+  S.C = p.s[0].C; S.HW = p.s[0].HW; S.M = p.s[0].M; S.blk_begin = p.s[0].blk_begin;
+#pragma unroll
+  for (int i = 1; i < kNumSites; ++i)
+    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) {
+      S.x = p.s[i].x; S.w = p.s[i].w; S.bias = p.s[i].bias; S.G = p.s[i].G; S.D = p.s[i].D;
+      S.C = p.s[i].C; S.HW = p.s[i].HW; S.M = p.s[i].M; S.blk_begin = p.s[i].blk_begin;
+    }
+  const int C = S.C, HW = S.HW, M = S.M;
+  const int m0 = ((int)blockIdx.x - S.blk_begin) * PW_BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // is any row of this block a source frame of the spatial branch?
+  bool down_active;
+  {
+    int f_first = m0 / HW;
+    int m_last = min(m0 + PW_BM, M) - 1;
+    int f_last = m_last / HW;
+    down_active = false;
+    for (int f = f_first; f <= f_last; ++f) down_active |= down_row(f, p.L, p.P, p.slice_mode) >= 0;
+  }
+
+  // ---- loader setup -----------------------------------------------------------
+  // mode 0: NCHW, HW % 4 == 0 : thread = (pixel quad pq = tid&31, k quad kq = tid>>5)
+  // mode 1: NCHW, any HW      : thread = (pixel i = tid&127, k quads (tid>>7) + 2r)
+  // mode 2: channels-last     : thread = (rows (tid>>3)+32r, k quad tid&7)
+  const int mode = p.nhwc ? 2 : ((HW & 3) == 0 ? 0 : 1);
+  const float* base;
+  bool row_ok;
+  if (mode == 0) {
+    int m = m0 + 4 * (tid & 31);
+    row_ok = m < M;                       // M % 4 == 0 here, so the quad is all-in or all-out
+    int mm = row_ok ? m : 0;
+    int n = mm / HW, pix = mm - n * HW;
+    base = S.x + ((size_t)n * C + 4 * (tid >> 5)) * HW + pix;
+  } else if (mode == 1) {
+    int m = m0 + (tid & 127);
+    row_ok = m < M;
+    int mm = row_ok ? m : 0;
+    int n = mm / HW, pix = mm - n * HW;
+    base = S.x + ((size_t)n * C + 4 * (tid >> 7)) * HW + pix;
+  } else {
+    base = S.x + (size_t)(m0 + (tid >> 3)) * C + 4 * (tid & 7);
+    row_ok = true;  // checked per row below
+  }
+
+  float4 rg[4 + PW_TN];   // prefetch registers: 4 x A, then 5 x B (one array: two arrays end up in scratch)
+  const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
+  auto load_tile = [&](int k0) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rg[j] = z;
+        if (row_ok) rg[j] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + j) * HW);
+      }
+    } else if (mode == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* q = base + (size_t)(k0 + 8 * r) * HW;
+        rg[r] = z;
+        if (row_ok) rg[r] = make_float4(q[0], q[HW], q[2 * (size_t)HW], q[3 * (size_t)HW]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rg[r] = z;
+        if (m0 + (tid >> 3) + 32 * r < M) rg[r] = *reinterpret_cast<const float4*>(base + (size_t)32 * r * C + k0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < PW_TN; ++r)
+      rg[4 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
+  };
+  auto store_tile = [&]() {
+    if (mode == 0) {
+      float* dst = As + 4 * (tid & 31) * LDS_K + 4 * (tid >> 5);
+      *reinterpret_cast<float4*>(dst) = make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x);
+      *reinterpret_cast<float4*>(dst + LDS_K) = make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y);
+      *reinterpret_cast<float4*>(dst + 2 * LDS_K) = make_float4(rg[0].z, rg[1].z, rg[2].z, rg[3].z);
+      *reinterpret_cast<float4*>(dst + 3 * LDS_K) = make_float4(rg[0].w, rg[1].w, rg[2].w, rg[3].w);
+    } else if (mode == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(As + (tid & 127) * LDS_K + 4 * ((tid >> 7) + 2 * r)) = rg[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < PW_TN; ++r)
+      *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[4 + r];
+  };
+
+  f32x16 acc[PW_TN];
+#pragma unroll
+  for (int t = 0; t < PW_TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nkt = C / BK;
+  load_tile(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+    if (down_active) pw_mma<5>(acc, As + wave * 32 * LDS_K, Bs, lane);
+    else pw_mma<4>(acc, As + wave * 32 * LDS_K, Bs, lane);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------
+  const int r32 = lane & 31, h = lane >> 5;
+  float bv[PW_TN];
+#pragma unroll
+  for (int t = 0; t < PW_TN; ++t) bv[t] = S.bias[t * 32 + r32];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + wave * 32 + acc_row(reg, h);
+    if (m < M) {
+      float* g = S.G + (size_t)m * kGenCh + r32;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g[t * 32] = fmaxf(acc[t][reg] + bv[t], 0.f);
+      if (down_active) {
+        int f = m / HW, pix = m - f * HW;
+        int dr = down_row(f, p.L, p.P, p.slice_mode);
+        if (dr >= 0) S.D[((size_t)dr * HW + pix) * kDownCh + r32] = acc[4][reg] + bv[4];
+      }
+    }
+  }
+}
+
+hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st) {
+  if (p.total_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pw_reduce_kernel, dim3(p.total_blocks), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace offk

@@ -1,0 +1,227 @@
+"""Thin PyTorch-ROCm host wrapper around the liboffk handle.
+
+PyTorch is plumbing here (device memory, the current HIP stream); all arithmetic runs
+in liboffk's HIP kernels.  Nothing in this file computes on the CPU and nothing falls
+back to torch ops.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, spec
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_dev(t, name, device):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous fp32 CUDA/HIP tensor" % name)
+    if t.device != device:
+        raise ValueError("%s lives on %s, handle on %s" % (name, t.device, device))
+
+
+class OffForward:
+    """One liboffk handle for a fixed (batch, length, variant).
+
+    Stands for the OFF part of BNInception_OFF (reference RGB_OFF.py:265-358 declarations,
+    :596-860 forward; Flow_OFF.py:606-887).
+    """
+
+    def __init__(self, batch, length, variant=spec.VARIANT_RGB, slice_mode=spec.SLICE_FLAT,
+                 consensus=None, num_classes=spec.NUM_CLASSES, feat_layout=0, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.OffkError("no HIP device visible: the OFF forward has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if consensus is None:  # reference default: only the Flow / v2 files apply it
+            consensus = variant == spec.VARIANT_FLOW
+        self.batch, self.length, self.variant = int(batch), int(length), int(variant)
+        self.slice_mode, self.consensus, self.num_classes = int(slice_mode), bool(consensus), int(num_classes)
+        self.feat_layout = int(feat_layout)
+        self.N = self.batch * self.length
+        self.P = self.batch * (self.length - 1)
+        cfg = _lib.OffkConfig(self.batch, self.length, self.variant, self.slice_mode, int(self.consensus),
+                              self.num_classes, self.feat_layout, self.device.index or 0)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.offk_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.offk_destroy(h)
+            self._h = None
+
+    # ---- weights ----------------------------------------------------------------
+    def set_weight(self, key, value):
+        if torch.is_tensor(value):
+            t = value.detach().to(dtype=torch.float32).contiguous()
+            shape = tuple(t.shape)
+            ptr, keep = ctypes.c_void_p(t.data_ptr()), t
+        else:
+            a = np.ascontiguousarray(value, dtype=np.float32)
+            shape = a.shape
+            ptr, keep = ctypes.c_void_p(a.ctypes.data), a
+        arr = (ctypes.c_int64 * len(shape))(*shape)
+        _lib.check(self.lib.offk_set_weight(self._h, key.encode(), ptr, arr, len(shape)), self._h)
+        del keep
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts a reference-format state_dict (extra backbone keys are ignored;
+        a 'module.' prefix is accepted, test_flow_off.py:52-58)."""
+        want = spec.weight_shapes(self.variant)
+        seen = set()
+        for k, v in state_dict.items():
+            kk = k[7:] if k.startswith("module.") else k
+            if kk in want:
+                self.set_weight(kk, v)
+                seen.add(kk)
+        missing = [k for k in want if k not in seen]
+        if strict and missing:
+            raise KeyError("missing OFF weights: %s" % ", ".join(missing[:5]))
+        return missing
+
+    def missing_weights(self):
+        buf = ctypes.create_string_buffer(256)
+        n = self.lib.offk_missing_weights(self._h, buf, 256)
+        return n, buf.value.decode()
+
+    # ---- workspace ----------------------------------------------------------------
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.offk_workspace_bytes(self._h))
+
+    @property
+    def workspace(self):
+        if self._ws is None:
+            self._ws = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def region(self, name, channels):
+        """View of a named workspace region as [rows, channels] fp32 (channels-last)."""
+        off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.lib.offk_workspace_region(self._h, name.encode(), ctypes.byref(off), ctypes.byref(nb)), self._h)
+        flat = self.workspace[off.value:off.value + nb.value].view(torch.float32)
+        return flat.view(-1, channels)
+
+    # ---- forward --------------------------------------------------------------------
+    def out_rows(self):
+        return self.batch if self.consensus else self.P
+
+    def _feat_array(self, feats):
+        if len(feats) != spec.NUM_SITES:
+            raise ValueError("need nine feature maps")
+        shapes = spec.feature_shapes(self.batch, self.length)
+        for i, (f, s) in enumerate(zip(feats, shapes)):
+            _check_dev(f, "feats[%d]" % i, self.device)
+            want = s if self.feat_layout == 0 else (s[0], s[2], s[3], s[1])
+            if tuple(f.shape) != tuple(want):
+                raise ValueError("feats[%d] has shape %s, expected %s" % (i, tuple(f.shape), tuple(want)))
+        return (ctypes.c_void_p * spec.NUM_SITES)(*[f.data_ptr() for f in feats])
+
+    def forward(self, feats, want28=True):
+        arr = self._feat_array(feats)
+        rows = self.out_rows()
+        out7 = torch.empty(rows, self.num_classes, dtype=torch.float32, device=self.device)
+        out14 = torch.empty_like(out7)
+        out28 = torch.empty_like(out7) if want28 else None
+        _lib.check(self.lib.offk_forward(self._h, _stream(), arr, _ptr(out7), _ptr(out14), _ptr(out28),
+                                         _ptr(self.workspace)), self._h)
+        return out7, out14, out28
+
+    def forward_into(self, feat_array, out7, out14, out28):
+        """Launch-only variant for benchmarking: pre-validated ctypes array + outputs."""
+        _lib.check(self.lib.offk_forward(self._h, _stream(), feat_array, _ptr(out7), _ptr(out14), _ptr(out28),
+                                         _ptr(self.workspace)), self._h)
+
+    def off_units(self, feats):
+        arr = self._feat_array(feats)
+        _lib.check(self.lib.offk_off_units(self._h, _stream(), arr, _ptr(self.workspace)), self._h)
+
+    # ---- stage entry points -----------------------------------------------------------
+    def pw_reduce(self, site, feat):
+        _name, _C, H = spec.SITES[site]
+        G = torch.empty(self.N * H * H, spec.GEN_CH, dtype=torch.float32, device=self.device)
+        D = torch.zeros(self.P * H * H, spec.DOWN_CH, dtype=torch.float32, device=self.device)
+        _check_dev(feat, "feat", self.device)
+        _lib.check(self.lib.offk_pw_reduce(self._h, _stream(), site, _ptr(feat), _ptr(G), _ptr(D)), self._h)
+        return G, D
+
+    def sobel_tdiff(self, site, G, D, M, m_coff, algo=0):
+        _check_dev(G, "G", self.device)
+        _check_dev(D, "D", self.device)
+        _check_dev(M, "M", self.device)
+        _lib.check(self.lib.offk_sobel_tdiff(self._h, _stream(), site, _ptr(G), _ptr(D), _ptr(M),
+                                             M.shape[-1], m_coff, algo), self._h)
+
+    # ---- profiling ---------------------------------------------------------------------
+    def set_profiling(self, on):
+        _lib.check(self.lib.offk_set_profiling(self._h, int(bool(on))), self._h)
+
+    def stage_times(self, reset=True):
+        ms = (ctypes.c_double * _lib.NUM_STAGES)()
+        calls = (ctypes.c_int64 * _lib.NUM_STAGES)()
+        _lib.check(self.lib.offk_stage_times(self._h, ms, calls, int(reset)), self._h)
+        return dict((n, (ms[i], int(calls[i]))) for i, n in enumerate(_lib.STAGE_NAMES))
+
+
+# ---- handle-less stage kernels (channels-last tensors) ----------------------------------
+def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=None, y=None, y_coff=0):
+    """x: [n, H, W, Cs] fp32 CUDA; uses channels [x_coff, x_coff+Ci).  Returns y [n, Ho, Wo, Co]
+    (or writes channels [y_coff, y_coff+Co) of the given y)."""
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    Co, Ci, KH, KW = w_oihw.shape
+    wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_pack_conv_weight(_stream(), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    if y is None:
+        y = torch.empty(n, Ho, Wo, Co, dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_conv2d(_stream(), _ptr(x), cs, x_coff, n, H, W, Ci, _ptr(wp), _ptr(bias), Co, KH, KW,
+                               stride, pad, _ptr(res), res.shape[-1] if res is not None else 0, 0, flags,
+                               _ptr(y), y.shape[-1], y_coff))
+    return y
+
+
+def head(x, fc_w, fc_b, maxpool, x_coff=0, c=None):
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    C = cs if c is None else c
+    out = torch.empty(n, fc_w.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_head(_stream(), _ptr(x), cs, x_coff, n, H, W, C, int(maxpool), _ptr(fc_w.contiguous()),
+                             _ptr(fc_b.contiguous()), fc_w.shape[0], _ptr(out)))
+    return out
+
+
+def segment_consensus(x, batch):
+    lib = _lib.load()
+    T = x.shape[0] // batch
+    out = torch.empty(batch, x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_segment_consensus(_stream(), _ptr(x.contiguous()), batch, T, x.shape[1], _ptr(out)))
+    return out
+
+
+def nchw_to_nhwc(x):
+    lib = _lib.load()
+    n, C, H, W = x.shape
+    out = torch.empty(n, H, W, C, dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_nchw_to_nhwc(_stream(), _ptr(x.contiguous()), n, C, H * W, _ptr(out)))
+    return out
+
+
+def nhwc_to_nchw(x, coff=0, c=None):
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    C = cs - coff if c is None else c
+    out = torch.empty(n, C, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_nhwc_to_nchw(_stream(), _ptr(x), cs, coff, n, C, H * W, _ptr(out)))
+    return out
