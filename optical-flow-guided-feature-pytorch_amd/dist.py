@@ -1,0 +1,63 @@
+"""Clip sharding over the GPUs of one node and the one collective on the path.
+
+The reference only knows nn.DataParallel (Flow_OFF.py:1415, model_utils.py:350) and has
+no explicit collective.  The OFF forward shards over clips (temporal coupling never
+crosses a clip, RGB_OFF.py:600-603): rank r owns a contiguous block of clips, runs the
+whole forward locally with replicated weights, and the only exchange is the per-clip
+score tensors at the end -- one RCCL all-gather over xGMI ([B/G, 101] x heads, <= 620 KB:
+latency-bound, so a single fused collective rather than one per head).
+
+Parity note (quirk Q1, RGB_OFF.py:609): in reference_flat slice mode the result of a
+forward depends on how clips are grouped into a call, so the sharded result equals the
+reference called with batch = B/G on each shard (what DataParallel would have had to do),
+not the reference called once with batch = B.  In per_clip mode both coincide.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_clips, world, rank):
+    """Contiguous block of clips owned by ``rank``: (first_clip, n_clips).  Requires an even split,
+    as every rank's handle is built for the same (batch, length)."""
+    if total_clips % world:
+        raise ValueError("clips (%d) must divide evenly over %d ranks" % (total_clips, world))
+    n = total_clips // world
+    return rank * n, n
+
+
+def shard_features(feats, total_clips, length, world, rank):
+    """Slice each [B*L, ...] feature map down to this rank's frames (views, no copy)."""
+    first, n = shard_range(total_clips, world, rank)
+    return [f[first * length:(first + n) * length] for f in feats]
+
+
+def gather_scores(local, group=None):
+    """local: [heads, b, classes] (or [b, classes]) per-clip consensus scores of this rank.
+    Returns the same with b -> B = world*b, clips in global order, on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    squeeze = local.dim() == 2
+    x = local.unsqueeze(0) if squeeze else local
+    x = x.contiguous()
+    heads, b, c = x.shape
+    buf = torch.empty(world, heads, b, c, dtype=x.dtype, device=x.device)
+    if x.is_cuda:
+        dist.all_gather_into_tensor(buf.view(world * heads * b, c), x.view(heads * b, c), group=group)
+    else:  # gloo (CPU tests): list form
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x, group=group)
+        buf = torch.stack(parts, 0)
+    out = buf.permute(1, 0, 2, 3).reshape(heads, world * b, c)
+    return out[0] if squeeze else out
+
+
+def fuse_scores_allreduce(weighted_local, group=None):
+    """Late two-stream fusion when the RGB and Flow streams live on different ranks
+    (score_fusion.ipynb lines 300-301: sum_i w_i * score_i): every rank passes its own
+    pre-weighted [B, classes] contribution; a sum all-reduce yields the fused scores."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return weighted_local
+    out = weighted_local.contiguous().clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out

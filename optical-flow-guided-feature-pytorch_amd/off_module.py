@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's model interface for the OFF path.
+
+The reference has no module boundary around the OFF sub-network (it is inline in
+BNInception_OFF.RGB_OFF_forward, RGB_OFF.py:360-860, and BNInception_OFF.forward,
+Flow_OFF.py:370-887).  This file provides
+
+* ``OFFSubNetwork`` -- an nn.Module that owns the OFF parameters under the reference's
+  exact state_dict key names (so reference-format checkpoints load) and whose forward
+  takes the nine tapped feature maps and runs liboffk;
+* ``BNInception_OFF`` / ``bninception_off`` -- same constructor arguments, attributes
+  (``batch``, ``length``, ``modality_fuse``, ``consensus_type``) and return conventions
+  as the reference classes (RGB_OFF.py:32,860,1346-1360; Flow_OFF.py:45,879-884,
+  1371-1385; RGB_OFF_v2.py:891), with the TSN backbone supplied by the caller as an
+  ordinary PyTorch module (it is out of scope and stays on stock PyTorch-ROCm).
+
+The nn.Conv2d / nn.Linear children are parameter containers only: they are never
+called.  All arithmetic happens in the HIP library; without it every forward raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import runtime, spec
+
+_VARIANTS = {"rgb": spec.VARIANT_RGB, "flow": spec.VARIANT_FLOW, "rgb_v2": spec.VARIANT_FLOW}
+
+
+class _SobelHolder(nn.Module):
+    """state_dict key 'sobel_edge_diagonal.conv.weight' (util.py:52-77): frozen diagonal kernel."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(spec.DOWN_CH, spec.DOWN_CH, 3, 1, 1, bias=False, groups=spec.DOWN_CH)
+        k = torch.tensor(spec.DIAG_SOBEL, dtype=torch.float32)
+        self.conv.weight = nn.Parameter(k.expand(spec.DOWN_CH, 1, 3, 3).clone(), requires_grad=False)
+
+
+class OFFSubNetwork(nn.Module):
+    def __init__(self, num_classes=spec.NUM_CLASSES, batch=16, length=7, variant="rgb",
+                 slice_mode=spec.SLICE_FLAT, consensus=None, feat_layout=0):
+        super().__init__()
+        if variant not in _VARIANTS:
+            raise ValueError("variant must be one of %s" % sorted(_VARIANTS))
+        self.variant_name = variant
+        self.variant = _VARIANTS[variant]
+        self.batch, self.length, self.num_classes = batch, length, num_classes
+        self.slice_mode, self.feat_layout = slice_mode, feat_layout
+        self.consensus_avg = (self.variant == spec.VARIANT_FLOW) if consensus is None else bool(consensus)
+        # parameter containers, names and shapes as in the reference (RGB_OFF.py:265-334, Flow_OFF.py:51)
+        for name, C, _H in spec.SITES:
+            setattr(self, "motion_conv_gen_" + name, nn.Conv2d(C, spec.GEN_CH, 1, 1))
+            setattr(self, "motion_spatial_down_" + name, nn.Conv2d(C, spec.DOWN_CH, 1, 1))
+            if self.variant == spec.VARIANT_RGB:
+                setattr(self, "motion_spatial_grad_" + name,
+                        nn.Conv2d(spec.DOWN_CH, spec.DOWN_CH, 3, 1, 1, groups=spec.DOWN_CH, bias=True))
+        if self.variant == spec.VARIANT_FLOW:
+            self.sobel_edge_diagonal = _SobelHolder()
+        for key, co, ci, k, s, p in spec.FUSION_CONVS:
+            setattr(self, key, nn.Conv2d(ci, co, k, s, p))
+        for key, cin in spec.HEADS:
+            setattr(self, key, nn.Linear(cin, num_classes))
+        self._rt = None
+        self._rt_key = None
+        self._dirty = True
+
+    # -- weights -> library ---------------------------------------------------------
+    def mark_weights_dirty(self):
+        self._dirty = True
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        own = set(self.state_dict().keys())
+        sd = {}
+        for k, v in state_dict.items():
+            kk = k[7:] if k.startswith("module.") else k     # DataParallel checkpoints (test_flow_off.py:52-58)
+            if kk in own:
+                sd[kk] = v
+        missing = sorted(own - set(sd))
+        if strict and missing:
+            raise KeyError("missing OFF weights: %s" % ", ".join(missing[:5]))
+        out = super().load_state_dict(sd, strict=False, **kw)
+        self._dirty = True
+        return out
+
+    def _handle(self, device):
+        key = (self.batch, self.length, self.variant, self.slice_mode, self.consensus_avg, self.feat_layout, str(device))
+        if self._rt is None or self._rt_key != key:
+            self._rt = runtime.OffForward(self.batch, self.length, self.variant, self.slice_mode,
+                                          self.consensus_avg, self.num_classes, self.feat_layout, device)
+            self._rt_key = key
+            self._dirty = True
+        if self._dirty:
+            self._rt.load_state_dict(self.state_dict())
+            self._dirty = False
+        return self._rt
+
+    # -- forward ----------------------------------------------------------------------
+    def forward(self, feats, want28=True):
+        """feats: the nine ``inception_{3a..5b}_output_out`` maps [B*L, C, H, H] fp32 on a HIP
+        device.  Returns (fc_action_motion_7, fc_action_motion_14, fc_action_motion_28):
+        [B*(L-1), classes] each, or [B, classes] with the consensus average."""
+        feats = [f.contiguous() for f in feats]
+        if not feats[0].is_cuda:
+            raise runtime._lib.OffkError("OFFSubNetwork has no CPU path: feature maps must live on an MI355X")
+        rt = self._handle(feats[0].device)
+        with torch.no_grad():
+            return rt.forward(feats, want28=want28)
+
+
+class BNInception_OFF(nn.Module):
+    """Drop-in for the reference class of the same name, OFF part on liboffk.
+
+    ``backbone`` is any module mapping the frame batch [B*L, 3|10, 224, 224] to
+    ``(feats, Feature_Generation_Score)`` or ``(feats, Feature_Generation_Score, conv2_relu_3x3_out)``
+    -- i.e. the reference's own layers up to RGB_OFF.py:594.  Without a backbone the
+    ``input`` of forward must already be the list of nine feature maps (then
+    Feature_Generation_Score is returned as None).
+    """
+
+    def __init__(self, num_classes=1000, batch=16, length=7, variant="rgb", backbone=None,
+                 slice_mode=spec.SLICE_FLAT):
+        super().__init__()
+        self.batch, self.length = batch, length
+        self.modality_fuse = False                       # Flow_OFF.py:45
+        self.consensus_type = "avg"                      # RGB_OFF.py:39
+        self.variant_name = variant
+        self.backbone = backbone
+        self.off = OFFSubNetwork(num_classes, batch, length, variant, slice_mode)
+
+    def state_dict(self, *a, **kw):
+        sd = super().state_dict(*a, **kw)
+        # flatten 'off.' so the keys are the reference's (motion_*, fc_action_motion*, sobel_edge_diagonal.*)
+        return type(sd)((k[4:] if k.startswith("off.") else k, v) for k, v in sd.items())
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self.off.load_state_dict(state_dict, strict=strict)
+        if self.backbone is not None:
+            bb = {k[9:]: v for k, v in state_dict.items() if k.startswith("backbone.")}
+            if bb:
+                self.backbone.load_state_dict(bb, strict=False)
+
+    def _features(self, input):
+        if self.backbone is None:
+            return list(input), None, None
+        r = self.backbone(input)
+        return list(r[0]), r[1], (r[2] if len(r) > 2 else None)
+
+    @staticmethod
+    def _squeeze(x):
+        # torch.squeeze at RGB_OFF.py:786,792,846 also drops the pair axis when P == 1
+        return x[0] if x.shape[0] == 1 else x
+
+    def RGB_OFF_forward(self, input):
+        """RGB_OFF.py:360-860: returns (fc_action_motion_7, Feature_Generation_Score, fc_action_motion_14)."""
+        feats, fgs, _ = self._features(input)
+        fc7, fc14, _fc28 = self.off(feats, want28=False)
+        return self._squeeze(fc7), fgs, self._squeeze(fc14)
+
+    def forward(self, input):
+        """Flow_OFF.py:370-887 / RGB_OFF_v2.py:377-894 for the flow / rgb_v2 variants
+        (consensus average inside, optional fused score); for the rgb variant this is
+        RGB_OFF_forward (the reference's plain ``forward`` there is the backbone only)."""
+        if self.off.variant == spec.VARIANT_RGB:
+            return self.RGB_OFF_forward(input)
+        feats, fgs, conv2 = self._features(input)
+        fc7, fc14, _fc28 = self.off(feats, want28=False)
+        if fgs is not None and fgs.shape[0] == self.batch * self.length:
+            fgs = runtime.segment_consensus(fgs.contiguous().float(), self.batch)   # Flow_OFF.py:867,873 (K6)
+        if self.modality_fuse:
+            return fc7 + fgs + fc14                                            # Flow_OFF.py:881
+        if self.variant_name == "rgb_v2":
+            return fc7, fgs, fc14, conv2                                       # RGB_OFF_v2.py:891
+        return fc7, fgs, fc14                                                  # Flow_OFF.py:884
+
+
+def bninception_off(num_classes=101, batch=16, num_seg=7, variant="rgb", backbone=None, **kw):
+    """RGB_OFF.py:1346-1360 / Flow_OFF.py:1371-1385 factory."""
+    return BNInception_OFF(num_classes=num_classes, batch=batch, length=num_seg, variant=variant,
+                           backbone=backbone, **kw)

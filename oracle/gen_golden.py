@@ -129,7 +129,24 @@ def run_case(tag, variant, B, L, config_id):
     print(tag, "fc7", out["fc7"].shape, "->", os.path.getsize(path), "bytes")
 
 
+def dump_state_dict_keys():
+    """The weight-interchange contract: every key/shape of the reference state_dicts
+    (data only -- names and shapes), so tests can pin the wrapper's key set offline."""
+    import json
+    import RGB_OFF
+    import Flow_OFF
+    import RGB_OFF_v2
+    out = {}
+    for tag, mod in (("rgb", RGB_OFF), ("flow", Flow_OFF), ("rgb_v2", RGB_OFF_v2)):
+        sd = mod.bninception_off(spec.NUM_CLASSES, 1, 3).state_dict()
+        out[tag] = {k: list(v.shape) for k, v in sd.items()}
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("state_dict keys:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     for case in CASES:
         run_case(*case)
+    dump_state_dict_keys()
