@@ -137,15 +137,27 @@ int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_N
 
 /* K4. Generic channels-last convolution (the fusion convs, RGB_OFF.py:657-685,762-780,
  * 833-841): y = post( pre(conv(in(x)) + bias) + res ).  x,y,res are channel-sliced views
- * (ptr, channels-per-pixel stride, first channel).  w is [Co][KH][KW][Ci] (see
- * offk_pack_conv_weight).  Requires Ci % 32 == 0, Co % 32 == 0, strides/offsets % 4 == 0. */
+ * (ptr, channels-per-pixel stride, first channel).  w is in the library's K order
+ * [Co][Ci/32][KH*KW][32] (see offk_pack_conv_weight).  Requires Ci % 32 == 0, Co % 64 == 0,
+ * strides/offsets % 4 == 0.  Tile shape and K-split are chosen automatically. */
 enum offk_conv_flags { OFFK_CONV_RELU_IN = 1, OFFK_CONV_RELU_PRE = 2, OFFK_CONV_RELU_POST = 4 };
 int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci,
                 const float* w, const float* bias, int Co, int KH, int KW, int stride, int pad,
                 const float* res, int res_cstride, int res_coff, int flags,
                 float* y, int y_cstride, int y_coff);
-/* [Co][Ci][KH][KW] (PyTorch) -> [Co][KH][KW][Ci]; both device pointers. */
-int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_ohwi);
+/* Same with an explicit plan (tuning / micro-benchmarks): tile_cfg 0..5 = block tile 128x128,
+ * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), < 0 = automatic; splitk >= 1
+ * K-slices whose fp32 partial slabs [splitk][M][Co] go to `partial` (summed in slice order by
+ * a second launch, so results are bit-reproducible); splitk < 1 = automatic. */
+int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci,
+                   const float* w, const float* bias, int Co, int KH, int KW, int stride, int pad,
+                   const float* res, int res_cstride, int res_coff, int flags,
+                   float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial, size_t partial_floats);
+/* [Co][Ci][KH][KW] (PyTorch) -> [Co][Ci/32][KH*KW][32]; both device pointers. */
+int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_packed);
+/* Override the plan offk_forward uses for one fusion conv (key = its state_dict name without
+ * ".weight", e.g. "motion_conv_trans_28"); tile_cfg < 0 / splitk < 1 restore the automatic choice. */
+int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int splitk);
 
 /* K5. Replaces motion_pool_trans_28 / global_pool / squeeze / fc_action_motion*
  * (RGB_OFF.py:782-787, 789-793, 843-847): optional MaxPool(3,2,ceil) then global

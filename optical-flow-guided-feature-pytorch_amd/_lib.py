@@ -45,7 +45,10 @@ SIGNATURES = {
     "offk_sobel_tdiff": (_I, [_P, _P, _I, _F, _F, _F, _I, _I, _I]),
     "offk_off_units": (_I, [_P, _P, _c.POINTER(_F), _P]),
     "offk_conv2d": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I]),
+    "offk_conv2d_ex": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I,
+                            _I, _I, _F, _c.c_size_t]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
+    "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),
     "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),
     "offk_segment_consensus": (_I, [_P, _F, _I, _I, _I, _F]),
     "offk_nchw_to_nhwc": (_I, [_P, _F, _I, _I, _I, _F]),

@@ -15,40 +15,70 @@ namespace offk {
 
 constexpr int HEAD_MAX_C = 1024;
 
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+// One block per image.  Pooling: a thread owns a channel QUAD (16-B loads, 64 lanes = 1 KiB
+// contiguous per pixel) and the 256 threads are split into 256/(C/4) pixel groups whose partial
+// sums meet in LDS.  FC: one output class per wave at a time, lanes along C with 16-B loads of
+// the weight row, wavefront-shuffle reduction.
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int cs, int coff, int H, int W, int C, int maxpool,
                                                    const float* __restrict__ fw, const float* __restrict__ fb,
                                                    int ncls, float* __restrict__ out) {
-  __shared__ float pooled[HEAD_MAX_C];
+  __shared__ __attribute__((aligned(16))) float part[4 * HEAD_MAX_C];   // [group][C] partial sums (groups <= 4 when C >= 256)
+  __shared__ __attribute__((aligned(16))) float pooled[HEAD_MAX_C];
   const int img = blockIdx.x, tid = threadIdx.x;
   const float* xi = x + (size_t)img * H * W * cs + coff;
+  const int nq = C >> 2;                          // channel quads
+  int ngroups = 256 / nq;
+  if (ngroups < 1) ngroups = 1;
+  if (ngroups > 4) ngroups = 4;
+  const int Ho = maxpool ? (H - 3 + 1) / 2 + 1 : H, Wo = maxpool ? (W - 3 + 1) / 2 + 1 : W;
+  const int nwin = Ho * Wo;
+  for (int q = tid % (nq < 256 ? nq : 256); q < nq; q += 256) {
+    const int g = nq < 256 ? tid / nq : 0;
+    if (g < ngroups) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (maxpool) {
+        // MaxPool2d(kernel 3, stride 2, pad 0, ceil_mode=True): windows clipped at the border
+        for (int wdw = g; wdw < nwin; wdw += ngroups) {
+          const int oy = wdw / Wo, ox = wdw - oy * Wo;
+          float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int y = 2 * oy + dy, xx = 2 * ox + dx;
+              if (y < H && xx < W) m = max4(m, *reinterpret_cast<const float4*>(xi + (size_t)(y * W + xx) * cs + 4 * q));
+            }
+          s = add4(s, m);
+        }
+      } else {
+#pragma unroll 7
+        for (int px = g; px < nwin; px += ngroups) s = add4(s, *reinterpret_cast<const float4*>(xi + (size_t)px * cs + 4 * q));
+      }
+      *reinterpret_cast<float4*>(part + g * C + 4 * q) = s;
+    }
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)nwin;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    if (maxpool) {
-      // MaxPool2d(kernel 3, stride 2, pad 0, ceil_mode=True): windows clipped at the border
-      const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
-      for (int oy = 0; oy < Ho; ++oy)
-        for (int ox = 0; ox < Wo; ++ox) {
-          float m = -INFINITY;
-          for (int dy = 0; dy < 3; ++dy)
-            for (int dx = 0; dx < 3; ++dx) {
-              int y = 2 * oy + dy, xx = 2 * ox + dx;
-              if (y < H && xx < W) m = fmaxf(m, xi[(size_t)(y * W + xx) * cs + c]);
-            }
-          s += m;
-        }
-      s /= (float)(Ho * Wo);
-    } else {
-      for (int q = 0; q < H * W; ++q) s += xi[(size_t)q * cs + c];
-      s /= (float)(H * W);
-    }
-    pooled[c] = s;
+    for (int g = 0; g < ngroups; ++g) s += part[g * C + c];
+    pooled[c] = s * inv;
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   for (int o = wave; o < ncls; o += 4) {
     const float* wr = fw + (size_t)o * C;
     float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(wr[c], pooled[c], a);
+    for (int q = lane; q < nq; q += 64) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q);
+      const float4 pv = *reinterpret_cast<const float4*>(pooled + 4 * q);
+      a = fmaf(wv.x, pv.x, a); a = fmaf(wv.y, pv.y, a); a = fmaf(wv.z, pv.z, a); a = fmaf(wv.w, pv.w, a);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
     if (lane == 0) out[(size_t)img * ncls + o] = a + fb[o];
@@ -58,7 +88,10 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
 hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, const float* fw,
                        const float* fb, int ncls, float* out, hipStream_t st, const char** why) {
   *why = nullptr;
-  if (C > HEAD_MAX_C || C <= 0 || n_img <= 0) { *why = "head: C must be in 1..1024"; return hipErrorInvalidValue; }
+  if (C > HEAD_MAX_C || C < 4 || (C & 3) || (x_cs & 3) || (x_coff & 3) || n_img <= 0) {
+    *why = "head: need 4 <= C <= 1024, C and the channel slice 16-byte aligned";
+    return hipErrorInvalidValue;
+  }
   if (maxpool && (H < 3 || W < 3)) { *why = "head: maxpool needs H,W >= 3"; return hipErrorInvalidValue; }
   hipLaunchKernelGGL(head_kernel, dim3(n_img), dim3(256), 0, st, x, x_cs, x_coff, H, W, C, maxpool, fw, fb, ncls, out);
   return hipGetLastError();

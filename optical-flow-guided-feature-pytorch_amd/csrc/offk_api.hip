@@ -79,6 +79,10 @@ struct offk_handle {
   float* conv_b[kNumConvs] = {};
   float* fc_w[3] = {};
   float* fc_b[3] = {};
+  int conv_cfg[kNumConvs];       // tile plan per fusion conv (-1 = automatic)
+  int conv_splitk[kNumConvs];    // K-split per fusion conv (0 = automatic)
+  size_t splitk_floats = 0;      // size of the "splitk" workspace region
+  float* cur_splitk = nullptr;   // that region inside the workspace of the forward being enqueued
   std::vector<void*> allocs;
   // workspace plan
   std::map<std::string, std::pair<size_t, size_t>> regions;
@@ -166,6 +170,10 @@ void plan_workspace(offk_handle* h) {
   add_region(h, "logit_7", P * (size_t)h->cfg.num_classes);
   add_region(h, "logit_14", P * (size_t)h->cfg.num_classes);
   add_region(h, "logit_28", P * (size_t)h->cfg.num_classes);
+  // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64],
+  // 3x3 @7: [P*49, 256]); a conv whose plan needs more falls back to fewer slices
+  h->splitk_floats = 8 * P * 196 * 64;
+  add_region(h, "splitk", h->splitk_floats);
   h->ws_bytes = align_up(h->ws_bytes, 256);
 }
 
@@ -266,6 +274,8 @@ int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, co
   d.w = h->conv_w[id]; d.bias = h->conv_b[id]; d.Co = c.Co; d.KH = c.K; d.KW = c.K; d.stride = c.stride; d.pad = c.pad;
   d.res = res; d.res_cs = res_cs; d.res_coff = res_coff; d.flags = flags;
   d.y = y; d.y_cs = y_cs; d.y_coff = y_coff;
+  d.tile_cfg = h->conv_cfg[id]; d.splitk = h->conv_splitk[id];
+  d.partial = h->cur_splitk; d.partial_floats = h->splitk_floats;
   const char* why = nullptr;
   hipError_t e = conv2d_launch(d, st, &why);
   if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + ": " + (why ? why : hipGetErrorString(e)));
@@ -306,6 +316,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->cfg = *cfg;
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
+  for (int c = 0; c < kNumConvs; ++c) { h->conv_cfg[c] = -1; h->conv_splitk[c] = 0; }
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;
   for (int s = 0; s < kNumSites && rc == OFFK_OK; ++s) {
@@ -522,6 +533,7 @@ int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM
 
   TRY(run_off_units(h, st, feats, ws, ev));
 
+  h->cur_splitk = region(h, ws, "splitk");
   float* F28 = region(h, ws, "fusion_28");
   float* F14 = region(h, ws, "fusion_14");
   float* F7 = region(h, ws, "fusion_7");
@@ -605,8 +617,35 @@ int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_i
   return OFFK_OK;
 }
 
+int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci, const float* w,
+                   const float* bias, int Co, int KH, int KW, int stride, int pad, const float* res, int res_cstride,
+                   int res_coff, int flags, float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial,
+                   size_t partial_floats) {
+  if (!x || !w || !y || n_img < 1 || H < 1 || W < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_conv2d_ex: bad argument");
+  ConvDesc d;
+  d.x = x; d.x_cs = x_cstride; d.x_coff = x_coff; d.n_img = n_img; d.H = H; d.W = W; d.Ci = Ci;
+  d.w = w; d.bias = bias; d.Co = Co; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad;
+  d.res = res; d.res_cs = res_cstride; d.res_coff = res_coff; d.flags = flags; d.y = y; d.y_cs = y_cstride; d.y_coff = y_coff;
+  d.tile_cfg = tile_cfg; d.splitk = splitk; d.partial = partial; d.partial_floats = partial_floats;
+  const char* why = nullptr;
+  hipError_t e = conv2d_launch(d, static_cast<hipStream_t>(stream), &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  return OFFK_OK;
+}
+
+int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int splitk) {
+  if (!h || !conv_key) return fail(h, OFFK_ERR_INVALID, "offk_set_conv_plan: null argument");
+  for (int c = 0; c < kNumConvs; ++c)
+    if (!strcmp(kConvs[c].key, conv_key)) {
+      h->conv_cfg[c] = tile_cfg < 0 ? -1 : tile_cfg;
+      h->conv_splitk[c] = splitk < 1 ? 0 : splitk;
+      return OFFK_OK;
+    }
+  return fail(h, OFFK_ERR_UNKNOWN_KEY, std::string("offk_set_conv_plan: unknown conv ") + conv_key);
+}
+
 int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_ohwi) {
-  if (!w_oihw || !w_ohwi || Co < 1 || Ci < 1 || KH < 1 || KW < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_pack_conv_weight: bad argument");
+  if (!w_oihw || !w_ohwi || Co < 1 || Ci < 32 || (Ci & 31) || KH < 1 || KW < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_pack_conv_weight: bad argument (Ci % 32 == 0)");
   hipError_t e = pack_conv_weight_launch(w_oihw, Co, Ci, KH, KW, w_ohwi, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail_hip(nullptr, e, "offk_pack_conv_weight");
   return OFFK_OK;

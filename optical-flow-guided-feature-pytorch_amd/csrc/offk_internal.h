@@ -19,7 +19,11 @@ struct ConvDesc {
   const float* res; int res_cs, res_coff;
   int flags;
   float* y; int y_cs, y_coff;
+  int tile_cfg = -1, splitk = 0;          // < 0 / < 1: pick automatically
+  float* partial = nullptr;               // split-K slab scratch
+  size_t partial_floats = 0;
 };
+void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
 hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st);
 

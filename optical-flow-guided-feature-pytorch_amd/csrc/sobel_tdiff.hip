@@ -27,10 +27,14 @@
 namespace offk {
 
 constexpr int ST_THREADS = 256;
+constexpr int ST_STAGE_MAX = 6;   // >= ceil((rows+2)*(W+2)*8 / 256) for every plan below
+constexpr int ST_OUT_MAX = 4;     // >= ceil(rows*W*8 / 256): output pixels per thread
+constexpr int ST_TGROUP = 6;      // frames loaded per temporal step (L = 7 -> one step)
 
 void st_plan(int H, int* strips, int* rows) {
-  // <= 196 pixels per block: 28x28 planes are cut into four 7-row strips
-  *rows = H > 14 ? 7 : H;
+  // 98..112 pixels per block: fine-grained enough that the 1664 blocks at B = 64 balance over
+  // the CUs, coarse enough that the halo rows re-read by the neighbouring strip stay < 50 % of D
+  *rows = H >= 28 ? 4 : 7;
   *strips = (H + *rows - 1) / *rows;
 }
 
@@ -67,20 +71,27 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
   const size_t f0 = (size_t)b * L;        // first frame of the clip
   const size_t p0 = (size_t)b * T;        // first pair of the clip
   const int npix = R * W, q0 = y0 * W;
+  const size_t gstride = (size_t)HW * kGenCh, mstride = (size_t)HW * S.m_cs;
 
   // ---------------- temporal difference: M[.., coff+32 .. coff+160) ----------------
   if (ALGO == 0) {
+    // A thread owns (pixel, 4 channels); up to ST_TGROUP frames are in flight per step (all of
+    // them for L = 7), the previous frame's value stays in registers: each G element is read
+    // exactly once, 16 B per lane, 1 KiB contiguous per wave instruction.
     for (int task = tid; task < npix * 32; task += ST_THREADS) {
       const int q = q0 + (task >> 5), c4 = (task & 31) * 4;
       const float* g = S.G + (f0 * HW + q) * kGenCh + c4;
       float* m = S.M + (p0 * HW + q) * S.m_cs + S.m_coff + kDownCh + c4;
       float4 prev = *reinterpret_cast<const float4*>(g);
-      for (int t = 0; t < T; ++t) {
-        g += (size_t)HW * kGenCh;
-        float4 cur = *reinterpret_cast<const float4*>(g);
-        *reinterpret_cast<float4*>(m) = sub4(cur, prev);
-        m += (size_t)HW * S.m_cs;
-        prev = cur;
+      for (int t0 = 1; t0 < L; t0 += ST_TGROUP) {
+        float4 v[ST_TGROUP];
+#pragma unroll
+        for (int j = 0; j < ST_TGROUP; ++j)
+          if (t0 + j < L) v[j] = *reinterpret_cast<const float4*>(g + (size_t)(t0 + j) * gstride);
+#pragma unroll
+        for (int j = 0; j < ST_TGROUP; ++j)
+          if (t0 + j < L) *reinterpret_cast<float4*>(m + (size_t)(t0 + j - 1) * mstride) = sub4(v[j], j ? v[j - 1] : prev);
+        prev = v[ST_TGROUP - 1];
       }
     }
   } else {
@@ -105,47 +116,79 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
 
   // ---------------- spatial gradient: M[.., coff .. coff+32) ------------------------
   const int cq4 = (tid & 7) * 4;            // this thread's channel quad, fixed for the whole block
-  float4 wt[9], bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const float4*>(S.dw + k * kDownCh + cq4);
-  if (S.db) bias4 = *reinterpret_cast<const float4*>(S.db + cq4);
+  // tap weights [9][32] + bias [32] sit behind the tile in LDS (keeps ~40 VGPRs free for loads in flight)
+  float* wl = tile + (S.rows + 2) * (W + 2) * kDownCh;
+  for (int i = tid; i < 10 * kDownCh; i += ST_THREADS)
+    wl[i] = i < 9 * kDownCh ? S.dw[i] : (S.db ? S.db[i - 9 * kDownCh] : 0.f);
   const int TW = W + 2, TR = R + 2;
-  for (int t = 0; t < T; ++t) {
+  const int nstage = TR * TW;              // tile pixels; this thread stages pixels (tid>>3) + 32*j
+  // source offset (in floats, within one pair's D plane) of each staged pixel, or -1 for the zero halo
+  int soff[ST_STAGE_MAX];
+#pragma unroll
+  for (int j = 0; j < ST_STAGE_MAX; ++j) {
+    const int tp = (tid >> 3) + 32 * j;
+    const int ty = tp / TW, tx = tp - ty * TW;
+    const int y = y0 - 1 + ty, x = tx - 1;
+    soff[j] = (tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (y * W + x) * kDownCh + cq4 : -1;
+  }
+  // LDS offset of the centre tap of each output pixel (tid>>3) + 32*j of the strip, or -1
+  int coff[ST_OUT_MAX];
+#pragma unroll
+  for (int j = 0; j < ST_OUT_MAX; ++j) {
+    const int px = (tid >> 3) + 32 * j;
+    const int r = px / W, x = px - r * W;
+    coff[j] = px < npix ? ((r + 1) * TW + (x + 1)) * kDownCh + cq4 : -1;
+  }
+  float4 st[ST_STAGE_MAX];
+  auto load_pair = [&](int t) {
     const float* d = S.D + (p0 + t) * HW * kDownCh;
-    // stage rows y0-1 .. y0+R with zero halo; task = (tile pixel, channel quad)
-    for (int task = tid; task < TR * TW * 8; task += ST_THREADS) {
-      const int tp = task >> 3;
-      const int ty = tp / TW, tx = tp - ty * TW;
-      const int y = y0 - 1 + ty, x = tx - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-        v = *reinterpret_cast<const float4*>(d + (size_t)(y * W + x) * kDownCh + cq4);
-      *reinterpret_cast<float4*>(tile + tp * kDownCh + cq4) = v;
+#pragma unroll
+    for (int j = 0; j < ST_STAGE_MAX; ++j) {
+      st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (soff[j] >= 0) st[j] = *reinterpret_cast<const float4*>(d + soff[j]);
+    }
+  };
+  load_pair(0);
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int j = 0; j < ST_STAGE_MAX; ++j) {
+      const int tp = (tid >> 3) + 32 * j;
+      if (tp < nstage) *reinterpret_cast<float4*>(tile + tp * kDownCh + cq4) = st[j];
     }
     __syncthreads();
+    if (t + 1 < T) load_pair(t + 1);       // next pair's strip is in flight while this one is filtered
+    // taps outer, this thread's (<= ST_OUT_MAX) output pixels inner: one weight quad live at a time
     float* mrow = S.M + (p0 + t) * HW * S.m_cs + S.m_coff + cq4;
-    for (int task = tid; task < npix * 8; task += ST_THREADS) {
-      const int px = task >> 3;
-      const int r = px / W, x = px - r * W;
-      const float* c = tile + ((r + 1) * TW + (x + 1)) * kDownCh + cq4;
-      float4 acc = bias4;
+    float4 acc[ST_OUT_MAX];
+    const float4 b4 = *reinterpret_cast<const float4*>(wl + 9 * kDownCh + cq4);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+    for (int j = 0; j < ST_OUT_MAX; ++j) acc[j] = b4;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          acc = fma4(wt[dy * 3 + dx], *reinterpret_cast<const float4*>(c + ((dy - 1) * TW + (dx - 1)) * kDownCh), acc);
-      *reinterpret_cast<float4*>(mrow + (size_t)(q0 + px) * S.m_cs) = acc;
-    }
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wl + (dy * 3 + dx) * kDownCh + cq4);
+        const int toff = ((dy - 1) * TW + (dx - 1)) * kDownCh;
+#pragma unroll
+        for (int j = 0; j < ST_OUT_MAX; ++j)
+          if (coff[j] >= 0) acc[j] = fma4(w4, *reinterpret_cast<const float4*>(tile + coff[j] + toff), acc[j]);
+      }
+#pragma unroll
+    for (int j = 0; j < ST_OUT_MAX; ++j)
+      if (coff[j] >= 0) *reinterpret_cast<float4*>(mrow + (size_t)(q0 + (tid >> 3) + 32 * j) * S.m_cs) = acc[j];
     __syncthreads();
   }
 }
 
 hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st) {
   if (p.total_blocks <= 0) return hipSuccess;
-  int maxH = 0, rows = 0;
-  for (int i = 0; i < p.nsites; ++i)
-    if (p.s[i].H > maxH) { maxH = p.s[i].H; rows = p.s[i].rows; }
-  size_t lds = (size_t)(rows + 2) * (maxH + 2) * kDownCh * sizeof(float);
+  size_t tile_px = 0;
+  for (int i = 0; i < p.nsites; ++i) {
+    const size_t px = (size_t)(p.s[i].rows + 2) * (p.s[i].H + 2);
+    if (px > tile_px) tile_px = px;
+    if (px > 32 * ST_STAGE_MAX || p.s[i].rows * p.s[i].H > 32 * ST_OUT_MAX) return hipErrorInvalidValue;
+  }
+  size_t lds = (tile_px + 10) * kDownCh * sizeof(float);   // tile + taps + bias
   if (algo == 0) hipLaunchKernelGGL(sobel_tdiff_kernel<0>, dim3(p.total_blocks), dim3(ST_THREADS), lds, st, p);
   else hipLaunchKernelGGL(sobel_tdiff_kernel<1>, dim3(p.total_blocks), dim3(ST_THREADS), lds, st, p);
   return hipGetLastError();

@@ -162,6 +162,9 @@ class OffForward:
         _lib.check(self.lib.offk_sobel_tdiff(self._h, _stream(), site, _ptr(G), _ptr(D), _ptr(M),
                                              M.shape[-1], m_coff, algo), self._h)
 
+    def set_conv_plan(self, conv_key, tile_cfg, splitk):
+        _lib.check(self.lib.offk_set_conv_plan(self._h, conv_key.encode(), tile_cfg, splitk), self._h)
+
     # ---- profiling ---------------------------------------------------------------------
     def set_profiling(self, on):
         _lib.check(self.lib.offk_set_profiling(self._h, int(bool(on))), self._h)
@@ -174,21 +177,28 @@ class OffForward:
 
 
 # ---- handle-less stage kernels (channels-last tensors) ----------------------------------
-def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=None, y=None, y_coff=0):
+def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=None, y=None, y_coff=0,
+                tile_cfg=-1, splitk=0, w_packed=None):
     """x: [n, H, W, Cs] fp32 CUDA; uses channels [x_coff, x_coff+Ci).  Returns y [n, Ho, Wo, Co]
     (or writes channels [y_coff, y_coff+Co) of the given y)."""
     lib = _lib.load()
     n, H, W, cs = x.shape
     Co, Ci, KH, KW = w_oihw.shape
-    wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_pack_conv_weight(_stream(), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
+    wp = w_packed
+    if wp is None:
+        wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=x.device)   # library K order [Co][Ci/32][KH*KW][32]
+        _lib.check(lib.offk_pack_conv_weight(_stream(), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     if y is None:
         y = torch.empty(n, Ho, Wo, Co, dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_conv2d(_stream(), _ptr(x), cs, x_coff, n, H, W, Ci, _ptr(wp), _ptr(bias), Co, KH, KW,
-                               stride, pad, _ptr(res), res.shape[-1] if res is not None else 0, 0, flags,
-                               _ptr(y), y.shape[-1], y_coff))
+    part, nfl = None, 0
+    if splitk > 1:
+        nfl = splitk * n * Ho * Wo * Co
+        part = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_conv2d_ex(_stream(), _ptr(x), cs, x_coff, n, H, W, Ci, _ptr(wp), _ptr(bias), Co, KH, KW,
+                                  stride, pad, _ptr(res), res.shape[-1] if res is not None else 0, 0, flags,
+                                  _ptr(y), y.shape[-1], y_coff, tile_cfg, splitk, _ptr(part), nfl))
     return y
 
 

@@ -99,6 +99,25 @@ def test_conv2d_epilogues_and_slices(rt):
     assert rel_err(y.permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1) + res) < RTOL
 
 
+@pytest.mark.parametrize("cfg,splitk", [(0, 1), (1, 3), (2, 2), (3, 4), (4, 1), (5, 2), (-1, 0)])
+def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk):
+    """Every tile configuration and the deterministic split-K reduction give the same conv."""
+    from offk_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    n, H, Ci, Co = 5, 7, 128, 256
+    x = torch.randn(n, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 34.0
+    b = torch.randn(Co, generator=g)
+    res = torch.randn(n, Co, H, H, generator=g)
+    ref = torch.relu(torch.relu(F.conv2d(x, w, b, padding=1)) + res)
+    y = rt.conv2d_nhwc(nhwc(x), dev(w), dev(b), 1, 1, res=nhwc(res), flags=_lib.CONV_RELU_PRE | _lib.CONV_RELU_POST,
+                       tile_cfg=cfg, splitk=splitk)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < RTOL
+    y2 = rt.conv2d_nhwc(nhwc(x), dev(w), dev(b), 1, 1, res=nhwc(res), flags=_lib.CONV_RELU_PRE | _lib.CONV_RELU_POST,
+                        tile_cfg=cfg, splitk=splitk)
+    assert torch.equal(y, y2)      # split-K sums slabs in a fixed order: bit-reproducible
+
+
 def test_head_and_consensus(rt):
     g = torch.Generator().manual_seed(9)
     for C, H, mp in ((256, 14, True), (512, 7, False), (1024, 7, False)):
