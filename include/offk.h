@@ -128,9 +128,15 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
  * diagonal Sobel (RGB_OFF.py:611; Flow_OFF.py:622 + util.py:52-77) and the concats
  * (RGB_OFF.py:616,656,760,832): writes [spatial 32 | temporal 128] into channels
  * [m_coff, m_coff+160) of M, a channels-last buffer with m_cstride channels per pixel.
- * algo: 0 = register rotation over t (default), 1 = t across lanes + wavefront shuffle. */
+ * algo: 0 = register rotation over t (default), 1 = t across lanes + wavefront shuffle;
+ * 2 / 3 = diagnostics for bandwidth attribution (temporal half only / spatial half only). */
 int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, const float* D,
                      float* M, int m_cstride, int m_coff, int algo);
+
+/* K2 alone for all nine sites in ONE grouped launch (exactly what offk_forward enqueues), reading
+ * the G_<site> / D_<site> workspace regions a previous offk_off_units / offk_forward filled and
+ * writing the fusion buffers.  algo as in offk_sobel_tdiff.  Used by bench / tools to time K2. */
+int offk_sobel_tdiff_all(offk_handle* h, void* stream, void* workspace, int algo);
 
 /* K1+K2 for all nine sites into the workspace fusion buffers (two grouped launches). */
 int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "offk_stage_times": (_I, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _I]),
     "offk_pw_reduce": (_I, [_P, _P, _I, _F, _F, _F]),
     "offk_sobel_tdiff": (_I, [_P, _P, _I, _F, _F, _F, _I, _I, _I]),
+    "offk_sobel_tdiff_all": (_I, [_P, _P, _P, _I]),
     "offk_off_units": (_I, [_P, _P, _c.POINTER(_F), _P]),
     "offk_conv2d": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I]),
     "offk_conv2d_ex": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I,

@@ -226,23 +226,21 @@ static hipError_t launch_shape(const ConvArgs& a, int cfg, hipStream_t st) {
   }
 }
 
-// Heuristic when the caller gives no plan: the largest tile whose grid still fills the chip
-// about twice over; split K (<= 8, >= 16 K-tiles per split) until it does.
+// Heuristic when the caller gives no plan, distilled from tools/tune_conv.py sweeps on MI355X:
+// small tiles win (more resident waves hide the gather latency, finer work quantisation):
+// 64x64 for short K, 64x128 for long K with wide outputs; then split K until the grid has
+// >= 1536 blocks (6 per CU) while every slice keeps >= 16 K-tiles.
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out) {
-  const int order[kNumTileCfg] = {0, 4, 1, 3, 2, 5};
-  int best = -1;
-  for (int i = 0; i < 4 && best < 0; ++i) {
-    const int c = order[i];
-    if (Co % kTileBN[c]) continue;
-    long long blocks = ((M + kTileBM[c] - 1) / kTileBM[c]) * (Co / kTileBN[c]);
-    if (blocks >= 448) best = c;
-  }
-  if (best < 0) best = (Co % 128 == 0 && M > 64) ? 0 : (M > 64 ? 1 : 3);
-  if (Co % kTileBN[best]) best = 3;
-  long long blocks = ((M + kTileBM[best] - 1) / kTileBM[best]) * (Co / kTileBN[best]);
+  int cfg = (nkt >= 36 && Co % 128 == 0) ? 4 : 3;
+  long long blocks = ((M + kTileBM[cfg] - 1) / kTileBM[cfg]) * (Co / kTileBN[cfg]);
+  static const int cand[] = {1, 2, 3, 4, 6, 8, 12};
   int sk = 1;
-  while (blocks * sk < 448 && sk < 8 && nkt / (sk * 2) >= 16) sk *= 2;
-  *cfg_out = best;
+  for (int c : cand) {
+    if (nkt / c < 16) break;
+    sk = c;
+    if (blocks * c >= 1536) break;
+  }
+  *cfg_out = cfg;
   *splitk_out = sk;
 }
 

@@ -45,6 +45,12 @@ const ConvSpec kConvs[kNumConvs] = {
     {"motion_conv3_trans_14b", 512, 128, 3, 1, 1},   {"motion_conv_trans", 256, 832, 3, 1, 1},
     {"motion_conv1_trans", 256, 256, 1, 1, 0},       {"motion_conv2_trans", 256, 256, 3, 1, 1},
     {"motion_conv3_trans", 1024, 256, 1, 1, 0},      {"motion_conv_branch_trans", 1024, 256, 1, 1, 0}};
+// (tile_cfg, splitk) per fusion conv measured fastest by tools/tune_conv.py at P = 384 pairs
+// (BASELINE config 2: B = 64, L = 7) on MI355X; other sizes use conv2d_auto_plan.
+const int kTunedP384[kNumConvs][2] = {
+    {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
+    {4, 12}, {3, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {4, 1},                          // fusion @14
+    {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -225,7 +231,28 @@ void fill_st_site(const offk_handle* h, int site, const float* G, const float* D
   o->db = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? nullptr : h->dw_b[site];
   o->M = M; o->H = kSites[site].H; o->m_cs = m_cs; o->m_coff = m_coff;
   st_plan(o->H, &o->strips, &o->rows);
-  o->blk_begin = 0;
+  o->tchunks = st_tchunks(o->H);
+  o->s_begin = 0; o->t_begin = 0;
+}
+
+int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo) {
+  StParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.nsites = kNumSites; sp.B = h->cfg.batch; sp.L = h->cfg.length;
+  const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
+  int sblk = 0, tblk = 0;
+  for (int s = 0; s < kNumSites; ++s) {
+    fill_st_site(h, s, region(h, ws, (std::string("G_") + kSites[s].name).c_str()),
+                 region(h, ws, (std::string("D_") + kSites[s].name).c_str()), region(h, ws, fus[kSiteFusion[s]]),
+                 kFusionC[kSiteFusion[s]], kSiteCoff[s], &sp.s[s]);
+    sp.s[s].s_begin = sblk;
+    sp.s[s].t_begin = tblk;
+    sblk += h->P * sp.s[s].strips;
+    tblk += h->cfg.batch * sp.s[s].tchunks;
+  }
+  sp.total_s = sblk; sp.total_t = tblk;
+  HIP_TRY(h, sobel_tdiff_launch(sp, algo, st));
+  return OFFK_OK;
 }
 
 int run_off_units(offk_handle* h, hipStream_t st, const float* const feats[], void* ws, hipEvent_t* ev) {
@@ -246,20 +273,7 @@ int run_off_units(offk_handle* h, hipStream_t st, const float* const feats[], vo
   HIP_TRY(h, pw_reduce_launch(pp, st));
   if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
 
-  StParams sp;
-  memset(&sp, 0, sizeof(sp));
-  sp.nsites = kNumSites; sp.B = h->cfg.batch; sp.L = h->cfg.length;
-  const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
-  blk = 0;
-  for (int s = 0; s < kNumSites; ++s) {
-    fill_st_site(h, s, region(h, ws, (std::string("G_") + kSites[s].name).c_str()),
-                 region(h, ws, (std::string("D_") + kSites[s].name).c_str()), region(h, ws, fus[kSiteFusion[s]]),
-                 kFusionC[kSiteFusion[s]], kSiteCoff[s], &sp.s[s]);
-    sp.s[s].blk_begin = blk;
-    blk += h->cfg.batch * sp.s[s].strips;
-  }
-  sp.total_blocks = blk;
-  HIP_TRY(h, sobel_tdiff_launch(sp, 0, st));
+  { int rc = run_sobel_tdiff_all(h, st, ws, 0); if (rc != OFFK_OK) return rc; }
   if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
   return OFFK_OK;
 }
@@ -316,7 +330,11 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->cfg = *cfg;
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
-  for (int c = 0; c < kNumConvs; ++c) { h->conv_cfg[c] = -1; h->conv_splitk[c] = 0; }
+  for (int c = 0; c < kNumConvs; ++c) {
+    const bool tuned = h->P == 384;
+    h->conv_cfg[c] = tuned ? kTunedP384[c][0] : -1;
+    h->conv_splitk[c] = tuned ? kTunedP384[c][1] : 0;
+  }
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;
   for (int s = 0; s < kNumSites && rc == OFFK_OK; ++s) {
@@ -484,17 +502,28 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
 int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, const float* D, float* M, int m_cstride,
                      int m_coff, int algo) {
   if (!h || site < 0 || site >= kNumSites || !G || !D || !M) return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: bad argument");
-  if (m_cstride % 4 || m_coff % 4 || m_coff < 0 || m_coff + kUnitCh > m_cstride || (algo != 0 && algo != 1))
-    return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: need 16-byte aligned channel slice of 160 channels inside m_cstride, algo in {0,1}");
+  if (m_cstride % 4 || m_coff % 4 || m_coff < 0 || m_coff + kUnitCh > m_cstride || algo < 0 || algo > 3)
+    return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: need 16-byte aligned channel slice of 160 channels inside m_cstride, algo in 0..3");
   TRY(site_weights_ready(h, site, false, true));
   DeviceGuard guard(h->cfg.device);
   StParams sp;
   memset(&sp, 0, sizeof(sp));
   sp.nsites = 1; sp.B = h->cfg.batch; sp.L = h->cfg.length;
   fill_st_site(h, site, G, D, M, m_cstride, m_coff, &sp.s[0]);
-  sp.total_blocks = h->cfg.batch * sp.s[0].strips;
+  sp.total_s = h->P * sp.s[0].strips;
+  sp.total_t = h->cfg.batch * sp.s[0].tchunks;
   HIP_TRY(h, sobel_tdiff_launch(sp, algo, static_cast<hipStream_t>(stream)));
   return OFFK_OK;
+}
+
+int offk_sobel_tdiff_all(offk_handle* h, void* stream, void* workspace, int algo) {
+  if (!h || !workspace || algo < 0 || algo > 3) return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff_all: bad argument");
+  for (int s = 0; s < kNumSites; ++s) {
+    int rc = site_weights_ready(h, s, false, true);
+    if (rc != OFFK_OK) return rc;
+  }
+  DeviceGuard guard(h->cfg.device);
+  return run_sobel_tdiff_all(h, static_cast<hipStream_t>(stream), workspace, algo);
 }
 
 int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace) {

@@ -53,15 +53,19 @@ struct StSite {
   const float* db;    // [32] bias or nullptr
   float* M;           // fusion buffer, channels-last
   int H, m_cs, m_coff;
-  int strips, rows;   // strips per plane, rows per strip
-  int blk_begin;
+  int strips, rows;   // S-blocks: strips per plane, rows per strip
+  int tchunks;        // T-blocks per clip
+  int s_begin;        // first S-block (spatial role) of this site within the S index space
+  int t_begin;        // first T-block (temporal role) of this site within the T index space
 };
 struct StParams {
   StSite s[kNumSites];
-  int nsites, total_blocks;
-  int B, L;
+  int nsites;
+  int total_s, total_t;   // S-blocks = sum P*strips, T-blocks = sum B*tchunks
+  int B, L, tpix;         // tpix = pixels per T-block
 };
 void st_plan(int H, int* strips, int* rows);
+int st_tchunks(int H);
 hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st);
 
 // ---- K5 / K6 / layout helpers ----------------------------------------------------

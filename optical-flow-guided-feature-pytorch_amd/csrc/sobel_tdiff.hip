@@ -10,32 +10,69 @@
 // identity in eval mode.
 //
 // Layout: everything channels-last.  G [N*HW][128], D [P*HW][32], M [P*HW][m_cs].
-// One block = (site, clip b, strip of `rows` image rows).  All nine sites share one
-// grouped launch.
-//   temporal: a thread owns (pixel, 4 channels) and walks t with the previous frame's
-//             value kept in registers, so every G element is read exactly once with
-//             16-B loads (1 KiB contiguous per wave instruction) -- algo 0; algo 1 puts
-//             t on the lanes (8 t-slots x 8 channel quads) and takes the difference
-//             with a wavefront shuffle (kept for the A/B measurement in DESIGN.md).
-//   spatial : the D strip plus a one-pixel zero halo is staged in LDS per pair; a thread
-//             owns a fixed channel quad (its 9 tap weights + bias live in registers) and
-//             reads its 3x3 neighbourhood from LDS with ds_read_b128.
+// All nine sites share ONE grouped launch made of two block roles, interleaved in block-id
+// order (Bresenham) so every CU always holds a mix of both:
+//   T-block = (site, clip, chunk of <= 64 pixels): temporal difference, pure streaming, no LDS.
+//             A thread owns (pixel, 4 channels) and loads all L frames (6 per step) before it
+//             stores, the previous frame stays in registers: every G element is read exactly
+//             once with 16-B loads, 1 KiB contiguous per wave instruction -- algo 0.  algo 1
+//             puts t on the lanes (8 t-slots x 8 channel quads) and takes the difference with
+//             a wavefront shuffle (kept for the A/B measurement in DESIGN.md: it is slower).
+//   S-block = (site, pair, strip of <= 7 rows): the D strip plus a one-pixel zero halo is
+//             staged in LDS (all loads of a block in flight at once), then each thread
+//             filters its <= 4 pixels for a fixed channel quad, taps outer, ds_read_b128.
+//             One stage->barrier->filter round per block; the latency is hidden by the other
+//             resident blocks (4 per CU) rather than by a per-block pipeline.
+// Measured (profiles/r01): run back to back inside one block the two halves add up (temporal
+// 5.9 TB/s + spatial 2.5 TB/s => 4.7 TB/s); as separate interleaved roles they overlap.
 // Algorithmic HBM bytes per (clip, site): H*H*4*(128*L + 192*(L-1))  (SURVEY.md 8d).
+#include <cstdlib>
+
 #include "offk_common.h"
 #include "offk_internal.h"
 
 namespace offk {
 
 constexpr int ST_THREADS = 256;
-constexpr int ST_STAGE_MAX = 6;   // >= ceil((rows+2)*(W+2)*8 / 256) for every plan below
-constexpr int ST_OUT_MAX = 4;     // >= ceil(rows*W*8 / 256): output pixels per thread
+constexpr int ST_STAGE_MAX = 9;   // >= ceil((rows+2)*(W+2) / 32): staged tile pixels per thread
+constexpr int ST_OUT_MAX = 7;     // >= ceil(rows*W / 32): output pixels per thread
 constexpr int ST_TGROUP = 6;      // frames loaded per temporal step (L = 7 -> one step)
 
+// tuning knobs (environment overrides are for tools/bench_k2.py sweeps only)
+static int knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+int st_tpix() { return knob("OFFK_K2_TPIX", 64); }   // pixels per T-block (0 = per-site: 112 / 98 / 49)
+
 void st_plan(int H, int* strips, int* rows) {
-  // 98..112 pixels per block: fine-grained enough that the 1664 blocks at B = 64 balance over
-  // the CUs, coarse enough that the halo rows re-read by the neighbouring strip stay < 50 % of D
-  *rows = H >= 28 ? 4 : 7;
+  *rows = H >= 28 ? knob("OFFK_K2_ROWS28", 7) : 7;   // 28x28 planes: four 7-row strips; 14x14 and 7x7: 2 / 1 strips
+  if (*rows < 1 || *rows > 7) *rows = 7;
   *strips = (H + *rows - 1) / *rows;
+}
+int st_tpix_for(int H) { int t = st_tpix(); return t > 0 ? t : (H >= 28 ? 112 : H >= 14 ? 98 : 49); }
+int st_tchunks(int H) { return (H * H + st_tpix_for(H) - 1) / st_tpix_for(H); }
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+// Non-temporal variants: a plain float4 stream reads at 7.1 instead of 6.3 TB/s with them on this
+// chip (tools/hbm_probe.hip), but K2 is bound by its strided write side and measured no gain
+// (profiles/r01/k2_ab.txt), so they stay off by default.
+template <int NT>
+__device__ __forceinline__ float4 ldg4(const float* p) {
+  if (NT) {
+    f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+template <int NT>
+__device__ __forceinline__ void stg4(float* p, float4 v) {
+  if (NT) {
+    f4v u = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(u, reinterpret_cast<f4v*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
 }
 
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) {
@@ -45,143 +82,143 @@ __device__ __forceinline__ float4 fma4(float4 w, float4 x, float4 acc) {
   return make_float4(fmaf(w.x, x.x, acc.x), fmaf(w.y, x.y, acc.y), fmaf(w.z, x.z, acc.z), fmaf(w.w, x.w, acc.w));
 }
 
-template <int ALGO>
+template <int ALGO, int NTL, int NTS>
 __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(rows+2)][(W+2)][32]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [(rows+2)][(W+2)][32] + taps [9][32] + bias [32]
 
-  // block -> site: field-wise scalar select chain (see pw_reduce.hip)
+  // ---- block id -> (role, index within role): proportional interleave of the two roles ----
+  const unsigned bid = blockIdx.x, total = (unsigned)(p.total_s + p.total_t);
+  const unsigned t_before = (unsigned)((unsigned long long)bid * p.total_t / total);
+  const unsigned t_after = (unsigned)((unsigned long long)(bid + 1) * p.total_t / total);
+  const bool is_t = t_after > t_before;
+  const int ridx = is_t ? (int)t_before : (int)(bid - t_before);
+
+  // ---- role index -> site: field-wise scalar select chain (see pw_reduce.hip) ----
   StSite S;
   S.G = p.s[0].G; S.D = p.s[0].D; S.dw = p.s[0].dw; S.db = p.s[0].db; S.M = p.s[0].M; S.H = p.s[0].H;
   S.m_cs = p.s[0].m_cs; S.m_coff = p.s[0].m_coff; S.strips = p.s[0].strips; S.rows = p.s[0].rows;
-  S.blk_begin = p.s[0].blk_begin;
+  S.s_begin = p.s[0].s_begin; S.t_begin = p.s[0].t_begin; S.tchunks = p.s[0].tchunks;
 #pragma unroll
   for (int i = 1; i < kNumSites; ++i)
-    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) {
+    if (i < p.nsites && ridx >= (is_t ? p.s[i].t_begin : p.s[i].s_begin)) {
       S.G = p.s[i].G; S.D = p.s[i].D; S.dw = p.s[i].dw; S.db = p.s[i].db; S.M = p.s[i].M; S.H = p.s[i].H;
       S.m_cs = p.s[i].m_cs; S.m_coff = p.s[i].m_coff; S.strips = p.s[i].strips; S.rows = p.s[i].rows;
-      S.blk_begin = p.s[i].blk_begin;
+      S.s_begin = p.s[i].s_begin; S.t_begin = p.s[i].t_begin; S.tchunks = p.s[i].tchunks;
     }
   const int H = S.H, W = S.H, HW = H * H;
-  const int local = (int)blockIdx.x - S.blk_begin;
-  const int b = local / S.strips, strip = local - b * S.strips;
-  const int y0 = strip * S.rows;
-  const int R = min(S.rows, H - y0);
   const int L = p.L, T = L - 1;
   const int tid = threadIdx.x;
-  const size_t f0 = (size_t)b * L;        // first frame of the clip
-  const size_t p0 = (size_t)b * T;        // first pair of the clip
-  const int npix = R * W, q0 = y0 * W;
-  const size_t gstride = (size_t)HW * kGenCh, mstride = (size_t)HW * S.m_cs;
 
-  // ---------------- temporal difference: M[.., coff+32 .. coff+160) ----------------
-  if (ALGO == 0) {
-    // A thread owns (pixel, 4 channels); up to ST_TGROUP frames are in flight per step (all of
-    // them for L = 7), the previous frame's value stays in registers: each G element is read
-    // exactly once, 16 B per lane, 1 KiB contiguous per wave instruction.
-    for (int task = tid; task < npix * 32; task += ST_THREADS) {
-      const int q = q0 + (task >> 5), c4 = (task & 31) * 4;
-      const float* g = S.G + (f0 * HW + q) * kGenCh + c4;
-      float* m = S.M + (p0 * HW + q) * S.m_cs + S.m_coff + kDownCh + c4;
-      float4 prev = *reinterpret_cast<const float4*>(g);
-      for (int t0 = 1; t0 < L; t0 += ST_TGROUP) {
-        float4 v[ST_TGROUP];
+  if (is_t) {
+    // ---------------- temporal difference: M[.., coff+32 .. coff+160) ----------------
+    const int local = ridx - S.t_begin;
+    const int b = local / S.tchunks, chunk = local - b * S.tchunks;
+    const int tpix = p.tpix > 0 ? p.tpix : (H >= 28 ? 112 : H >= 14 ? 98 : 49);
+    const int q0 = chunk * tpix, npix = min(tpix, HW - q0);
+    const size_t f0 = (size_t)b * L, p0 = (size_t)b * T;
+    const size_t gstride = (size_t)HW * kGenCh, mstride = (size_t)HW * S.m_cs;
+    if (ALGO != 1) {
+      for (int task = tid; task < npix * 32; task += ST_THREADS) {
+        const int q = q0 + (task >> 5), c4 = (task & 31) * 4;
+        const float* g = S.G + (f0 * HW + q) * kGenCh + c4;
+        float* m = S.M + (p0 * HW + q) * S.m_cs + S.m_coff + kDownCh + c4;
+        float4 prev = ldg4<NTL>(g);
+        for (int t0 = 1; t0 < L; t0 += ST_TGROUP) {
+          float4 v[ST_TGROUP];
 #pragma unroll
-        for (int j = 0; j < ST_TGROUP; ++j)
-          if (t0 + j < L) v[j] = *reinterpret_cast<const float4*>(g + (size_t)(t0 + j) * gstride);
+          for (int j = 0; j < ST_TGROUP; ++j)
+            if (t0 + j < L) v[j] = ldg4<NTL>(g + (size_t)(t0 + j) * gstride);
 #pragma unroll
-        for (int j = 0; j < ST_TGROUP; ++j)
-          if (t0 + j < L) *reinterpret_cast<float4*>(m + (size_t)(t0 + j - 1) * mstride) = sub4(v[j], j ? v[j - 1] : prev);
-        prev = v[ST_TGROUP - 1];
+          for (int j = 0; j < ST_TGROUP; ++j)
+            if (t0 + j < L) stg4<NTS>(m + (size_t)(t0 + j - 1) * mstride, sub4(v[j], j ? v[j - 1] : prev));
+          prev = v[ST_TGROUP - 1];
+        }
+      }
+    } else {
+      // lanes: slot = lane>>3 (t within a group of 8), cq = lane&7; a wave covers 8 t x 32 channels per
+      // step, the next group of t overlaps by one so every pair has both ends in one wave.
+      const int lane = tid & 63, wave = tid >> 6;
+      const int slot = lane >> 3, cq = lane & 7;
+      for (int unit = wave; unit < npix * 4; unit += ST_THREADS / 64) {
+        const int q = q0 + (unit >> 2), c4 = ((unit & 3) * 8 + cq) * 4;
+        for (int tb = 0; tb < T; tb += 7) {
+          const int t = tb + slot;                       // frame index within the clip
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t < L) v = ldg4<NTL>(S.G + ((f0 + t) * HW + q) * kGenCh + c4);
+          float4 nx;
+          nx.x = __shfl_down(v.x, 8); nx.y = __shfl_down(v.y, 8);
+          nx.z = __shfl_down(v.z, 8); nx.w = __shfl_down(v.w, 8);
+          if (slot < 7 && t < T)
+            stg4<NTS>(S.M + ((p0 + t) * HW + q) * S.m_cs + S.m_coff + kDownCh + c4, sub4(nx, v));
+        }
       }
     }
-  } else {
-    // lanes: slot = lane>>3 (t within a group of 8), cq = lane&7; a wave covers 8 t x 32 channels
-    // per step, the next group of t overlaps by one so every pair has both ends in one wave.
-    const int lane = tid & 63, wave = tid >> 6;
-    const int slot = lane >> 3, cq = lane & 7;
-    for (int unit = wave; unit < npix * 4; unit += ST_THREADS / 64) {
-      const int q = q0 + (unit >> 2), c4 = ((unit & 3) * 8 + cq) * 4;
-      for (int tb = 0; tb < T; tb += 7) {
-        const int t = tb + slot;                       // frame index within the clip
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < L) v = *reinterpret_cast<const float4*>(S.G + ((f0 + t) * HW + q) * kGenCh + c4);
-        float4 nx;
-        nx.x = __shfl_down(v.x, 8); nx.y = __shfl_down(v.y, 8);
-        nx.z = __shfl_down(v.z, 8); nx.w = __shfl_down(v.w, 8);
-        if (slot < 7 && t < T)
-          *reinterpret_cast<float4*>(S.M + ((p0 + t) * HW + q) * S.m_cs + S.m_coff + kDownCh + c4) = sub4(nx, v);
-      }
-    }
+    return;
   }
 
   // ---------------- spatial gradient: M[.., coff .. coff+32) ------------------------
+  const int local = ridx - S.s_begin;
+  const int pr = local / S.strips, strip = local - pr * S.strips;   // pair, strip
+  const int y0 = strip * S.rows;
+  const int R = min(S.rows, H - y0);
+  const int npix = R * W, q0 = y0 * W;
   const int cq4 = (tid & 7) * 4;            // this thread's channel quad, fixed for the whole block
-  // tap weights [9][32] + bias [32] sit behind the tile in LDS (keeps ~40 VGPRs free for loads in flight)
-  float* wl = tile + (S.rows + 2) * (W + 2) * kDownCh;
-  for (int i = tid; i < 10 * kDownCh; i += ST_THREADS)
-    wl[i] = i < 9 * kDownCh ? S.dw[i] : (S.db ? S.db[i - 9 * kDownCh] : 0.f);
-  const int TW = W + 2, TR = R + 2;
-  const int nstage = TR * TW;              // tile pixels; this thread stages pixels (tid>>3) + 32*j
-  // source offset (in floats, within one pair's D plane) of each staged pixel, or -1 for the zero halo
-  int soff[ST_STAGE_MAX];
+  const int TW = W + 2, nstage = (R + 2) * TW;
+  float* wl = tile + (S.rows + 2) * TW * kDownCh;   // tap weights [9][32] + bias [32] behind the tile
+  const float* d = S.D + (size_t)pr * HW * kDownCh;
+  // stage rows y0-1 .. y0+R with the zero halo: this thread's tile pixels are (tid>>3) + 32*j,
+  // all of its loads are issued before the first LDS write
+  float4 st[ST_STAGE_MAX];
 #pragma unroll
   for (int j = 0; j < ST_STAGE_MAX; ++j) {
     const int tp = (tid >> 3) + 32 * j;
     const int ty = tp / TW, tx = tp - ty * TW;
     const int y = y0 - 1 + ty, x = tx - 1;
-    soff[j] = (tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (y * W + x) * kDownCh + cq4 : -1;
+    st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+      st[j] = ldg4<NTL>(d + (size_t)(y * W + x) * kDownCh + cq4);
   }
-  // LDS offset of the centre tap of each output pixel (tid>>3) + 32*j of the strip, or -1
+  for (int i = tid; i < 10 * kDownCh; i += ST_THREADS)
+    wl[i] = i < 9 * kDownCh ? S.dw[i] : (S.db ? S.db[i - 9 * kDownCh] : 0.f);
+#pragma unroll
+  for (int j = 0; j < ST_STAGE_MAX; ++j) {
+    const int tp = (tid >> 3) + 32 * j;
+    if (tp < nstage) *reinterpret_cast<float4*>(tile + tp * kDownCh + cq4) = st[j];
+  }
+  __syncthreads();
+  // taps outer, this thread's (<= ST_OUT_MAX) output pixels inner: one weight quad live at a time
   int coff[ST_OUT_MAX];
+  float4 acc[ST_OUT_MAX];
+  const float4 b4 = *reinterpret_cast<const float4*>(wl + 9 * kDownCh + cq4);
 #pragma unroll
   for (int j = 0; j < ST_OUT_MAX; ++j) {
     const int px = (tid >> 3) + 32 * j;
     const int r = px / W, x = px - r * W;
     coff[j] = px < npix ? ((r + 1) * TW + (x + 1)) * kDownCh + cq4 : -1;
+    acc[j] = b4;
   }
-  float4 st[ST_STAGE_MAX];
-  auto load_pair = [&](int t) {
-    const float* d = S.D + (p0 + t) * HW * kDownCh;
 #pragma unroll
-    for (int j = 0; j < ST_STAGE_MAX; ++j) {
-      st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (soff[j] >= 0) st[j] = *reinterpret_cast<const float4*>(d + soff[j]);
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wl + (dy * 3 + dx) * kDownCh + cq4);
+      const int toff = ((dy - 1) * TW + (dx - 1)) * kDownCh;
+#pragma unroll
+      for (int j = 0; j < ST_OUT_MAX; ++j)
+        if (coff[j] >= 0) acc[j] = fma4(w4, *reinterpret_cast<const float4*>(tile + coff[j] + toff), acc[j]);
     }
-  };
-  load_pair(0);
-  for (int t = 0; t < T; ++t) {
+  float* mrow = S.M + (size_t)pr * HW * S.m_cs + S.m_coff + cq4;
 #pragma unroll
-    for (int j = 0; j < ST_STAGE_MAX; ++j) {
-      const int tp = (tid >> 3) + 32 * j;
-      if (tp < nstage) *reinterpret_cast<float4*>(tile + tp * kDownCh + cq4) = st[j];
-    }
-    __syncthreads();
-    if (t + 1 < T) load_pair(t + 1);       // next pair's strip is in flight while this one is filtered
-    // taps outer, this thread's (<= ST_OUT_MAX) output pixels inner: one weight quad live at a time
-    float* mrow = S.M + (p0 + t) * HW * S.m_cs + S.m_coff + cq4;
-    float4 acc[ST_OUT_MAX];
-    const float4 b4 = *reinterpret_cast<const float4*>(wl + 9 * kDownCh + cq4);
-#pragma unroll
-    for (int j = 0; j < ST_OUT_MAX; ++j) acc[j] = b4;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wl + (dy * 3 + dx) * kDownCh + cq4);
-        const int toff = ((dy - 1) * TW + (dx - 1)) * kDownCh;
-#pragma unroll
-        for (int j = 0; j < ST_OUT_MAX; ++j)
-          if (coff[j] >= 0) acc[j] = fma4(w4, *reinterpret_cast<const float4*>(tile + coff[j] + toff), acc[j]);
-      }
-#pragma unroll
-    for (int j = 0; j < ST_OUT_MAX; ++j)
-      if (coff[j] >= 0) *reinterpret_cast<float4*>(mrow + (size_t)(q0 + (tid >> 3) + 32 * j) * S.m_cs) = acc[j];
-    __syncthreads();
-  }
+  for (int j = 0; j < ST_OUT_MAX; ++j)
+    if (coff[j] >= 0) stg4<NTS>(mrow + (size_t)(q0 + (tid >> 3) + 32 * j) * S.m_cs, acc[j]);
 }
 
 hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st) {
-  if (p.total_blocks <= 0) return hipSuccess;
+  StParams q = p;
+  q.tpix = st_tpix();
+  if (algo == 2) q.total_s = 0;   // diagnostic: temporal half only
+  if (algo == 3) q.total_t = 0;   // diagnostic: spatial half only
+  if (q.total_s + q.total_t <= 0) return hipSuccess;
   size_t tile_px = 0;
   for (int i = 0; i < p.nsites; ++i) {
     const size_t px = (size_t)(p.s[i].rows + 2) * (p.s[i].H + 2);
@@ -189,8 +226,21 @@ hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st) {
     if (px > 32 * ST_STAGE_MAX || p.s[i].rows * p.s[i].H > 32 * ST_OUT_MAX) return hipErrorInvalidValue;
   }
   size_t lds = (tile_px + 10) * kDownCh * sizeof(float);   // tile + taps + bias
-  if (algo == 0) hipLaunchKernelGGL(sobel_tdiff_kernel<0>, dim3(p.total_blocks), dim3(ST_THREADS), lds, st, p);
-  else hipLaunchKernelGGL(sobel_tdiff_kernel<1>, dim3(p.total_blocks), dim3(ST_THREADS), lds, st, p);
+  dim3 grid(q.total_s + q.total_t);
+  const int nt = knob("OFFK_K2_NT", 0);     // bit 0: non-temporal loads, bit 1: non-temporal stores (A/B: no gain here)
+  if (algo < 0 || algo > 3) return hipErrorInvalidValue;
+#define OFFK_K2_LAUNCH(A, NL, NS) hipLaunchKernelGGL((sobel_tdiff_kernel<A, NL, NS>), grid, dim3(ST_THREADS), lds, st, q)
+  if (algo == 1) {
+    if (nt & 1) OFFK_K2_LAUNCH(1, 1, 0); else OFFK_K2_LAUNCH(1, 0, 0);
+  } else {
+    switch (nt & 3) {
+      case 0: OFFK_K2_LAUNCH(0, 0, 0); break;
+      case 1: OFFK_K2_LAUNCH(0, 1, 0); break;
+      case 2: OFFK_K2_LAUNCH(0, 0, 1); break;
+      default: OFFK_K2_LAUNCH(0, 1, 1); break;
+    }
+  }
+#undef OFFK_K2_LAUNCH
   return hipGetLastError();
 }
 

@@ -162,6 +162,10 @@ class OffForward:
         _lib.check(self.lib.offk_sobel_tdiff(self._h, _stream(), site, _ptr(G), _ptr(D), _ptr(M),
                                              M.shape[-1], m_coff, algo), self._h)
 
+    def sobel_tdiff_all(self, algo=0):
+        """Grouped K2 launch over the workspace G/D regions (after off_units / forward)."""
+        _lib.check(self.lib.offk_sobel_tdiff_all(self._h, _stream(), _ptr(self.workspace), algo), self._h)
+
     def set_conv_plan(self, conv_key, tile_cfg, splitk):
         _lib.check(self.lib.offk_set_conv_plan(self._h, conv_key.encode(), tile_cfg, splitk), self._h)
 
