@@ -36,13 +36,17 @@ struct ConvArgs {
   float* partial;      // [splitk][M][Co] when splitk > 1
 };
 
-template <int KH, int KW, int S, int TM, int TN, int WM, int WN>
+// PREC 0: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
+template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int RA = BM / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As0 = smem;                         // [2][BM][LDS_K]
-  float* Bs0 = smem + 2 * BM * LDS_K;        // [2][BN][LDS_K]
+  float* As0 = smem;                         // fp32: [2][BM][LDS_K]
+  float* Bs0 = smem + 2 * BM * LDS_K;        // fp32: [2][BN][LDS_K]
+  // bf16x3: per stage  A_hi [BM] | A_lo [BM] | B_hi [BN] | B_lo [BN]  rows of B3_ROW bytes
+  constexpr int A_PLANE = BM * B3_ROW, B_PLANE = BN * B3_ROW, B3_STAGE = 2 * (A_PLANE + B_PLANE);
+  char* smem_c = reinterpret_cast<char*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -98,14 +102,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       rg[RA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
   };
   auto store_tile = [&](int stage) {
-    float* As = As0 + stage * BM * LDS_K;
+    if (PREC == 0) {
+      float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
-    for (int r = 0; r < RA; ++r)
-      *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[r];
-    float* Bs = Bs0 + stage * BN * LDS_K;
+      for (int r = 0; r < RA; ++r)
+        *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[r];
+      float* Bs = Bs0 + stage * BN * LDS_K;
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
-      *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[RA + r];
+      for (int r = 0; r < RB; ++r)
+        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[RA + r];
+    } else {
+      char* st = smem_c + stage * B3_STAGE;
+#pragma unroll
+      for (int r = 0; r < RA; ++r) b3_store(st, A_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[r]);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) b3_store(st + 2 * A_PLANE, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[RA + r]);
+    }
   };
 
   WaveAcc<TM, TN> acc;
@@ -116,8 +128,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int st = (kt - kt_begin) & 1;
     if (kt + 1 < kt_end) load_tile(kt + 1);
-    acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
-                  Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
+    if (PREC == 0)
+      acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
+                    Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
+    else
+      b3_mma_ktile<TM, TN>(acc.acc, smem_c + st * B3_STAGE + wm * (32 * TM) * B3_ROW, A_PLANE,
+                           smem_c + st * B3_STAGE + 2 * A_PLANE + wn * (32 * TN) * B3_ROW, B_PLANE, lane);
     if (kt + 1 < kt_end) store_tile(st ^ 1);
     __syncthreads();
   }
@@ -182,12 +198,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
   }
 }
 
-template <int KH, int KW, int S, int TM, int TN, int WM, int WN>
+template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
+  constexpr size_t lds = PREC == 0 ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * B3_ROW;
   if (a.Co % BN) return hipErrorInvalidConfiguration;
-  auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN>;
+  auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN, PREC>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -213,17 +229,21 @@ constexpr int kNumTileCfg = 6;
 const int kTileBM[kNumTileCfg] = {128, 128, 256, 64, 64, 128};
 const int kTileBN[kNumTileCfg] = {128, 64, 64, 64, 128, 256};
 
-template <int KH, int KW, int S>
-static hipError_t launch_shape(const ConvArgs& a, int cfg, hipStream_t st) {
+template <int KH, int KW, int S, int PREC>
+static hipError_t launch_prec(const ConvArgs& a, int cfg, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_cfg<KH, KW, S, 2, 2, 2, 2>(a, st);
-    case 1: return launch_cfg<KH, KW, S, 1, 2, 4, 1>(a, st);
-    case 2: return launch_cfg<KH, KW, S, 2, 2, 4, 1>(a, st);
-    case 3: return launch_cfg<KH, KW, S, 1, 1, 2, 2>(a, st);
-    case 4: return launch_cfg<KH, KW, S, 1, 2, 2, 2>(a, st);
-    case 5: return launch_cfg<KH, KW, S, 2, 4, 2, 2>(a, st);
+    case 0: return launch_cfg<KH, KW, S, 2, 2, 2, 2, PREC>(a, st);
+    case 1: return launch_cfg<KH, KW, S, 1, 2, 4, 1, PREC>(a, st);
+    case 2: return launch_cfg<KH, KW, S, 2, 2, 4, 1, PREC>(a, st);
+    case 3: return launch_cfg<KH, KW, S, 1, 1, 2, 2, PREC>(a, st);
+    case 4: return launch_cfg<KH, KW, S, 1, 2, 2, 2, PREC>(a, st);
+    case 5: return launch_cfg<KH, KW, S, 2, 4, 2, 2, PREC>(a, st);
     default: return hipErrorInvalidConfiguration;
   }
+}
+template <int KH, int KW, int S>
+static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t st) {
+  return prec == 0 ? launch_prec<KH, KW, S, 0>(a, cfg, st) : launch_prec<KH, KW, S, 1>(a, cfg, st);
 }
 
 // Heuristic when the caller gives no plan, distilled from tools/tune_conv.py sweeps on MI355X:
@@ -246,6 +266,7 @@ void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_ou
 
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   *why = nullptr;
+  if (d.precision != 0 && d.precision != 1) { *why = "conv2d: precision must be 0 (fp32) or 1 (bf16x3)"; return hipErrorInvalidValue; }
   if (d.Ci % 32 || d.Co % 64 || d.x_cs % 4 || d.x_coff % 4 || d.y_cs % 4 || d.y_coff % 4 || d.y_cs <= 0 ||
       (d.res && (d.res_cs % 4 || d.res_coff % 4))) {
     *why = "conv2d: need Ci % 32 == 0, Co % 64 == 0, 16-byte aligned channel slices";
@@ -272,10 +293,10 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   const int key = d.KH * 100 + d.KW * 10 + d.stride;
   hipError_t e;
   switch (key) {
-    case 111: e = launch_shape<1, 1, 1>(a, cfg, st); break;
-    case 331: e = launch_shape<3, 3, 1>(a, cfg, st); break;
-    case 552: e = launch_shape<5, 5, 2>(a, cfg, st); break;
-    case 772: e = launch_shape<7, 7, 2>(a, cfg, st); break;
+    case 111: e = launch_shape<1, 1, 1>(a, cfg, d.precision, st); break;
+    case 331: e = launch_shape<3, 3, 1>(a, cfg, d.precision, st); break;
+    case 552: e = launch_shape<5, 5, 2>(a, cfg, d.precision, st); break;
+    case 772: e = launch_shape<7, 7, 2>(a, cfg, d.precision, st); break;
     default: *why = "conv2d: unsupported kernel/stride (have 1x1s1, 3x3s1, 5x5s2, 7x7s2)"; return hipErrorInvalidValue;
   }
   if (e == hipErrorInvalidConfiguration) *why = "conv2d: tile configuration does not divide Co";

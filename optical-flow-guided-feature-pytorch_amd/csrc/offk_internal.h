@@ -22,6 +22,7 @@ struct ConvDesc {
   int tile_cfg = -1, splitk = 0;          // < 0 / < 1: pick automatically
   float* partial = nullptr;               // split-K slab scratch
   size_t partial_floats = 0;
+  int precision = 0;                      // 0 = exact fp32 MFMA, 1 = bf16x3
 };
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
