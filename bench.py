@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--length", type=int, default=7)
     ap.add_argument("--variant", choices=("rgb", "flow"), default="rgb")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="fp32")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -121,7 +122,7 @@ def main():
     weights = synth.make_weights(variant)
     feats_np = synth.make_features(B, L, config_id=2, clip_offset=rank * B)
     feats = [torch.from_numpy(f).to(dev) for f in feats_np]
-    h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, consensus, device=dev)
+    h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, consensus, device=dev, precision=args.precision)
     h.load_state_dict(weights)
     arr = h._feat_array(feats)
     rows = h.out_rows()
@@ -173,7 +174,8 @@ def main():
         res = {
             "metric": "OFF-forward clips/sec (7-seg 224x224)", "value": clips_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, f32 accumulate)",
             "data": "synthetic (portable counter-based generator: ReLU-like non-negative BN-Inception "
                     "feature maps, fan-in-scaled uniform weights; features resident in HBM)",
             "config": {"workload": "%s_OFF forward, batch=%d clips/GPU x %d segments, nine 224x224-geometry "

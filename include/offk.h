@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 1
+#define OFFK_ABI_VERSION 2
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -61,6 +61,13 @@ enum offk_feat_layout {
   OFFK_FEAT_NHWC = 1  /* channels_last physical layout of the same logical tensor */
 };
 
+enum offk_precision {
+  OFFK_PRECISION_FP32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
+  OFFK_PRECISION_BF16X3 = 1 /* each fp32 operand split into bf16 hi + lo, a*b = a_lo*b_hi + a_hi*b_lo +
+                               a_hi*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate: ~1e-5 relative
+                               to the fp32 path (budget 1e-3) at 3/16 of its matrix-core cycles */
+};
+
 typedef struct offk_config {
   int32_t batch;       /* B clips            (BNInception_OFF.batch,  RGB_OFF.py:35) */
   int32_t length;      /* L segments / clip  (BNInception_OFF.length, RGB_OFF.py:36), >= 2 */
@@ -70,6 +77,7 @@ typedef struct offk_config {
   int32_t num_classes; /* 101 (RGB_OFF.py:332-334) */
   int32_t feat_layout; /* enum offk_feat_layout */
   int32_t device;      /* HIP device ordinal the handle lives on */
+  int32_t precision;   /* enum offk_precision: arithmetic of the contractions (1x1 reduce, fusion convs) */
 } offk_config;
 
 typedef struct offk_handle offk_handle;
@@ -154,11 +162,13 @@ int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_i
 /* Same with an explicit plan (tuning / micro-benchmarks): tile_cfg 0..5 = block tile 128x128,
  * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), < 0 = automatic; splitk >= 1
  * K-slices whose fp32 partial slabs [splitk][M][Co] go to `partial` (summed in slice order by
- * a second launch, so results are bit-reproducible); splitk < 1 = automatic. */
+ * a second launch, so results are bit-reproducible); splitk < 1 = automatic; precision = enum
+ * offk_precision. */
 int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci,
                    const float* w, const float* bias, int Co, int KH, int KW, int stride, int pad,
                    const float* res, int res_cstride, int res_coff, int flags,
-                   float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial, size_t partial_floats);
+                   float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial, size_t partial_floats,
+                   int precision);
 /* [Co][Ci][KH][KW] (PyTorch) -> [Co][Ci/32][KH*KW][32]; both device pointers. */
 int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_packed);
 /* Override the plan offk_forward uses for one fusion conv (key = its state_dict name without

@@ -10,6 +10,8 @@ NUM_STAGES = 6
 STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7", "heads")
 
 CONV_RELU_IN, CONV_RELU_PRE, CONV_RELU_POST = 1, 2, 4
+PRECISION_FP32, PRECISION_BF16X3 = 0, 1
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
 
 
 class OffkError(RuntimeError):
@@ -20,7 +22,7 @@ class OffkConfig(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("length", ctypes.c_int32), ("variant", ctypes.c_int32),
                 ("slice_mode", ctypes.c_int32), ("consensus", ctypes.c_int32),
                 ("num_classes", ctypes.c_int32), ("feat_layout", ctypes.c_int32),
-                ("device", ctypes.c_int32)]
+                ("device", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
 _c = ctypes
@@ -47,7 +49,7 @@ SIGNATURES = {
     "offk_off_units": (_I, [_P, _P, _c.POINTER(_F), _P]),
     "offk_conv2d": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I]),
     "offk_conv2d_ex": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I,
-                            _I, _I, _F, _c.c_size_t]),
+                            _I, _I, _F, _c.c_size_t, _I]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),
     "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),
@@ -72,7 +74,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 1:
+    if lib.offk_abi_version() != 2:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

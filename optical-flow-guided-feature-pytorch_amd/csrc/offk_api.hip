@@ -260,6 +260,7 @@ int run_off_units(offk_handle* h, hipStream_t st, const float* const feats[], vo
   memset(&pp, 0, sizeof(pp));
   pp.nsites = kNumSites; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
+  pp.precision = h->cfg.precision;
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
     int s = kPwOrder[i];
@@ -290,6 +291,7 @@ int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, co
   d.y = y; d.y_cs = y_cs; d.y_coff = y_coff;
   d.tile_cfg = h->conv_cfg[id]; d.splitk = h->conv_splitk[id];
   d.partial = h->cur_splitk; d.partial_floats = h->splitk_floats;
+  d.precision = h->cfg.precision;
   const char* why = nullptr;
   hipError_t e = conv2d_launch(d, st, &why);
   if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + ": " + (why ? why : hipGetErrorString(e)));
@@ -317,6 +319,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   if (cfg->slice_mode != OFFK_SLICE_REFERENCE_FLAT && cfg->slice_mode != OFFK_SLICE_PER_CLIP) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad slice_mode");
   if (cfg->consensus != OFFK_CONSENSUS_NONE && cfg->consensus != OFFK_CONSENSUS_AVG) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad consensus");
   if (cfg->feat_layout != OFFK_FEAT_NCHW && cfg->feat_layout != OFFK_FEAT_NHWC) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad feat_layout");
+  if (cfg->precision != OFFK_PRECISION_FP32 && cfg->precision != OFFK_PRECISION_BF16X3) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad precision");
   if (cfg->num_classes < 1 || cfg->num_classes > 4096) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad num_classes");
   if ((long long)cfg->batch * cfg->length * 784 * 320 > 0x7fffffffLL) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: batch*length too large for one call; shard the clips");
   int ndev = 0;
@@ -493,6 +496,7 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
   memset(&pp, 0, sizeof(pp));
   pp.nsites = 1; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
+  pp.precision = h->cfg.precision;
   fill_pw_site(h, site, feat, G, D, &pp.s[0]);
   pp.total_blocks = pw_blocks_for(pp.s[0].M);
   HIP_TRY(h, pw_reduce_launch(pp, static_cast<hipStream_t>(stream)));
@@ -649,13 +653,14 @@ int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_i
 int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci, const float* w,
                    const float* bias, int Co, int KH, int KW, int stride, int pad, const float* res, int res_cstride,
                    int res_coff, int flags, float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial,
-                   size_t partial_floats) {
+                   size_t partial_floats, int precision) {
   if (!x || !w || !y || n_img < 1 || H < 1 || W < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_conv2d_ex: bad argument");
   ConvDesc d;
   d.x = x; d.x_cs = x_cstride; d.x_coff = x_coff; d.n_img = n_img; d.H = H; d.W = W; d.Ci = Ci;
   d.w = w; d.bias = bias; d.Co = Co; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad;
   d.res = res; d.res_cs = res_cstride; d.res_coff = res_coff; d.flags = flags; d.y = y; d.y_cs = y_cstride; d.y_coff = y_coff;
   d.tile_cfg = tile_cfg; d.splitk = splitk; d.partial = partial; d.partial_floats = partial_floats;
+  d.precision = precision;
   const char* why = nullptr;
   hipError_t e = conv2d_launch(d, static_cast<hipStream_t>(stream), &why);
   if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));

@@ -42,6 +42,7 @@ struct PwParams {
   PwSite s[kNumSites];
   int nsites, total_blocks;
   int L, P, slice_mode, nhwc;
+  int precision;       // 0 = exact fp32 MFMA, 1 = bf16x3
 };
 int pw_blocks_for(int M);
 hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st);

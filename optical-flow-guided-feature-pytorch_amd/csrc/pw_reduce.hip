@@ -49,9 +49,40 @@ __device__ __forceinline__ void pw_mma(f32x16 (&acc)[PW_TN], const float* As, co
   }
 }
 
+// bf16x3 twin of pw_mma (see offk_common.h): planes A_hi | A_lo | B_hi | B_lo
+template <int NT>
+__device__ __forceinline__ void pw_mma_b3(f32x16 (&acc)[PW_TN], const char* Ahi, const char* Bhi, int lane) {
+  constexpr int A_PLANE = PW_BM * B3_ROW, B_PLANE = PW_BN * B3_ROW;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll 1
+  for (int s = 0; s < BK / 16; ++s) {
+    const int off = r * B3_ROW + (16 * s + 8 * h) * 2;
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + off);
+    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + off);
+    bf16x8 bh[NT], bl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bh[t] = *reinterpret_cast<const bf16x8*>(Bhi + t * 32 * B3_ROW + off);
+      bl[t] = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + t * 32 * B3_ROW + off);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+    }
+  }
+}
+
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
-  __shared__ __attribute__((aligned(16))) float As[PW_BM * LDS_K];
-  __shared__ __attribute__((aligned(16))) float Bs[PW_BN * LDS_K];
+  constexpr int A_PLANE = PW_BM * B3_ROW, B_PLANE = PW_BN * B3_ROW;
+  constexpr int LDS_BYTES = PREC == 0 ? (PW_BM + PW_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  float* As = reinterpret_cast<float*>(lds);                    // fp32: [128][LDS_K] then [160][LDS_K]
+  float* Bs = As + PW_BM * LDS_K;
+  char* Ahi = lds;                                              // bf16x3: A_hi | A_lo | B_hi | B_lo
+  char* Bhi = lds + 2 * A_PLANE;
 
   // block -> site: field-wise scalar select chain over the (few) table entries; indexing
   // the by-value kernarg array with a runtime index (or copying a whole entry) goes
@@ -132,6 +163,24 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
       rg[4 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
   };
   auto store_tile = [&]() {
+    if (PREC == 1) {
+      if (mode == 0) {
+        const int row = 4 * (tid & 31), kq = tid >> 5;
+        b3_store(Ahi, A_PLANE, row, kq, make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x));
+        b3_store(Ahi, A_PLANE, row + 1, kq, make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y));
+        b3_store(Ahi, A_PLANE, row + 2, kq, make_float4(rg[0].z, rg[1].z, rg[2].z, rg[3].z));
+        b3_store(Ahi, A_PLANE, row + 3, kq, make_float4(rg[0].w, rg[1].w, rg[2].w, rg[3].w));
+      } else if (mode == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b3_store(Ahi, A_PLANE, tid & 127, (tid >> 7) + 2 * r, rg[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b3_store(Ahi, A_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < PW_TN; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[4 + r]);
+      return;
+    }
     if (mode == 0) {
       float* dst = As + 4 * (tid & 31) * LDS_K + 4 * (tid >> 5);
       *reinterpret_cast<float4*>(dst) = make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x);
@@ -164,8 +213,13 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nkt) load_tile((kt + 1) * BK);
-    if (down_active) pw_mma<5>(acc, As + wave * 32 * LDS_K, Bs, lane);
-    else pw_mma<4>(acc, As + wave * 32 * LDS_K, Bs, lane);
+    if (PREC == 0) {
+      if (down_active) pw_mma<5>(acc, As + wave * 32 * LDS_K, Bs, lane);
+      else pw_mma<4>(acc, As + wave * 32 * LDS_K, Bs, lane);
+    } else {
+      if (down_active) pw_mma_b3<5>(acc, Ahi + wave * 32 * B3_ROW, Bhi, lane);
+      else pw_mma_b3<4>(acc, Ahi + wave * 32 * B3_ROW, Bhi, lane);
+    }
     __syncthreads();
   }
 
@@ -192,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
 
 hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st) {
   if (p.total_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pw_reduce_kernel, dim3(p.total_blocks), dim3(256), 0, st, p);
+  if (p.precision == 0) hipLaunchKernelGGL(pw_reduce_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(pw_reduce_kernel<1>, dim3(p.total_blocks), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 

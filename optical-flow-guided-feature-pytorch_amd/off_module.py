@@ -36,8 +36,9 @@ class _SobelHolder(nn.Module):
 
 class OFFSubNetwork(nn.Module):
     def __init__(self, num_classes=spec.NUM_CLASSES, batch=16, length=7, variant="rgb",
-                 slice_mode=spec.SLICE_FLAT, consensus=None, feat_layout=0):
+                 slice_mode=spec.SLICE_FLAT, consensus=None, feat_layout=0, precision="fp32"):
         super().__init__()
+        self.precision = precision
         if variant not in _VARIANTS:
             raise ValueError("variant must be one of %s" % sorted(_VARIANTS))
         self.variant_name = variant
@@ -81,10 +82,10 @@ class OFFSubNetwork(nn.Module):
         return out
 
     def _handle(self, device):
-        key = (self.batch, self.length, self.variant, self.slice_mode, self.consensus_avg, self.feat_layout, str(device))
+        key = (self.batch, self.length, self.variant, self.slice_mode, self.consensus_avg, self.feat_layout, str(device), self.precision)
         if self._rt is None or self._rt_key != key:
             self._rt = runtime.OffForward(self.batch, self.length, self.variant, self.slice_mode,
-                                          self.consensus_avg, self.num_classes, self.feat_layout, device)
+                                          self.consensus_avg, self.num_classes, self.feat_layout, device, self.precision)
             self._rt_key = key
             self._dirty = True
         if self._dirty:
@@ -116,14 +117,14 @@ class BNInception_OFF(nn.Module):
     """
 
     def __init__(self, num_classes=1000, batch=16, length=7, variant="rgb", backbone=None,
-                 slice_mode=spec.SLICE_FLAT):
+                 slice_mode=spec.SLICE_FLAT, precision="fp32"):
         super().__init__()
         self.batch, self.length = batch, length
         self.modality_fuse = False                       # Flow_OFF.py:45
         self.consensus_type = "avg"                      # RGB_OFF.py:39
         self.variant_name = variant
         self.backbone = backbone
-        self.off = OFFSubNetwork(num_classes, batch, length, variant, slice_mode)
+        self.off = OFFSubNetwork(num_classes, batch, length, variant, slice_mode, precision=precision)
 
     def state_dict(self, *a, **kw):
         sd = super().state_dict(*a, **kw)

@@ -35,7 +35,7 @@ class OffForward:
     """
 
     def __init__(self, batch, length, variant=spec.VARIANT_RGB, slice_mode=spec.SLICE_FLAT,
-                 consensus=None, num_classes=spec.NUM_CLASSES, feat_layout=0, device=None):
+                 consensus=None, num_classes=spec.NUM_CLASSES, feat_layout=0, device=None, precision=0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.OffkError("no HIP device visible: the OFF forward has no CPU path")
@@ -45,10 +45,11 @@ class OffForward:
         self.batch, self.length, self.variant = int(batch), int(length), int(variant)
         self.slice_mode, self.consensus, self.num_classes = int(slice_mode), bool(consensus), int(num_classes)
         self.feat_layout = int(feat_layout)
+        self.precision = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         self.N = self.batch * self.length
         self.P = self.batch * (self.length - 1)
         cfg = _lib.OffkConfig(self.batch, self.length, self.variant, self.slice_mode, int(self.consensus),
-                              self.num_classes, self.feat_layout, self.device.index or 0)
+                              self.num_classes, self.feat_layout, self.device.index or 0, self.precision)
         h = ctypes.c_void_p()
         _lib.check(self.lib.offk_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
@@ -182,7 +183,7 @@ class OffForward:
 
 # ---- handle-less stage kernels (channels-last tensors) ----------------------------------
 def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=None, y=None, y_coff=0,
-                tile_cfg=-1, splitk=0, w_packed=None):
+                tile_cfg=-1, splitk=0, w_packed=None, precision=0):
     """x: [n, H, W, Cs] fp32 CUDA; uses channels [x_coff, x_coff+Ci).  Returns y [n, Ho, Wo, Co]
     (or writes channels [y_coff, y_coff+Co) of the given y)."""
     lib = _lib.load()
@@ -202,7 +203,7 @@ def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=No
         part = torch.empty(nfl, dtype=torch.float32, device=x.device)
     _lib.check(lib.offk_conv2d_ex(_stream(), _ptr(x), cs, x_coff, n, H, W, Ci, _ptr(wp), _ptr(bias), Co, KH, KW,
                                   stride, pad, _ptr(res), res.shape[-1] if res is not None else 0, 0, flags,
-                                  _ptr(y), y.shape[-1], y_coff, tile_cfg, splitk, _ptr(part), nfl))
+                                  _ptr(y), y.shape[-1], y_coff, tile_cfg, splitk, _ptr(part), nfl, precision))
     return y
 
 

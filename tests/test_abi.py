@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for s in header_symbols():
         assert hasattr(raw, s), s
-    assert built.offk_abi_version() == 1
+    assert built.offk_abi_version() == 2
 
 
 def test_handleless_errors_are_reported(built):
@@ -51,7 +51,7 @@ def test_create_without_gpu_fails_loudly(built):
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    cfg = _lib.OffkConfig(1, 7, 0, 0, 0, 101, 0, 0)
+    cfg = _lib.OffkConfig(1, 7, 0, 0, 0, 101, 0, 0, 0)
     h = ctypes.c_void_p()
     rc = built.offk_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc == -5 and not h.value

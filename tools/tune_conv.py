@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tune_conv.json"))
     ap.add_argument("--only", default="")
+    ap.add_argument("--precision", type=int, default=0)
     args = ap.parse_args()
     P = args.pairs
     torch.manual_seed(0)
@@ -61,7 +62,7 @@ def main():
                 y = None
                 try:
                     for _ in range(2):
-                        y = runtime.conv2d_nhwc(x, w, b, s, p, tile_cfg=cfg, splitk=sk, w_packed=wp)
+                        y = runtime.conv2d_nhwc(x, w, b, s, p, tile_cfg=cfg, splitk=sk, w_packed=wp, precision=args.precision)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     part = torch.empty(max(sk, 1) * M * co, device="cuda") if sk > 1 else None
@@ -71,7 +72,7 @@ def main():
                     for _ in range(args.iters):
                         _lib.check(lib.offk_conv2d_ex(runtime._stream(), runtime._ptr(x), ci, 0, P, H, H, ci, runtime._ptr(wp),
                                                       runtime._ptr(b), co, k, k, s, p, None, 0, 0, 0, runtime._ptr(yb), co, 0,
-                                                      cfg, sk, runtime._ptr(part), part.numel() if part is not None else 0))
+                                                      cfg, sk, runtime._ptr(part), part.numel() if part is not None else 0, args.precision))
                     e1.record()
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / args.iters
