@@ -70,18 +70,31 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
     pooled[c] = s * inv;
   }
   __syncthreads();
+  // FC: a wave takes four output classes at a time (their weight-row loads are all in flight
+  // together), lanes along C with 16-B loads, wavefront-shuffle reduction
   const int lane = tid & 63, wave = tid >> 6;
-  for (int o = wave; o < ncls; o += 4) {
-    const float* wr = fw + (size_t)o * C;
-    float a = 0.f;
+  for (int o0 = wave * 4; o0 < ncls; o0 += 16) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int q = lane; q < nq; q += 64) {
-      const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * q);
       const float4 pv = *reinterpret_cast<const float4*>(pooled + 4 * q);
-      a = fmaf(wv.x, pv.x, a); a = fmaf(wv.y, pv.y, a); a = fmaf(wv.z, pv.z, a); a = fmaf(wv.w, pv.w, a);
+      float4 wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = min(o0 + j, ncls - 1);
+        wv[j] = *reinterpret_cast<const float4*>(fw + (size_t)o * C + 4 * q);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = fmaf(wv[j].x, pv.x, a[j]); a[j] = fmaf(wv[j].y, pv.y, a[j]);
+        a[j] = fmaf(wv[j].z, pv.z, a[j]); a[j] = fmaf(wv[j].w, pv.w, a[j]);
+      }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-    if (lane == 0) out[(size_t)img * ncls + o] = a + fb[o];
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a[j] += __shfl_down(a[j], off);
+      if (lane == 0 && o0 + j < ncls) out[(size_t)img * ncls + o0 + j] = a[j] + fb[o0 + j];
+    }
   }
 }
 

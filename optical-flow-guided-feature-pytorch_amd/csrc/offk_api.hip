@@ -51,6 +51,11 @@ const int kTunedP384[kNumConvs][2] = {
     {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
     {4, 12}, {3, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {4, 1},                          // fusion @14
     {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+// same sweep with --precision 1 (bf16x3 core)
+const int kTunedP384B3[kNumConvs][2] = {
+    {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
+    {0, 12}, {4, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 1}, {0, 3}, {0, 2},                          // fusion @14
+    {0, 6}, {3, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -335,8 +340,9 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->P = cfg->batch * (cfg->length - 1);
   for (int c = 0; c < kNumConvs; ++c) {
     const bool tuned = h->P == 384;
-    h->conv_cfg[c] = tuned ? kTunedP384[c][0] : -1;
-    h->conv_splitk[c] = tuned ? kTunedP384[c][1] : 0;
+    const int (*tab)[2] = cfg->precision == OFFK_PRECISION_BF16X3 ? kTunedP384B3 : kTunedP384;
+    h->conv_cfg[c] = tuned ? tab[c][0] : -1;
+    h->conv_splitk[c] = tuned ? tab[c][1] : 0;
   }
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;

@@ -21,6 +21,7 @@ from oracle import off_oracle as orc
 pytestmark = pytest.mark.gpu
 RTOL_NORTH_STAR = 1e-3
 RTOL = 2e-4
+PRECISIONS = ["fp32", "bf16x3"]   # bf16x3: split-fp32 on the bf16 matrix cores, measured ~1-3e-5 (tools/precision_report.py)
 
 
 def rel_err(a, b):
@@ -61,14 +62,15 @@ CONV_CASES = [  # (Ci, Co, k, stride, pad, H, n_img)  -- the distinct shapes of 
 ]
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("Ci,Co,k,stride,pad,H,n", CONV_CASES)
-def test_conv2d_vs_torch(rt, Ci, Co, k, stride, pad, H, n):
+def test_conv2d_vs_torch(rt, Ci, Co, k, stride, pad, H, n, prec):
     g = torch.Generator().manual_seed(Ci * 7 + Co + k)
     x = torch.randn(n, Ci, H, H, generator=g)
     w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
     b = torch.randn(Co, generator=g)
     ref = F.conv2d(x, w, b, stride=stride, padding=pad)
-    y = rt.conv2d_nhwc(nhwc(x), dev(w), dev(b), stride, pad)
+    y = rt.conv2d_nhwc(nhwc(x), dev(w), dev(b), stride, pad, precision=prec)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < RTOL
 
 
@@ -99,8 +101,9 @@ def test_conv2d_epilogues_and_slices(rt):
     assert rel_err(y.permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1) + res) < RTOL
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("cfg,splitk", [(0, 1), (1, 3), (2, 2), (3, 4), (4, 1), (5, 2), (-1, 0)])
-def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk):
+def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk, prec):
     """Every tile configuration and the deterministic split-K reduction give the same conv."""
     from offk_amd import _lib
     g = torch.Generator().manual_seed(77)
@@ -111,10 +114,10 @@ def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk):
     res = torch.randn(n, Co, H, H, generator=g)
     ref = torch.relu(torch.relu(F.conv2d(x, w, b, padding=1)) + res)
     y = rt.conv2d_nhwc(nhwc(x), dev(w), dev(b), 1, 1, res=nhwc(res), flags=_lib.CONV_RELU_PRE | _lib.CONV_RELU_POST,
-                       tile_cfg=cfg, splitk=splitk)
+                       tile_cfg=cfg, splitk=splitk, precision=prec)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < RTOL
     y2 = rt.conv2d_nhwc(nhwc(x), dev(w), dev(b), 1, 1, res=nhwc(res), flags=_lib.CONV_RELU_PRE | _lib.CONV_RELU_POST,
-                        tile_cfg=cfg, splitk=splitk)
+                        tile_cfg=cfg, splitk=splitk, precision=prec)
     assert torch.equal(y, y2)      # split-K sums slabs in a fixed order: bit-reproducible
 
 
@@ -131,19 +134,20 @@ def test_head_and_consensus(rt):
     assert rel_err(rt.segment_consensus(dev(x), 4), orc.segment_consensus(x, 4)) < 1e-6
 
 
-def make_handle(rt, B, L, variant, slice_mode=spec.SLICE_FLAT, consensus=None, weights=None):
-    h = rt.OffForward(B, L, variant, slice_mode, consensus)
+def make_handle(rt, B, L, variant, slice_mode=spec.SLICE_FLAT, consensus=None, weights=None, precision="fp32"):
+    h = rt.OffForward(B, L, variant, slice_mode, consensus, precision=precision)
     w = synth.make_weights(variant) if weights is None else weights
     assert h.load_state_dict(w) == []
     assert h.missing_weights()[0] == 0
     return h, orc.to_torch_weights(w)
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("slice_mode", [spec.SLICE_FLAT, spec.SLICE_PER_CLIP])
 @pytest.mark.parametrize("site", range(spec.NUM_SITES))
-def test_pw_reduce_vs_oracle(rt, site, slice_mode):
+def test_pw_reduce_vs_oracle(rt, site, slice_mode, prec):
     B, L = 2, 3
-    h, w = make_handle(rt, B, L, spec.VARIANT_RGB, slice_mode)
+    h, w = make_handle(rt, B, L, spec.VARIANT_RGB, slice_mode, precision=prec)
     name, C, H = spec.SITES[site]
     x = torch.from_numpy(synth.make_features(B, L, 4)[site])
     G, D = h.pw_reduce(site, dev(x))
@@ -181,11 +185,12 @@ def test_sobel_tdiff_vs_oracle(rt, site, variant, algo):
 GOLDEN = ["rgb_b1_l7", "rgb_b2_l3", "rgb_b3_l7", "flow_b1_l7", "flow_b2_l3", "flow_b3_l7"]
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("tag", GOLDEN)
-def test_forward_vs_golden_and_oracle(rt, tag, golden_dir):
+def test_forward_vs_golden_and_oracle(rt, tag, golden_dir, prec):
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
     variant, B, L, cfg = (int(v) for v in g["meta"])
-    h, w = make_handle(rt, B, L, variant, consensus=False)
+    h, w = make_handle(rt, B, L, variant, consensus=False, precision=prec)
     feats_np = synth.make_features(B, L, cfg)
     out7, out14, out28 = h.forward([dev(f) for f in feats_np])
     torch.cuda.synchronize()
@@ -263,11 +268,12 @@ def test_missing_weight_fails_loudly(rt):
         h.set_weight("conv1_7x7_s2.weight", np.zeros((64, 3, 7, 7), dtype=np.float32))
 
 
-def test_full_size_b64_vs_oracle(rt):
-    """BASELINE config 2 (RGB_OFF, B=64, L=7) against the oracle at full size."""
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_full_size_b64_vs_oracle(rt, prec):
+    """BASELINE config 2 (RGB_OFF, B=64, L=7) against the oracle at full size, both arithmetic modes."""
     B, L = 64, 7
     feats = synth.make_features(B, L, 2)
-    h, w = make_handle(rt, B, L, spec.VARIANT_RGB)
+    h, w = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
     out7, out14, out28 = h.forward([dev(f) for f in feats])
     torch.cuda.synchronize()
     with torch.no_grad():
