@@ -50,6 +50,7 @@ SIGNATURES = {
     "offk_conv2d": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I]),
     "offk_conv2d_ex": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I,
                             _I, _I, _F, _c.c_size_t, _I]),
+    "offk_split_bf16x3": (_I, [_P, _F, _c.c_size_t, _F]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),
     "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),

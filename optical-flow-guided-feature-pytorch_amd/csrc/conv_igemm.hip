@@ -40,13 +40,9 @@ struct ConvArgs {
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr int RA = BM / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;                         // fp32: [2][BM][LDS_K]
   float* Bs0 = smem + 2 * BM * LDS_K;        // fp32: [2][BN][LDS_K]
-  // bf16x3: per stage  A_hi [BM] | A_lo [BM] | B_hi [BN] | B_lo [BN]  rows of B3_ROW bytes
-  constexpr int A_PLANE = BM * B3_ROW, B_PLANE = BN * B3_ROW, B3_STAGE = 2 * (A_PLANE + B_PLANE);
-  char* smem_c = reinterpret_cast<char*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -64,12 +60,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int nkt_all = TAPS * (p.Ci / BK);
   const int kt_begin = (int)((long long)nkt_all * zs / p.splitk), kt_end = (int)((long long)nkt_all * (zs + 1) / p.splitk);
 
-  // per-thread A rows: (tid>>3) + 32*r ; the pixel decode is loop invariant
-  int hi0[RA], wi0[RA];
-  size_t pix0[RA];
+  // Loader mapping.  fp32: thread = (row (tid>>3) + 32*r, 4 k at 4*(tid&7)), 16 B per row visit.
+  // bf16x3: thread = (row (tid>>2) + 64*r, 8 k at 8*(tid&3)): 32 B of fp32 activations that become
+  // one 16-B hi and one 16-B lo LDS store; weights arrive pre-split (hi plane, lo plane) and go
+  // to LDS untouched.
+  constexpr int RSH = PREC == 0 ? 3 : 2;            // row = tid >> RSH
+  constexpr int RSTEP = PREC == 0 ? 32 : 64;
+  constexpr int NRA = BM / RSTEP, NRB = BN / RSTEP;  // row visits per thread
+  constexpr int VA = PREC == 0 ? 1 : 2;              // float4 registers per A row visit
+  constexpr int VB = PREC == 0 ? 1 : 2;              // 16-B registers per B row visit (b3: hi, lo)
+  const int kpos = PREC == 0 ? 4 * (tid & 7) : 8 * (tid & 3);
+
+  int hi0[NRA], wi0[NRA];
+  size_t pix0[NRA];
 #pragma unroll
-  for (int r = 0; r < RA; ++r) {
-    int m = m0 + (tid >> 3) + 32 * r;
+  for (int r = 0; r < NRA; ++r) {
+    int m = m0 + (tid >> RSH) + RSTEP * r;
     bool ok = m < p.M;
     int mm = ok ? m : 0;
     int img = mm / (p.Ho * p.Wo);
@@ -79,44 +85,106 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     wi0[r] = wo * S - p.pad;
     pix0[r] = (size_t)img * p.H * p.W;
   }
-  const float* xbase = p.x + p.x_coff + 4 * (tid & 7);
+  const float* xbase = p.x + p.x_coff + kpos;
   const bool relu_in = p.flags & OFFK_CONV_RELU_IN_;
-  // weight rows (tid>>3) + 32*r of this block's N slab, 16 B at k = 4*(tid&7)
+  // fp32: weight rows of this block's N slab, fp32 [Co][K].  bf16x3: bf16 hi plane [Co][K] then lo plane.
   const float* wbase = p.w + (size_t)(n0 + (tid >> 3)) * K + 4 * (tid & 7);
+  const unsigned short* wb3 = reinterpret_cast<const unsigned short*>(p.w) + (size_t)(n0 + (tid >> 2)) * K + 8 * (tid & 3);
+  const size_t wlo_off = (size_t)p.Co * K;           // elements from the hi plane to the lo plane
 
-  constexpr int RB = BN / 32;
-  float4 rg[RA + RB];   // prefetch registers: A rows then B rows
+  float4 rg[NRA * VA + NRB * VB];   // prefetch registers: A rows then B rows (one array: two arrays end up in scratch)
   auto load_tile = [&](int kt) {
     int chunk = kt / TAPS, tap = kt - chunk * TAPS, c0 = chunk * BK;
     int kh = tap / KW, kw = tap - kh * KW;
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
+    for (int r = 0; r < NRA; ++r) {
       int hi = hi0[r] + kh, wi = wi0[r] + kw;
       bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(xbase + (pix0[r] + (size_t)(hi * p.W + wi)) * p.x_cs + c0);
-      rg[r] = relu_in ? relu4(v) : v;
-    }
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
-      rg[RA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
+      for (int v = 0; v < VA; ++v) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) t = *reinterpret_cast<const float4*>(xbase + (pix0[r] + (size_t)(hi * p.W + wi)) * p.x_cs + c0 + 4 * v);
+        rg[r * VA + v] = relu_in ? relu4(t) : t;
+      }
+    }
+    if (PREC == 0) {
+#pragma unroll
+      for (int r = 0; r < NRB; ++r)
+        rg[NRA * VA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
+    } else {
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) {
+        const unsigned short* q = wb3 + (size_t)64 * r * K + kt * BK;
+        rg[NRA * VA + 2 * r] = *reinterpret_cast<const float4*>(q);
+        rg[NRA * VA + 2 * r + 1] = *reinterpret_cast<const float4*>(q + wlo_off);
+      }
+    }
   };
+  // bf16x3 LDS image per stage: A_hi [BM] | A_lo [BM] | B_hi [BN] | B_lo [BN], rows of 64 B (32 bf16), the
+  // 16-B chunk c of row r stored at chunk c ^ ((r >> 2) & 3): conflict-free for the 16-B stores (8
+  // consecutive lanes = 2 whole rows = one 128-B bank row) and for the ds_read_b128 operand reads (the 16
+  // lanes of a read group hit 16 distinct 16-B slots of the 256-B bank row).
+  constexpr int B3R = 64;
+  constexpr int A_PLANE = BM * B3R, B_PLANE = BN * B3R, B3_STAGE = 2 * (A_PLANE + B_PLANE);
+  char* smem_c = reinterpret_cast<char*>(smem);
   auto store_tile = [&](int stage) {
     if (PREC == 0) {
       float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
-      for (int r = 0; r < RA; ++r)
+      for (int r = 0; r < NRA; ++r)
         *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[r];
       float* Bs = Bs0 + stage * BN * LDS_K;
 #pragma unroll
-      for (int r = 0; r < RB; ++r)
-        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[RA + r];
+      for (int r = 0; r < NRB; ++r)
+        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[NRA + r];
     } else {
       char* st = smem_c + stage * B3_STAGE;
 #pragma unroll
-      for (int r = 0; r < RA; ++r) b3_store(st, A_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[r]);
+      for (int r = 0; r < NRA; ++r) {
+        const int row = (tid >> 2) + 64 * r;
+        uint2 h0, l0, h1, l1;
+        split4(rg[2 * r], h0, l0);
+        split4(rg[2 * r + 1], h1, l1);
+        char* q = st + row * B3R + (((tid & 3) ^ ((row >> 2) & 3)) << 4);
+        *reinterpret_cast<uint4*>(q) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(q + A_PLANE) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+      }
 #pragma unroll
-      for (int r = 0; r < RB; ++r) b3_store(st + 2 * A_PLANE, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[RA + r]);
+      for (int r = 0; r < NRB; ++r) {
+        const int row = (tid >> 2) + 64 * r;
+        char* q = st + 2 * A_PLANE + row * B3R + (((tid & 3) ^ ((row >> 2) & 3)) << 4);
+        *reinterpret_cast<float4*>(q) = rg[NRA * VA + 2 * r];
+        *reinterpret_cast<float4*>(q + B_PLANE) = rg[NRA * VA + 2 * r + 1];
+      }
+    }
+  };
+  auto mma_b3 = [&](f32x16 (&acc)[TM][TN], int stage) {
+    const char* Ahi = smem_c + stage * B3_STAGE + wm * (32 * TM) * B3R;
+    const char* Bhi = smem_c + stage * B3_STAGE + 2 * A_PLANE + wn * (32 * TN) * B3R;
+    const int r = lane & 31, hh = lane >> 5;
+    const int base = r * B3R + ((hh ^ ((r >> 2) & 3)) << 4);    // chunk (2s + h) ^ swz == ((h ^ swz) ^ 2s)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int off = base ^ (s2 << 5);
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        ah[t] = *reinterpret_cast<const bf16x8*>(Ahi + t * 32 * B3R + off);
+        al[t] = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + t * 32 * B3R + off);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        bh[t] = *reinterpret_cast<const bf16x8*>(Bhi + t * 32 * B3R + off);
+        bl[t] = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + t * 32 * B3R + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
     }
   };
 
@@ -132,8 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
       acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
                     Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
     else
-      b3_mma_ktile<TM, TN>(acc.acc, smem_c + st * B3_STAGE + wm * (32 * TM) * B3_ROW, A_PLANE,
-                           smem_c + st * B3_STAGE + 2 * A_PLANE + wn * (32 * TN) * B3_ROW, B_PLANE, lane);
+      mma_b3(acc.acc, st);
     if (kt + 1 < kt_end) store_tile(st ^ 1);
     __syncthreads();
   }
@@ -201,7 +268,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = PREC == 0 ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * B3_ROW;
+  constexpr size_t lds = PREC == 0 ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64;
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN, PREC>;
   static bool attr_done = false;
@@ -315,6 +382,22 @@ __global__ void pack_oihw_kernel(const float* __restrict__ src, float* __restric
     int co = (int)(t / (Ci >> 5));
     dst[i] = src[((size_t)co * Ci + chunk * 32 + cl) * KHW + tap];
   }
+}
+
+// fp32 [n] -> bf16 hi plane [n] followed by bf16 lo plane [n] (the bf16x3 weight format)
+__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
+  for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    uint2 h, l;
+    split4(*reinterpret_cast<const float4*>(src + i), h, l);
+    *reinterpret_cast<uint2*>(dst + i) = h;
+    *reinterpret_cast<uint2*>(dst + n + i) = l;
+  }
+}
+hipError_t split_bf16_launch(const float* src, size_t n, void* dst, hipStream_t st) {
+  if (n % 4) return hipErrorInvalidValue;
+  int blocks = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<unsigned short*>(dst), n);
+  return hipGetLastError();
 }
 
 hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st) {

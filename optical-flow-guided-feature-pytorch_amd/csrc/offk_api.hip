@@ -53,9 +53,9 @@ const int kTunedP384[kNumConvs][2] = {
     {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
-    {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
-    {0, 12}, {4, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 1}, {0, 3}, {0, 2},                          // fusion @14
-    {0, 6}, {3, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+    {2, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1},   // fusion @28
+    {0, 3}, {3, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 1}, {0, 3}, {4, 1},                           // fusion @14
+    {0, 3}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -87,6 +87,7 @@ struct offk_handle {
   float* dw_b[kNumSites] = {};   // [32] or null
   float* sobel_w = nullptr;      // shared [9][32] (diag variant)
   float* conv_w[kNumConvs] = {};
+  float* conv_wb3[kNumConvs] = {};   // bf16x3 mode: bf16 hi plane | lo plane of conv_w (same byte size)
   float* conv_b[kNumConvs] = {};
   float* fc_w[3] = {};
   float* fc_b[3] = {};
@@ -291,7 +292,7 @@ int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, co
   const ConvSpec& c = kConvs[id];
   ConvDesc d;
   d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.n_img = n_img; d.H = H; d.W = H; d.Ci = c.Ci;
-  d.w = h->conv_w[id]; d.bias = h->conv_b[id]; d.Co = c.Co; d.KH = c.K; d.KW = c.K; d.stride = c.stride; d.pad = c.pad;
+  d.w = h->cfg.precision == OFFK_PRECISION_BF16X3 ? h->conv_wb3[id] : h->conv_w[id]; d.bias = h->conv_b[id]; d.Co = c.Co; d.KH = c.K; d.KW = c.K; d.stride = c.stride; d.pad = c.pad;
   d.res = res; d.res_cs = res_cs; d.res_coff = res_coff; d.flags = flags;
   d.y = y; d.y_cs = y_cs; d.y_coff = y_coff;
   d.tile_cfg = h->conv_cfg[id]; d.splitk = h->conv_splitk[id];
@@ -371,6 +372,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     add_slot(h, std::string(cs.key) + ".weight", {cs.Co, cs.Ci, cs.K, cs.K}, SK_CONV_W, c);
     add_slot(h, std::string(cs.key) + ".bias", {cs.Co}, SK_CONV_B, c);
     rc = dev_alloc(h, &h->conv_w[c], (size_t)cs.Co * cs.Ci * cs.K * cs.K);
+    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->conv_wb3[c], (size_t)cs.Co * cs.Ci * cs.K * cs.K);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->conv_b[c], cs.Co);
   }
   for (int k = 0; k < 3 && rc == OFFK_OK; ++k) {
@@ -438,6 +440,11 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
     case SK_CONV_W:
       if (kConvs[i].K == 1) rc = copy(h->conv_w[i]);
       else rc = staged([&](const float* t) { return pack_conv_weight_launch(t, kConvs[i].Co, kConvs[i].Ci, kConvs[i].K, kConvs[i].K, h->conv_w[i], nullptr); });
+      if (rc == OFFK_OK && h->conv_wb3[i]) {
+        hipError_t e = split_bf16_launch(h->conv_w[i], n, h->conv_wb3[i], nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) rc = fail_hip(h, e, "offk_set_weight split");
+      }
       break;
     case SK_CONV_B: rc = copy(h->conv_b[i]); break;
     case SK_FC_W: rc = copy(h->fc_w[i]); break;
@@ -682,6 +689,13 @@ int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int s
       return OFFK_OK;
     }
   return fail(h, OFFK_ERR_UNKNOWN_KEY, std::string("offk_set_conv_plan: unknown conv ") + conv_key);
+}
+
+int offk_split_bf16x3(void* stream, const float* src, size_t n, void* dst) {
+  if (!src || !dst || n == 0 || n % 4) return fail(nullptr, OFFK_ERR_INVALID, "offk_split_bf16x3: need n % 4 == 0");
+  hipError_t e = split_bf16_launch(src, n, dst, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_split_bf16x3");
+  return OFFK_OK;
 }
 
 int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_ohwi) {

@@ -14,7 +14,8 @@ constexpr int kGenCh = 128, kDownCh = 32, kUnitCh = 160;
 struct ConvDesc {
   const float* x; int x_cs, x_coff;
   int n_img, H, W, Ci;
-  const float* w; const float* bias;
+  const float* w;     // precision 0: fp32 [Co][K] in the library K order; precision 1: bf16 hi plane then lo plane
+  const float* bias;
   int Co, KH, KW, stride, pad;
   const float* res; int res_cs, res_coff;
   int flags;
@@ -26,6 +27,7 @@ struct ConvDesc {
 };
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
+hipError_t split_bf16_launch(const float* src, size_t n, void* dst, hipStream_t st);   // fp32 -> bf16 hi plane | lo plane
 hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st);
 
 // ---- K1 ------------------------------------------------------------------------

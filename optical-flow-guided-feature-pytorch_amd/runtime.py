@@ -193,6 +193,10 @@ def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=No
     if wp is None:
         wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=x.device)   # library K order [Co][Ci/32][KH*KW][32]
         _lib.check(lib.offk_pack_conv_weight(_stream(), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
+    if precision == 1 and w_packed is None:      # bf16x3: the kernel consumes pre-split hi | lo bf16 planes
+        ws = torch.empty_like(wp)
+        _lib.check(lib.offk_split_bf16x3(_stream(), _ptr(wp), wp.numel(), _ptr(ws)))
+        wp = ws
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     if y is None:

@@ -47,6 +47,10 @@ def main():
         wp = torch.empty(co, k, k, ci, device="cuda")
         from offk_amd import _lib
         _lib.check(_lib.load().offk_pack_conv_weight(runtime._stream(), runtime._ptr(w), co, ci, k, k, runtime._ptr(wp)))
+        if args.precision == 1:
+            ws = torch.empty_like(wp)
+            _lib.check(_lib.load().offk_split_bf16x3(runtime._stream(), runtime._ptr(wp), wp.numel(), runtime._ptr(ws)))
+            wp = ws
         Ho = (H + 2 * p - k) // s + 1
         M = P * Ho * Ho
         flops = 2.0 * M * co * ci * k * k
