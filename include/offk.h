@@ -191,6 +191,16 @@ int offk_head(void* stream, const float* x, int x_cstride, int x_coff, int n_img
  * Flow_OFF.py:867-876: x [B, T, C] -> mean over T -> [B, C]. */
 int offk_segment_consensus(void* stream, const float* x, int B, int T, int C, float* out);
 
+/* K7. Late score fusion as the eval scripts do it after the forward (test_rgb_off.py:138:
+ * np.mean over the 10 crops, weighted sum of the score sets; score_fusion.ipynb cell 8: six sets,
+ * weights 1.0/1.5/1.6 (RGB 7x7 / TSN / 14x14) and 1.2/0.8/1.7 (Flow), then argmax):
+ *   fused[v][c] = sum_i weights[i] * mean_k scores[i][v][k][c],   pred[v] = argmax_c fused[v][c]
+ * scores: n_sets device pointers to [videos, crops, classes] fp32 (host array of pointers);
+ * weights: n_sets host floats; pred may be NULL.  With crops = 1 this is the plain weighted sum
+ * used for the modality_fuse return (Flow_OFF.py:881). */
+int offk_score_fusion(void* stream, const float* const* scores, const float* weights, int n_sets, int videos,
+                      int crops, int classes, float* fused, int32_t* pred);
+
 /* NCHW <-> channels-last helpers (device pointers), used by tests and by callers that
  * want a reference-layout view of an internal buffer. */
 int offk_nchw_to_nhwc(void* stream, const float* src, int n_img, int C, int HW, float* dst);

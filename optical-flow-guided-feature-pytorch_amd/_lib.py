@@ -55,6 +55,7 @@ SIGNATURES = {
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),
     "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),
     "offk_segment_consensus": (_I, [_P, _F, _I, _I, _I, _F]),
+    "offk_score_fusion": (_I, [_P, _c.POINTER(_F), _c.POINTER(_c.c_float), _I, _I, _I, _I, _F, _F]),
     "offk_nchw_to_nhwc": (_I, [_P, _F, _I, _I, _I, _F]),
     "offk_nhwc_to_nchw": (_I, [_P, _F, _I, _I, _I, _I, _I, _F]),
 }

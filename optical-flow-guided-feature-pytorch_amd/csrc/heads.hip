@@ -123,6 +123,51 @@ hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hip
   return hipGetLastError();
 }
 
+// K7: fused[v][c] = sum_i w_i * mean_k s_i[v][k][c]; pred[v] = argmax_c (first maximum, like np.argmax)
+constexpr int SF_MAX_SETS = 8;
+struct ScoreFusionArgs { const float* s[SF_MAX_SETS]; float w[SF_MAX_SETS]; int n, crops, classes; float* fused; int* pred; };
+__global__ __launch_bounds__(256) void score_fusion_kernel(ScoreFusionArgs a) {
+  __shared__ float best_v[256];
+  __shared__ int best_i[256];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid; c < a.classes; c += 256) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SF_MAX_SETS; ++i)
+      if (i < a.n) {
+        const float* p = a.s[i] + ((size_t)v * a.crops) * a.classes + c;
+        float m = 0.f;
+        for (int k = 0; k < a.crops; ++k) m += p[(size_t)k * a.classes];
+        acc += a.w[i] * (m / (float)a.crops);
+      }
+    a.fused[(size_t)v * a.classes + c] = acc;
+    if (acc > bv) { bv = acc; bi = c; }
+  }
+  if (!a.pred) return;
+  best_v[tid] = bv; best_i[tid] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float ov = best_v[tid + s];
+      const int oi = best_i[tid + s];
+      if (ov > best_v[tid] || (ov == best_v[tid] && oi < best_i[tid])) { best_v[tid] = ov; best_i[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) a.pred[v] = best_i[0];
+}
+hipError_t score_fusion_launch(const float* const* scores, const float* weights, int n, int videos, int crops, int classes,
+                               float* fused, int* pred, hipStream_t st) {
+  if (n < 1 || n > SF_MAX_SETS) return hipErrorInvalidValue;
+  ScoreFusionArgs a;
+  for (int i = 0; i < SF_MAX_SETS; ++i) { a.s[i] = i < n ? scores[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+  a.n = n; a.crops = crops; a.classes = classes; a.fused = fused; a.pred = pred;
+  hipLaunchKernelGGL(score_fusion_kernel, dim3(videos), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 // [n][C][HW] -> [n*HW][C], tiled through LDS so both sides are coalesced
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int HW, float* __restrict__ dst) {
   __shared__ float t[32][33];

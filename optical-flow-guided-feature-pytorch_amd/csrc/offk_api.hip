@@ -722,6 +722,17 @@ int offk_segment_consensus(void* stream, const float* x, int B, int T, int C, fl
   return OFFK_OK;
 }
 
+int offk_score_fusion(void* stream, const float* const* scores, const float* weights, int n_sets, int videos, int crops,
+                      int classes, float* fused, int32_t* pred) {
+  if (!scores || !weights || !fused || n_sets < 1 || n_sets > 8 || videos < 1 || crops < 1 || classes < 1)
+    return fail(nullptr, OFFK_ERR_INVALID, "offk_score_fusion: bad argument (1..8 score sets)");
+  for (int i = 0; i < n_sets; ++i)
+    if (!scores[i]) return fail(nullptr, OFFK_ERR_INVALID, "offk_score_fusion: null score set");
+  hipError_t e = score_fusion_launch(scores, weights, n_sets, videos, crops, classes, fused, pred, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_score_fusion");
+  return OFFK_OK;
+}
+
 int offk_nchw_to_nhwc(void* stream, const float* src, int n_img, int C, int HW, float* dst) {
   if (!src || !dst || n_img < 1 || n_img > 65535 || C < 1 || HW < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_nchw_to_nhwc: bad argument");
   hipError_t e = nchw_to_nhwc_launch(src, n_img, C, HW, dst, static_cast<hipStream_t>(stream));

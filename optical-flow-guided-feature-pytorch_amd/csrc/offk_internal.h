@@ -75,6 +75,8 @@ hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st);
 // ---- K5 / K6 / layout helpers ----------------------------------------------------
 hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, const float* fw,
                        const float* fb, int ncls, float* out, hipStream_t st, const char** why);
+hipError_t score_fusion_launch(const float* const* scores, const float* weights, int n, int videos, int crops, int classes,
+                               float* fused, int* pred, hipStream_t st);
 hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hipStream_t st);
 hipError_t nchw_to_nhwc_launch(const float* src, int n_img, int C, int HW, float* dst, hipStream_t st);
 hipError_t nhwc_to_nchw_launch(const float* src, int cs, int coff, int n_img, int C, int HW, float* dst, hipStream_t st);

@@ -244,3 +244,20 @@ def nhwc_to_nchw(x, coff=0, c=None):
     out = torch.empty(n, C, H, W, dtype=torch.float32, device=x.device)
     _lib.check(lib.offk_nhwc_to_nchw(_stream(), _ptr(x), cs, coff, n, C, H * W, _ptr(out)))
     return out
+
+
+def score_fusion(score_sets, weights, want_pred=True):
+    """score_sets: list of [videos, crops, classes] (or [videos, classes]) fp32 CUDA tensors.
+    Returns (fused [videos, classes], pred [videos] int32 or None) -- K7, include/offk.h."""
+    lib = _lib.load()
+    sets = [s.contiguous() if s.dim() == 3 else s.contiguous().unsqueeze(1) for s in score_sets]
+    v, k, c = sets[0].shape
+    for s in sets:
+        if tuple(s.shape) != (v, k, c) or not s.is_cuda or s.dtype != torch.float32:
+            raise ValueError("score sets must be same-shape fp32 CUDA tensors")
+    fused = torch.empty(v, c, dtype=torch.float32, device=sets[0].device)
+    pred = torch.empty(v, dtype=torch.int32, device=sets[0].device) if want_pred else None
+    ptrs = (ctypes.c_void_p * len(sets))(*[s.data_ptr() for s in sets])
+    w = (ctypes.c_float * len(sets))(*[float(x) for x in weights])
+    _lib.check(lib.offk_score_fusion(_stream(), ptrs, w, len(sets), v, k, c, _ptr(fused), _ptr(pred)))
+    return fused, pred

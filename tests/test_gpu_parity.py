@@ -282,3 +282,21 @@ def test_full_size_b64_vs_oracle(rt, prec):
     # determinism: same inputs, same bits
     o7b, _, _ = h.forward([dev(f) for f in feats])
     assert torch.equal(out7, o7b)
+
+
+def test_two_stream_fused_forward(rt):
+    """BASELINE config 5 at small size: RGB-OFF + Flow-OFF on two streams, K7 late fusion."""
+    from offk_amd import scores, two_stream
+    B, L = 2, 3
+    wr, wf = synth.make_weights(spec.VARIANT_RGB), synth.make_weights(spec.VARIANT_FLOW, seed=0xF10)
+    fr, ff = synth.make_features(B, L, 11), synth.make_features(B, L, 12)
+    ts = two_stream.TwoStreamOFF(B, L, precision="fp32")
+    ts.load_state_dicts(wr, wf)
+    fused, pred = ts.forward([dev(f) for f in fr], [dev(f) for f in ff])
+    with torch.no_grad():
+        r = orc.off_forward([torch.from_numpy(f) for f in fr], orc.to_torch_weights(wr), B, L, spec.VARIANT_RGB, consensus=True)
+        f = orc.off_forward([torch.from_numpy(x) for x in ff], orc.to_torch_weights(wf), B, L, spec.VARIANT_FLOW, consensus=True)
+    w = scores.FUSION_BEST
+    ref = w[0] * r[0] + w[2] * r[1] + w[3] * f[0] + w[5] * f[1]
+    assert rel_err(fused, ref) < RTOL
+    assert torch.equal(pred.cpu().long(), ref.argmax(dim=1))
