@@ -169,10 +169,10 @@ int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int 
                    const float* res, int res_cstride, int res_coff, int flags,
                    float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial, size_t partial_floats,
                    int precision);
-/* bf16x3 operand format: n fp32 values (n % 4 == 0) -> n bf16 "hi" (upper 16 bits of each value)
- * followed by n bf16 "lo" (bf16_rne(x - hi)); dst holds 2*n bf16 = 4*n bytes.  With
- * precision = OFFK_PRECISION_BF16X3, offk_conv2d_ex expects `w` to point at the split form of the
- * packed weights. */
+/* bf16x3 weight format: n fp32 values (rows of K, K % 32 == 0, so n % 32 == 0) -> for every 32-wide
+ * K-tile 64 bf16: the 32 "hi" halves (upper 16 bits of each value) then the 32 "lo" halves
+ * (bf16_rne(x - hi)); same byte count as the fp32 input.  With precision = OFFK_PRECISION_BF16X3,
+ * offk_conv2d_ex expects `w` to point at this form of the packed weights. */
 int offk_split_bf16x3(void* stream, const float* src, size_t n, void* dst);
 /* [Co][Ci][KH][KW] (PyTorch) -> [Co][Ci/32][KH*KW][32]; both device pointers. */
 int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_packed);

@@ -18,6 +18,8 @@
 //   partial slabs that splitk_reduce_kernel sums in a fixed order (deterministic).
 //   M = pixels sits on the MFMA row axis, N = out-channels on the lane axis, so each
 //   accumulator register stores 32 consecutive channels of one pixel (128-B runs).
+#include <cstdlib>
+
 #include "offk_common.h"
 #include "offk_internal.h"
 
@@ -37,15 +39,22 @@ struct ConvArgs {
 };
 
 // PREC 0: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
+// Threads: fp32 = 256 (4 waves, every wave loads and multiplies).  bf16x3 = 512: waves 0-3 are
+// CONSUMERS (ds_read + MFMA only), waves 4-7 are PRODUCERS (global loads two K-tiles ahead, the
+// fp32 -> bf16 hi/lo split and the LDS stores).  Each SIMD then holds one wave of each kind, so the
+// split's VALU work and the LDS stores run beside the other wave's MFMAs instead of in front of
+// them (measured before the split: 39 % matrix-pipe busy with 20 % VALU and 26 % LDS time serialised
+// in the same waves).  One s_barrier per K-tile hands a filled LDS stage over.
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvArgs p) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;                         // fp32: [2][BM][LDS_K]
   float* Bs0 = smem + 2 * BM * LDS_K;        // fp32: [2][BN][LDS_K]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x & 255;          // index within the 4 loading waves (fp32: all; bf16x3: producers)
+  const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
   // XCD-aware bijective remap of the linear block id (blocks are dealt round-robin over the 8
   // XCDs): XCD x owns the contiguous logical range, ordered n-tile fastest, then m-tile, then split
   int lid;
@@ -60,19 +69,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   const int nkt_all = TAPS * (p.Ci / BK);
   const int kt_begin = (int)((long long)nkt_all * zs / p.splitk), kt_end = (int)((long long)nkt_all * (zs + 1) / p.splitk);
 
-  // Loader mapping.  fp32: thread = (row (tid>>3) + 32*r, 4 k at 4*(tid&7)), 16 B per row visit.
-  // bf16x3: thread = (row (tid>>2) + 64*r, 8 k at 8*(tid&3)): 32 B of fp32 activations that become
-  // one 16-B hi and one 16-B lo LDS store; weights arrive pre-split (hi plane, lo plane) and go
-  // to LDS untouched.
-  constexpr int RSH = PREC == 0 ? 3 : 2;            // row = tid >> RSH
-  constexpr int RSTEP = PREC == 0 ? 32 : 64;
+  // Loader mapping (both precisions): thread = (row (tid>>3) + 32*r, 16-B chunk tid&7), so every load
+  // instruction of a wave reads eight whole 128-B lines (the texture-address path works per line; an
+  // earlier 32-B-per-lane bf16x3 mapping touched every line with two instructions and was load-bound).
+  //   activations: 4 fp32 k-values per visit; bf16x3 splits them into 8 B of hi + 8 B of lo.
+  //   weights: fp32 [Co][K] (fp32 path) or, pre-split, [Co][K/32][hi 32 | lo 32] bf16 (bf16x3 path):
+  //            chunks 0-3 of a row's 128 B are the hi plane of the K-tile, chunks 4-7 the lo plane.
+  constexpr int RSH = 3, RSTEP = 32;
   constexpr int NRA = BM / RSTEP, NRB = BN / RSTEP;  // row visits per thread
-  constexpr int VA = PREC == 0 ? 1 : 2;              // float4 registers per A row visit
-  constexpr int VB = PREC == 0 ? 1 : 2;              // 16-B registers per B row visit (b3: hi, lo)
-  const int kpos = PREC == 0 ? 4 * (tid & 7) : 8 * (tid & 3);
+  constexpr int VA = 1, VB = 1;
+  const int kpos = 4 * (tid & 7);
 
   int hi0[NRA], wi0[NRA];
-  size_t pix0[NRA];
+  int pix0[NRA];      // image * H * W (fits: M and the feature maps are < 2^31 elements)
 #pragma unroll
   for (int r = 0; r < NRA; ++r) {
     int m = m0 + (tid >> RSH) + RSTEP * r;
@@ -83,17 +92,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     hi0[r] = ok ? ho * S - p.pad : -100000;  // pushes every tap out of bounds
     wi0[r] = wo * S - p.pad;
-    pix0[r] = (size_t)img * p.H * p.W;
+    pix0[r] = img * p.H * p.W;
   }
   const float* xbase = p.x + p.x_coff + kpos;
   const bool relu_in = p.flags & OFFK_CONV_RELU_IN_;
   // fp32: weight rows of this block's N slab, fp32 [Co][K].  bf16x3: bf16 hi plane [Co][K] then lo plane.
-  const float* wbase = p.w + (size_t)(n0 + (tid >> 3)) * K + 4 * (tid & 7);
-  const unsigned short* wb3 = reinterpret_cast<const unsigned short*>(p.w) + (size_t)(n0 + (tid >> 2)) * K + 8 * (tid & 3);
-  const size_t wlo_off = (size_t)p.Co * K;           // elements from the hi plane to the lo plane
+  const float* wbase = p.w + (size_t)(n0 + (tid >> 3)) * K + 4 * (tid & 7);   // same byte offsets in both formats
 
-  float4 rg[NRA * VA + NRB * VB];   // prefetch registers: A rows then B rows (one array: two arrays end up in scratch)
-  auto load_tile = [&](int kt) {
+  constexpr int NRG = NRA * VA + NRB * VB;
+  // prefetch registers: A rows then B rows (one array per set: separate A / B arrays end up in scratch).
+  // rg0 is the only set of the fp32 path; the bf16x3 producers alternate rg0 / rg1 (loads two tiles ahead).
+  float4 rg0[NRG], rg1[PREC == 0 ? 1 : NRG];
+  auto load_tile = [&](float4 (&rg)[NRG], int kt) {
     int chunk = kt / TAPS, tap = kt - chunk * TAPS, c0 = chunk * BK;
     int kh = tap / KW, kw = tap - kh * KW;
 #pragma unroll
@@ -103,22 +113,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int v = 0; v < VA; ++v) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) t = *reinterpret_cast<const float4*>(xbase + (pix0[r] + (size_t)(hi * p.W + wi)) * p.x_cs + c0 + 4 * v);
+        if (ok) t = *reinterpret_cast<const float4*>(xbase + (size_t)(pix0[r] + hi * p.W + wi) * p.x_cs + c0 + 4 * v);
         rg[r * VA + v] = relu_in ? relu4(t) : t;
       }
     }
-    if (PREC == 0) {
 #pragma unroll
-      for (int r = 0; r < NRB; ++r)
-        rg[NRA * VA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
-    } else {
-#pragma unroll
-      for (int r = 0; r < NRB; ++r) {
-        const unsigned short* q = wb3 + (size_t)64 * r * K + kt * BK;
-        rg[NRA * VA + 2 * r] = *reinterpret_cast<const float4*>(q);
-        rg[NRA * VA + 2 * r + 1] = *reinterpret_cast<const float4*>(q + wlo_off);
-      }
-    }
+    for (int r = 0; r < NRB; ++r)
+      rg[NRA * VA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
   };
   // bf16x3 LDS image per stage: A_hi [BM] | A_lo [BM] | B_hi [BN] | B_lo [BN], rows of 64 B (32 bf16), the
   // 16-B chunk c of row r stored at chunk c ^ ((r >> 2) & 3): conflict-free for the 16-B stores (8
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   constexpr int B3R = 64;
   constexpr int A_PLANE = BM * B3R, B_PLANE = BN * B3R, B3_STAGE = 2 * (A_PLANE + B_PLANE);
   char* smem_c = reinterpret_cast<char*>(smem);
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](const float4 (&rg)[NRG], int stage) {
     if (PREC == 0) {
       float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
@@ -139,22 +140,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[NRA + r];
     } else {
       char* st = smem_c + stage * B3_STAGE;
+      const int c8 = tid & 7;
 #pragma unroll
       for (int r = 0; r < NRA; ++r) {
-        const int row = (tid >> 2) + 64 * r;
-        uint2 h0, l0, h1, l1;
-        split4(rg[2 * r], h0, l0);
-        split4(rg[2 * r + 1], h1, l1);
-        char* q = st + row * B3R + (((tid & 3) ^ ((row >> 2) & 3)) << 4);
-        *reinterpret_cast<uint4*>(q) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        *reinterpret_cast<uint4*>(q + A_PLANE) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        const int row = (tid >> 3) + 32 * r;
+        uint2 h, l;
+        split4(rg[r], h, l);
+        char* q = st + row * B3R + ((((c8 >> 1) ^ ((row >> 2) & 3)) << 4) | ((c8 & 1) << 3));
+        *reinterpret_cast<uint2*>(q) = h;
+        *reinterpret_cast<uint2*>(q + A_PLANE) = l;
       }
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
-        const int row = (tid >> 2) + 64 * r;
-        char* q = st + 2 * A_PLANE + row * B3R + (((tid & 3) ^ ((row >> 2) & 3)) << 4);
-        *reinterpret_cast<float4*>(q) = rg[NRA * VA + 2 * r];
-        *reinterpret_cast<float4*>(q + B_PLANE) = rg[NRA * VA + 2 * r + 1];
+        const int row = (tid >> 3) + 32 * r;
+        char* q = st + 2 * A_PLANE + (c8 >> 2) * B_PLANE + row * B3R + (((c8 & 3) ^ ((row >> 2) & 3)) << 4);
+        *reinterpret_cast<float4*>(q) = rg[NRA * VA + r];
       }
     }
   };
@@ -190,19 +190,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
   WaveAcc<TM, TN> acc;
   acc.zero();
-  load_tile(kt_begin);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int st = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) load_tile(kt + 1);
-    if (PREC == 0)
+  if constexpr (PREC == 0) {
+    load_tile(rg0, kt_begin);
+    store_tile(rg0, 0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int st = (kt - kt_begin) & 1;
+      if (kt + 1 < kt_end) load_tile(rg0, kt + 1);
       acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
                     Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
-    else
-      mma_b3(acc.acc, st);
-    if (kt + 1 < kt_end) store_tile(st ^ 1);
+      if (kt + 1 < kt_end) store_tile(rg0, st ^ 1);
+      __syncthreads();
+    }
+  } else {
+    if (wave >= 4) {
+      // ---- producers: tile t is stored one step before it is consumed and loaded two steps before that
+      load_tile(rg0, kt_begin);
+      store_tile(rg0, 0);
+      if (kt_begin + 1 < kt_end) load_tile(rg0, kt_begin + 1);
+      if (kt_begin + 2 < kt_end) load_tile(rg1, kt_begin + 2);
+      __syncthreads();
+      int kt = kt_begin;
+      for (; kt + 1 < kt_end; kt += 2) {
+        store_tile(rg0, 1);                                    // tile kt+1 while tile kt is multiplied
+        if (kt + 3 < kt_end) load_tile(rg0, kt + 3);
+        __syncthreads();
+        if (kt + 2 < kt_end) store_tile(rg1, 0);      // tile kt+2 while tile kt+1 is multiplied
+        if (kt + 4 < kt_end) load_tile(rg1, kt + 4);
+        __syncthreads();
+      }
+      if (kt < kt_end) __syncthreads();
+      return;
+    }
+    // ---- consumers
     __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      mma_b3(acc.acc, (kt - kt_begin) & 1);
+      __syncthreads();
+    }
   }
 
   const int r32 = lane & 31, h = lane >> 5;
@@ -280,7 +305,7 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   }
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;
-  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(PREC == 0 ? 256 : 512), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.splitk == 1) return e;
   size_t n4 = (size_t)a.M * (a.Co / 4);
@@ -384,17 +409,19 @@ __global__ void pack_oihw_kernel(const float* __restrict__ src, float* __restric
   }
 }
 
-// fp32 [n] -> bf16 hi plane [n] followed by bf16 lo plane [n] (the bf16x3 weight format)
+// bf16x3 weight format: fp32 [rows][K] (K % 32 == 0) -> per row and 32-wide K-tile 64 bf16:
+// the 32 hi halves followed by the 32 lo halves (one 128-B line per (row, K-tile), same bytes as fp32)
 __global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
   for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
     uint2 h, l;
     split4(*reinterpret_cast<const float4*>(src + i), h, l);
-    *reinterpret_cast<uint2*>(dst + i) = h;
-    *reinterpret_cast<uint2*>(dst + n + i) = l;
+    const size_t tile = i >> 5, k = i & 31;            // K % 32 == 0, so tiles never straddle rows
+    *reinterpret_cast<uint2*>(dst + tile * 64 + k) = h;
+    *reinterpret_cast<uint2*>(dst + tile * 64 + 32 + k) = l;
   }
 }
 hipError_t split_bf16_launch(const float* src, size_t n, void* dst, hipStream_t st) {
-  if (n % 4) return hipErrorInvalidValue;
+  if (n % 32) return hipErrorInvalidValue;
   int blocks = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<unsigned short*>(dst), n);
   return hipGetLastError();

@@ -53,9 +53,9 @@ const int kTunedP384[kNumConvs][2] = {
     {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
-    {2, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1},   // fusion @28
-    {0, 3}, {3, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 1}, {0, 3}, {4, 1},                           // fusion @14
-    {0, 3}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+    {1, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
+    {0, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1},                           // fusion @14
+    {5, 3}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -692,7 +692,7 @@ int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int s
 }
 
 int offk_split_bf16x3(void* stream, const float* src, size_t n, void* dst) {
-  if (!src || !dst || n == 0 || n % 4) return fail(nullptr, OFFK_ERR_INVALID, "offk_split_bf16x3: need n % 4 == 0");
+  if (!src || !dst || n == 0 || n % 32) return fail(nullptr, OFFK_ERR_INVALID, "offk_split_bf16x3: need n % 32 == 0");
   hipError_t e = split_bf16_launch(src, n, dst, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail_hip(nullptr, e, "offk_split_bf16x3");
   return OFFK_OK;
