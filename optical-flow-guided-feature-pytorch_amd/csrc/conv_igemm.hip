@@ -35,6 +35,7 @@ struct ConvArgs {
   float* y; int y_cs, y_coff;
   int flags, M;
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
+  int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   float* partial;      // [splitk][M][Co] when splitk > 1
 };
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvA
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         int m = m0 + wm * 32 * TM + tm * 32 + acc_row(reg, h);
-        if (m < p.M) {
+        if (m < p.M && co < p.co_limit) {
           float v = acc.acc[tm][tn][reg] + bv;
           if (relu_pre) v = fmaxf(v, 0.f);
           if (p.res) v += p.res[(size_t)m * p.res_cs + p.res_coff + co];
@@ -359,7 +360,8 @@ void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_ou
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   *why = nullptr;
   if (d.precision != 0 && d.precision != 1) { *why = "conv2d: precision must be 0 (fp32) or 1 (bf16x3)"; return hipErrorInvalidValue; }
-  if (d.Ci % 32 || d.Co % 64 || d.x_cs % 4 || d.x_coff % 4 || d.y_cs % 4 || d.y_coff % 4 || d.y_cs <= 0 ||
+  const bool narrow = d.co_limit > 0 && d.co_limit < d.Co;   // padded-N GEMM with scalar stores (the FC heads)
+  if (d.Ci % 32 || d.Co % 64 || d.x_cs % 4 || d.x_coff % 4 || d.y_cs <= 0 || (!narrow && (d.y_cs % 4 || d.y_coff % 4)) ||
       (d.res && (d.res_cs % 4 || d.res_coff % 4))) {
     *why = "conv2d: need Ci % 32 == 0, Co % 64 == 0, 16-byte aligned channel slices";
     return hipErrorInvalidValue;
@@ -380,6 +382,8 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   int cfg = d.tile_cfg, sk = d.splitk;
   if (cfg < 0 || sk < 1) conv2d_auto_plan(M, d.Co, nkt, &cfg, &sk);
   if (sk > nkt) sk = nkt;
+  if (narrow) sk = 1;
+  a.co_limit = narrow ? d.co_limit : d.Co;
   if (sk > 1 && (!d.partial || d.partial_floats < (size_t)sk * (size_t)M * d.Co)) sk = 1;   // no slab space: unsplit
   a.splitk = sk; a.partial = d.partial; a.gm = a.gn = 0;
   const int key = d.KH * 100 + d.KW * 10 + d.stride;

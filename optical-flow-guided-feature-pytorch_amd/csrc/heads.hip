@@ -110,6 +110,93 @@ hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, i
   return hipGetLastError();
 }
 
+// Pooling half of a head as its own launch: grid (image, C / 256 channel slabs); the 256 threads of a
+// block are 64 channel quads x 4 pixel groups whose partial sums meet in LDS.  Writes pooled [n_img][C].
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, int cs, int coff, int H, int W, int C, int maxpool,
+                                                   float* __restrict__ pooled) {
+  __shared__ __attribute__((aligned(16))) float part[4][256];
+  const int img = blockIdx.x, c0 = blockIdx.y * 256, tid = threadIdx.x;
+  const int q = tid & 63, g = tid >> 6;            // channel quad within the slab, pixel group
+  const float* xi = x + (size_t)img * H * W * cs + coff + c0 + 4 * q;
+  const bool live = c0 + 4 * q < C;
+  const int Ho = maxpool ? (H - 3 + 1) / 2 + 1 : H, Wo = maxpool ? (W - 3 + 1) / 2 + 1 : W;
+  const int nwin = Ho * Wo;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    if (maxpool) {
+      for (int wdw = g; wdw < nwin; wdw += 4) {
+        const int oy = wdw / Wo, ox = wdw - oy * Wo;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int y = 2 * oy + dy, xx = 2 * ox + dx;
+            if (y < H && xx < W) m = max4(m, *reinterpret_cast<const float4*>(xi + (size_t)(y * W + xx) * cs));
+          }
+        s = add4(s, m);
+      }
+    } else {
+#pragma unroll 13
+      for (int px = g; px < nwin; px += 4) s = add4(s, *reinterpret_cast<const float4*>(xi + (size_t)px * cs));
+    }
+  }
+  *reinterpret_cast<float4*>(&part[g][4 * q]) = s;
+  __syncthreads();
+  const int c = c0 + tid;
+  if (c < C) pooled[(size_t)img * C + c] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * (1.f / (float)nwin);
+}
+hipError_t pool_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, float* pooled,
+                       hipStream_t st) {
+  if ((C & 3) || (x_cs & 3) || (x_coff & 3) || n_img <= 0 || (maxpool && (H < 3 || W < 3))) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_kernel, dim3(n_img, (C + 255) / 256), dim3(256), 0, st, x, x_cs, x_coff, H, W, C, maxpool, pooled);
+  return hipGetLastError();
+}
+
+// FC half of a head: grid (image, ceil(classes / 8)); every thread takes one channel quad for eight
+// classes, so all of a block's weight loads are in flight at once (the op is pure latency), then a
+// wavefront-shuffle + LDS reduction.
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ pooled, int C, const float* __restrict__ fw,
+                                                 const float* __restrict__ fb, int ncls, float* __restrict__ out) {
+  __shared__ float red[4][8];
+  const int img = blockIdx.x, o0 = blockIdx.y * 8, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c4 = tid * 4; c4 < C; c4 += 1024) {
+    const float4 pv = *reinterpret_cast<const float4*>(pooled + (size_t)img * C + c4);
+    float4 wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = *reinterpret_cast<const float4*>(fw + (size_t)min(o0 + j, ncls - 1) * C + c4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = fmaf(wv[j].x, pv.x, a[j]); a[j] = fmaf(wv[j].y, pv.y, a[j]);
+      a[j] = fmaf(wv[j].z, pv.z, a[j]); a[j] = fmaf(wv[j].w, pv.w, a[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a[j] += __shfl_down(a[j], off);
+    if (lane == 0) red[wave][j] = a[j];
+  }
+  __syncthreads();
+  if (tid < 8 && o0 + tid < ncls)
+    out[(size_t)img * ncls + o0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + fb[o0 + tid];
+}
+hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, const float* fb, int ncls, float* out, hipStream_t st) {
+  if ((C & 3) || n_img <= 0 || ncls <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fc_kernel, dim3(n_img, (ncls + 7) / 8), dim3(256), 0, st, pooled, C, fw, fb, ncls, out);
+  return hipGetLastError();
+}
+
+__global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+hipError_t vec_add_launch(const float* a, const float* b, float* o, int n, hipStream_t st) {
+  hipLaunchKernelGGL(vec_add_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, o, n);
+  return hipGetLastError();
+}
+
 __global__ void consensus_kernel(const float* __restrict__ x, int T, int C, float* __restrict__ out) {
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {

@@ -56,6 +56,9 @@ const int kTunedP384B3[kNumConvs][2] = {
     {1, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
     {0, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1},                           // fusion @14
     {5, 3}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+// (main 1x1, branch 1x1) pairs whose outputs are summed: RGB_OFF.py:663-666, :768-770, :839-841
+struct MergedSpec { const char* name; int main_id, branch_id; };
+const MergedSpec kMerged[3] = {{"merged_28a", C3_28A, CB_28A}, {"merged_14a", C3_14A, CE_14A}, {"merged_7", C3_7, CB_7}};
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -91,6 +94,13 @@ struct offk_handle {
   float* conv_b[kNumConvs] = {};
   float* fc_w[3] = {};
   float* fc_b[3] = {};
+  // residual-branch 1x1 convs merged into their sibling: out = W3*t + Wb*x == [W3|Wb] * [t|x] (K-concatenated)
+  float* merged_w[3] = {};
+  float* merged_wb3[3] = {};
+  float* merged_b[3] = {};
+  int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};
+  bool merged_dirty = true;
+
   int conv_cfg[kNumConvs];       // tile plan per fusion conv (-1 = automatic)
   int conv_splitk[kNumConvs];    // K-split per fusion conv (0 = automatic)
   size_t splitk_floats = 0;      // size of the "splitk" workspace region
@@ -160,28 +170,25 @@ void plan_workspace(offk_handle* h) {
   add_region(h, "fusion_14", P * 196 * 1056);
   add_region(h, "fusion_7", P * 49 * 832);
   // fusion@28 temporaries, 14x14 maps
-  add_region(h, "x0_28", P * 196 * 64);
+  add_region(h, "xt_28", P * 196 * 128);   // [t2 (c2 output) | x0 (pre-ReLU 7x7 output)]: input of the merged c3+branch conv
   add_region(h, "t1_28", P * 196 * 64);
-  add_region(h, "t2_28", P * 196 * 64);
-  add_region(h, "br_28", P * 196 * 256);
   add_region(h, "sa_28", P * 196 * 256);
   add_region(h, "sb_28", P * 196 * 256);
   // fusion@14 temporaries, 7x7 maps
-  add_region(h, "x1_14", P * 49 * 128);
+  add_region(h, "xu_14", P * 49 * 256);    // [u2 | x1]
   add_region(h, "u1_14", P * 49 * 128);
-  add_region(h, "u2_14", P * 49 * 128);
-  add_region(h, "ex_14", P * 49 * 512);
   add_region(h, "sa_14", P * 49 * 512);
   // fusion@7
-  add_region(h, "x2_7", P * 49 * 256);
+  add_region(h, "xv_7", P * 49 * 512);     // [v2 | x2]
   add_region(h, "v1_7", P * 49 * 256);
-  add_region(h, "v2_7", P * 49 * 256);
-  add_region(h, "br_7", P * 49 * 1024);
   add_region(h, "sum_7", P * 49 * 1024);
   // per-pair logits when consensus averages them afterwards
   add_region(h, "logit_7", P * (size_t)h->cfg.num_classes);
   add_region(h, "logit_14", P * (size_t)h->cfg.num_classes);
   add_region(h, "logit_28", P * (size_t)h->cfg.num_classes);
+  add_region(h, "pooled_7", P * 1024);
+  add_region(h, "pooled_14", P * 512);
+  add_region(h, "pooled_28", P * 256);
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64],
   // 3x3 @7: [P*49, 256]); a conv whose plan needs more falls back to fewer slices
   h->splitk_floats = 8 * P * 196 * 64;
@@ -287,20 +294,55 @@ int run_off_units(offk_handle* h, hipStream_t st, const float* const feats[], vo
 
 struct View { const float* p; int cs, coff; };
 
-int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, const float* res, int res_cs, int res_coff,
-         int flags, float* y, int y_cs, int y_coff) {
-  const ConvSpec& c = kConvs[id];
+int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, int K, int stride, int pad, const float* w,
+             const float* bias, int cfg, int sk, int n_img, int H, View x, const float* res, int res_cs, int res_coff,
+             int flags, float* y, int y_cs, int y_coff) {
   ConvDesc d;
-  d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.n_img = n_img; d.H = H; d.W = H; d.Ci = c.Ci;
-  d.w = h->cfg.precision == OFFK_PRECISION_BF16X3 ? h->conv_wb3[id] : h->conv_w[id]; d.bias = h->conv_b[id]; d.Co = c.Co; d.KH = c.K; d.KW = c.K; d.stride = c.stride; d.pad = c.pad;
+  d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.n_img = n_img; d.H = H; d.W = H; d.Ci = Ci;
+  d.w = w; d.bias = bias; d.Co = Co; d.KH = K; d.KW = K; d.stride = stride; d.pad = pad;
   d.res = res; d.res_cs = res_cs; d.res_coff = res_coff; d.flags = flags;
   d.y = y; d.y_cs = y_cs; d.y_coff = y_coff;
-  d.tile_cfg = h->conv_cfg[id]; d.splitk = h->conv_splitk[id];
+  d.tile_cfg = cfg; d.splitk = sk;
   d.partial = h->cur_splitk; d.partial_floats = h->splitk_floats;
   d.precision = h->cfg.precision;
   const char* why = nullptr;
   hipError_t e = conv2d_launch(d, st, &why);
-  if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + ": " + (why ? why : hipGetErrorString(e)));
+  if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
+  return OFFK_OK;
+}
+
+int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, const float* res, int res_cs, int res_coff,
+         int flags, float* y, int y_cs, int y_coff) {
+  const ConvSpec& c = kConvs[id];
+  const float* w = h->cfg.precision == OFFK_PRECISION_BF16X3 ? h->conv_wb3[id] : h->conv_w[id];
+  return conv_raw(h, st, c.key, c.Co, c.Ci, c.K, c.stride, c.pad, w, h->conv_b[id], h->conv_cfg[id], h->conv_splitk[id], n_img,
+                  H, x, res, res_cs, res_coff, flags, y, y_cs, y_coff);
+}
+
+// main 1x1 + branch 1x1 as ONE conv over the channel-concatenated input [t | x]
+int conv_merged(offk_handle* h, hipStream_t st, int m, int n_img, int H, View x, int flags, float* y, int y_cs, int y_coff) {
+  const ConvSpec& a = kConvs[kMerged[m].main_id];
+  const ConvSpec& b = kConvs[kMerged[m].branch_id];
+  const float* w = h->cfg.precision == OFFK_PRECISION_BF16X3 ? h->merged_wb3[m] : h->merged_w[m];
+  return conv_raw(h, st, kMerged[m].name, a.Co, a.Ci + b.Ci, 1, 1, 0, w, h->merged_b[m], h->merged_cfg[m], h->merged_sk[m], n_img,
+                  H, x, nullptr, 0, 0, flags, y, y_cs, y_coff);
+}
+
+// (re)build the merged weights after any conv weight changed: [Co][Ci_main | Ci_branch], bias = b_main + b_branch
+int finalize_merged(offk_handle* h, hipStream_t st) {
+  if (!h->merged_dirty) return OFFK_OK;
+  for (int m = 0; m < 3; ++m) {
+    const ConvSpec& a = kConvs[kMerged[m].main_id];
+    const ConvSpec& b = kConvs[kMerged[m].branch_id];
+    const size_t K = (size_t)a.Ci + b.Ci;
+    HIP_TRY(h, hipMemcpy2DAsync(h->merged_w[m], K * 4, h->conv_w[kMerged[m].main_id], (size_t)a.Ci * 4, (size_t)a.Ci * 4, a.Co,
+                                hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpy2DAsync(h->merged_w[m] + a.Ci, K * 4, h->conv_w[kMerged[m].branch_id], (size_t)b.Ci * 4, (size_t)b.Ci * 4,
+                                a.Co, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, vec_add_launch(h->conv_b[kMerged[m].main_id], h->conv_b[kMerged[m].branch_id], h->merged_b[m], a.Co, st));
+    if (h->merged_wb3[m]) HIP_TRY(h, split_bf16_launch(h->merged_w[m], (size_t)a.Co * K, h->merged_wb3[m], st));
+  }
+  h->merged_dirty = false;
   return OFFK_OK;
 }
 #define TRY(expr)            \
@@ -375,11 +417,20 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->conv_wb3[c], (size_t)cs.Co * cs.Ci * cs.K * cs.K);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->conv_b[c], cs.Co);
   }
+  for (int m = 0; m < 3 && rc == OFFK_OK; ++m) {
+    const ConvSpec& a = kConvs[kMerged[m].main_id];
+    const ConvSpec& b = kConvs[kMerged[m].branch_id];
+    const size_t n = (size_t)a.Co * (a.Ci + b.Ci);
+    rc = dev_alloc(h, &h->merged_w[m], n);
+    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->merged_wb3[m], n);
+    if (rc == OFFK_OK) rc = dev_alloc(h, &h->merged_b[m], a.Co);
+  }
   for (int k = 0; k < 3 && rc == OFFK_OK; ++k) {
     add_slot(h, std::string(kHeads[k].key) + ".weight", {cfg->num_classes, kHeads[k].C}, SK_FC_W, k);
     add_slot(h, std::string(kHeads[k].key) + ".bias", {cfg->num_classes}, SK_FC_B, k);
     rc = dev_alloc(h, &h->fc_w[k], (size_t)cfg->num_classes * kHeads[k].C);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->fc_b[k], cfg->num_classes);
+
   }
   if (rc != OFFK_OK) {
     g_err = h->err;
@@ -451,6 +502,7 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
     case SK_FC_B: rc = copy(h->fc_b[i]); break;
   }
   if (rc == OFFK_OK) s.set = true;
+  if (s.kind == SK_CONV_W || s.kind == SK_CONV_B) h->merged_dirty = true;
   return rc;
 }
 
@@ -585,43 +637,40 @@ int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM
   float* F7 = region(h, ws, "fusion_7");
   const int RI = OFFK_CONV_RELU_IN_, RP = OFFK_CONV_RELU_PRE_, RO = OFFK_CONV_RELU_POST_;
 
+  TRY(finalize_merged(h, st));
   // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
-  float *x0 = region(h, ws, "x0_28"), *t1 = region(h, ws, "t1_28"), *t2 = region(h, ws, "t2_28");
-  float *br = region(h, ws, "br_28"), *sa = region(h, ws, "sa_28"), *sb = region(h, ws, "sb_28");
-  TRY(conv(h, st, C_T28, P, 28, View{F28, 320, 0}, nullptr, 0, 0, 0, x0, 64, 0));              // :657 (pre-ReLU kept for the branch)
-  TRY(conv(h, st, C1_28A, P, 14, View{x0, 64, 0}, nullptr, 0, 0, RI | RP, t1, 64, 0));          // :658-660
-  TRY(conv(h, st, C2_28A, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, t2, 64, 0));               // :661-662
-  TRY(conv(h, st, CB_28A, P, 14, View{x0, 64, 0}, nullptr, 0, 0, 0, br, 256, 0));               // :665
-  TRY(conv(h, st, C3_28A, P, 14, View{t2, 64, 0}, br, 256, 0, RO, sa, 256, 0));                 // :663,666-667
+  // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
+  float *xt = region(h, ws, "xt_28"), *t1 = region(h, ws, "t1_28");
+  float *sa = region(h, ws, "sa_28"), *sb = region(h, ws, "sb_28");
+  TRY(conv(h, st, C_T28, P, 28, View{F28, 320, 0}, nullptr, 0, 0, 0, xt, 128, 64));             // :657 x0, pre-ReLU kept for the branch
+  TRY(conv(h, st, C1_28A, P, 14, View{xt, 128, 64}, nullptr, 0, 0, RI | RP, t1, 64, 0));        // :658-660
+  TRY(conv(h, st, C2_28A, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :661-662 t2
+  TRY(conv_merged(h, st, 0, P, 14, View{xt, 128, 0}, RO, sa, 256, 0));                           // :663-667
   TRY(conv(h, st, C1_28B, P, 14, View{sa, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));              // :670-671
-  TRY(conv(h, st, C2_28B, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, t2, 64, 0));               // :672-673
-  TRY(conv(h, st, C3_28B, P, 14, View{t2, 64, 0}, sa, 256, 0, RO, sb, 256, 0));                 // :674-676
+  TRY(conv(h, st, C2_28B, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :672-673
+  TRY(conv(h, st, C3_28B, P, 14, View{xt, 128, 0}, sa, 256, 0, RO, sb, 256, 0));                // :674-676
   TRY(conv(h, st, C1_28C, P, 14, View{sb, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));              // :679-680
-  TRY(conv(h, st, C2_28C, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, t2, 64, 0));               // :681-682
-  TRY(conv(h, st, C3_28C, P, 14, View{t2, 64, 0}, sb, 256, 0, RO, F14, 1056, 800));             // :683-685 -> cat at :760
+  TRY(conv(h, st, C2_28C, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :681-682
+  TRY(conv(h, st, C3_28C, P, 14, View{xt, 128, 0}, sb, 256, 0, RO, F14, 1056, 800));            // :683-685 -> cat at :760
   if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
 
   // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
-  float *x1 = region(h, ws, "x1_14"), *u1 = region(h, ws, "u1_14"), *u2 = region(h, ws, "u2_14");
-  float *ex = region(h, ws, "ex_14"), *s14 = region(h, ws, "sa_14");
-  TRY(conv(h, st, C_T14, P, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, x1, 128, 0));            // :762-763
-  TRY(conv(h, st, C1_14A, P, 7, View{x1, 128, 0}, nullptr, 0, 0, RP, u1, 128, 0));              // :764-765
-  TRY(conv(h, st, C2_14A, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, u2, 128, 0));              // :766-767
-  TRY(conv(h, st, CE_14A, P, 7, View{x1, 128, 0}, nullptr, 0, 0, 0, ex, 512, 0));               // :769
-  TRY(conv(h, st, C3_14A, P, 7, View{u2, 128, 0}, ex, 512, 0, RO, s14, 512, 0));                // :768,770-771
+  float *xu = region(h, ws, "xu_14"), *u1 = region(h, ws, "u1_14"), *s14 = region(h, ws, "sa_14");   // xu = [u2 | x1]
+  TRY(conv(h, st, C_T14, P, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128));          // :762-763 x1
+  TRY(conv(h, st, C1_14A, P, 7, View{xu, 256, 128}, nullptr, 0, 0, RP, u1, 128, 0));            // :764-765
+  TRY(conv(h, st, C2_14A, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));              // :766-767 u2
+  TRY(conv_merged(h, st, 1, P, 7, View{xu, 256, 0}, RO, s14, 512, 0));                           // :768-771
   TRY(conv(h, st, C1_14B, P, 7, View{s14, 512, 0}, nullptr, 0, 0, RP, u1, 128, 0));             // :773-774
-  TRY(conv(h, st, C2_14B, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, u2, 128, 0));              // :775-776
-  TRY(conv(h, st, C3_14B, P, 7, View{u2, 128, 0}, s14, 512, 0, RP | RO, F7, 832, 320));         // :777-780 -> cat at :832
+  TRY(conv(h, st, C2_14B, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));              // :775-776
+  TRY(conv(h, st, C3_14B, P, 7, View{xu, 256, 0}, s14, 512, 0, RP | RO, F7, 832, 320));         // :777-780 -> cat at :832
   if (ev) HIP_TRY(h, hipEventRecord(ev[4], st));
 
   // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
-  float *x2 = region(h, ws, "x2_7"), *v1 = region(h, ws, "v1_7"), *v2 = region(h, ws, "v2_7");
-  float *b7 = region(h, ws, "br_7"), *s7 = region(h, ws, "sum_7");
-  TRY(conv(h, st, C_T7, P, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, x2, 256, 0));                // :833-834
-  TRY(conv(h, st, C1_7, P, 7, View{x2, 256, 0}, nullptr, 0, 0, RP, v1, 256, 0));                // :835-836
-  TRY(conv(h, st, C2_7, P, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, v2, 256, 0));                // :837-838
-  TRY(conv(h, st, CB_7, P, 7, View{x2, 256, 0}, nullptr, 0, 0, 0, b7, 1024, 0));                // :840
-  TRY(conv(h, st, C3_7, P, 7, View{v2, 256, 0}, b7, 1024, 0, 0, s7, 1024, 0));                  // :839,841 (no ReLU)
+  float *xv = region(h, ws, "xv_7"), *v1 = region(h, ws, "v1_7"), *s7 = region(h, ws, "sum_7");   // xv = [v2 | x2]
+  TRY(conv(h, st, C_T7, P, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256));              // :833-834 x2
+  TRY(conv(h, st, C1_7, P, 7, View{xv, 512, 256}, nullptr, 0, 0, RP, v1, 256, 0));              // :835-836
+  TRY(conv(h, st, C2_7, P, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0));                // :837-838 v2
+  TRY(conv_merged(h, st, 2, P, 7, View{xv, 512, 0}, 0, s7, 1024, 0));                            // :839-841 (no ReLU)
   if (ev) HIP_TRY(h, hipEventRecord(ev[5], st));
 
   // ---- heads (+ consensus) ------------------------------------------------------------
@@ -629,16 +678,18 @@ int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM
   float* l7 = cons ? region(h, ws, "logit_7") : out7;
   float* l14 = cons ? region(h, ws, "logit_14") : out14;
   float* l28 = cons ? region(h, ws, "logit_28") : out28;
-  const char* why = nullptr;
-  hipError_t e;
-  e = head_launch(s7, 1024, 0, P, 7, 7, 1024, 0, h->fc_w[0], h->fc_b[0], ncls, l7, st, &why);   // :843-847
-  if (e != hipSuccess) return fail_hip(h, e, "head 7");
-  e = head_launch(F7, 832, 320, P, 7, 7, 512, 0, h->fc_w[2], h->fc_b[2], ncls, l14, st, &why);  // :789-793
-  if (e != hipSuccess) return fail_hip(h, e, "head 14");
-  if (out28) {
-    e = head_launch(F14, 1056, 800, P, 14, 14, 256, 1, h->fc_w[1], h->fc_b[1], ncls, l28, st, &why);  // :782-787
-    if (e != hipSuccess) return fail_hip(h, e, "head 28");
-  }
+  // each head = a pooling launch (1536 blocks at C = 1024) + a latency-oriented FC launch
+  auto run_head = [&](int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool, const char* pooled_name,
+                      float* logits) -> int {
+    float* pooled = region(h, ws, pooled_name);
+    hipError_t e = pool_launch(x, x_cs, x_coff, P, Hh, Hh, C, maxpool, pooled, st);
+    if (e == hipSuccess) e = fc_launch(pooled, P, C, h->fc_w[k], h->fc_b[k], ncls, logits, st);
+    if (e != hipSuccess) return fail_hip(h, e, "head");
+    return OFFK_OK;
+  };
+  TRY(run_head(0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7));                                      // :843-847
+  TRY(run_head(2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));                                    // :789-793
+  if (out28) TRY(run_head(1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28));                      // :782-787
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;
     HIP_TRY(h, consensus_launch(l7, B, T, ncls, out7, st));                                       // Flow_OFF.py:874
@@ -686,6 +737,12 @@ int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int s
     if (!strcmp(kConvs[c].key, conv_key)) {
       h->conv_cfg[c] = tile_cfg < 0 ? -1 : tile_cfg;
       h->conv_splitk[c] = splitk < 1 ? 0 : splitk;
+      return OFFK_OK;
+    }
+  for (int m = 0; m < 3; ++m)
+    if (!strcmp(kMerged[m].name, conv_key)) {
+      h->merged_cfg[m] = tile_cfg < 0 ? -1 : tile_cfg;
+      h->merged_sk[m] = splitk < 1 ? 0 : splitk;
       return OFFK_OK;
     }
   return fail(h, OFFK_ERR_UNKNOWN_KEY, std::string("offk_set_conv_plan: unknown conv ") + conv_key);

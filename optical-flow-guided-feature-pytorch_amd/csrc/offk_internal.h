@@ -24,6 +24,7 @@ struct ConvDesc {
   float* partial = nullptr;               // split-K slab scratch
   size_t partial_floats = 0;
   int precision = 0;                      // 0 = exact fp32 MFMA, 1 = bf16x3
+  int co_limit = 0;                       // > 0: store only output channels < co_limit (weights padded to Co); needs splitk == 1
 };
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
@@ -75,6 +76,10 @@ hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st);
 // ---- K5 / K6 / layout helpers ----------------------------------------------------
 hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, const float* fw,
                        const float* fb, int ncls, float* out, hipStream_t st, const char** why);
+hipError_t pool_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, float* pooled,
+                       hipStream_t st);
+hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, const float* fb, int ncls, float* out, hipStream_t st);
+hipError_t vec_add_launch(const float* a, const float* b, float* o, int n, hipStream_t st);
 hipError_t score_fusion_launch(const float* const* scores, const float* weights, int n, int videos, int crops, int classes,
                                float* fused, int* pred, hipStream_t st);
 hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hipStream_t st);
