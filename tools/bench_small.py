@@ -1,0 +1,30 @@
+"""Latency of the forward at small batch (BASELINE config 1: B = 1) and at the test-time shape
+(B = 10 crops x L = 25 segments, test_rgb_off.py:24-25).  GPU only."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import offk_amd  # noqa: E402,F401
+from offk_amd import runtime, spec, synth  # noqa: E402
+
+for B, L in ((1, 7), (4, 7), (10, 25)):
+    for prec in ("fp32", "bf16x3"):
+        h = runtime.OffForward(B, L, spec.VARIANT_RGB, precision=prec)
+        h.load_state_dict(synth.make_weights(spec.VARIANT_RGB))
+        feats = [torch.from_numpy(f).cuda() for f in synth.make_features(B, L, 1)]
+        arr = h._feat_array(feats)
+        out = [torch.empty(h.out_rows(), 101, device="cuda") for _ in range(3)]
+        for _ in range(5):
+            h.forward_into(arr, *out)
+        torch.cuda.synchronize()
+        n = 50
+        t0 = time.perf_counter()
+        for _ in range(n):
+            h.forward_into(arr, *out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print("B=%2d L=%2d %-7s %8.3f ms/forward  %9.1f clips/s" % (B, L, prec, dt * 1e3, B / dt), flush=True)
