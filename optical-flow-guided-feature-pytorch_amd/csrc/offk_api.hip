@@ -59,6 +59,15 @@ const int kTunedP384B3[kNumConvs][2] = {
 // (main 1x1, branch 1x1) pairs whose outputs are summed: RGB_OFF.py:663-666, :768-770, :839-841
 struct MergedSpec { const char* name; int main_id, branch_id; };
 const MergedSpec kMerged[3] = {{"merged_28a", C3_28A, CB_28A}, {"merged_14a", C3_14A, CE_14A}, {"merged_7", C3_7, CB_7}};
+// test-time shape of the reference eval scripts: 10 crops x 25 segments -> P = 240 (test_rgb_off.py:24-25)
+const int kTunedP240[kNumConvs][2] = {
+    {3, 8}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},
+    {4, 8}, {3, 1}, {3, 2}, {3, 1}, {3, 1}, {3, 1}, {3, 2}, {4, 2},
+    {0, 8}, {3, 1}, {3, 1}, {3, 1}, {3, 1}};
+const int kTunedP240B3[kNumConvs][2] = {
+    {3, 4}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {4, 1},
+    {0, 8}, {3, 1}, {3, 1}, {4, 1}, {4, 1}, {3, 1}, {3, 1}, {4, 1},
+    {5, 8}, {3, 1}, {4, 2}, {4, 1}, {4, 1}};
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -382,10 +391,10 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
   for (int c = 0; c < kNumConvs; ++c) {
-    const bool tuned = h->P == 384;
-    const int (*tab)[2] = cfg->precision == OFFK_PRECISION_BF16X3 ? kTunedP384B3 : kTunedP384;
-    h->conv_cfg[c] = tuned ? tab[c][0] : -1;
-    h->conv_splitk[c] = tuned ? tab[c][1] : 0;
+    const bool b3 = cfg->precision == OFFK_PRECISION_BF16X3;
+    const int (*tab)[2] = h->P == 384 ? (b3 ? kTunedP384B3 : kTunedP384) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
+    h->conv_cfg[c] = tab ? tab[c][0] : -1;
+    h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;
