@@ -112,6 +112,19 @@ size_t offk_workspace_bytes(const offk_handle* h);
 int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES],
                  float* out7, float* out14, float* out28, void* workspace);
 
+/* Same forward with every feature map handed over as its 1..4 channel groups in concat order --
+ * the inception block's branch outputs BEFORE the torch.cat that builds inception_*_output_out
+ * (RGB_OFF.py:395,418,435,458,481,504,527,567,590) -- so the backbone can skip that copy (31.6 MB
+ * written + re-read per clip).  Group p of site i is [B*L, channels[p], H_i, H_i] (layout per
+ * cfg.feat_layout), channels[p] % 32 == 0 (true for every BN-Inception branch), sum = C_i. */
+typedef struct offk_feat_parts {
+  int32_t n_parts;      /* 1..4 */
+  int32_t channels[4];
+  const float* data[4];
+} offk_feat_parts;
+int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts parts[OFFK_NUM_SITES],
+                       float* out7, float* out14, float* out28, void* workspace);
+
 /* Named regions of the workspace after offk_forward (for stage-level parity tests):
  * "G_<site>", "D_<site>", "fusion_28", "fusion_14", "fusion_7", "sum_7".  All channels-last. */
 int offk_workspace_region(const offk_handle* h, const char* name, size_t* offset_bytes, size_t* nbytes);

@@ -25,6 +25,10 @@ class OffkConfig(ctypes.Structure):
                 ("device", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
+class OffkFeatParts(ctypes.Structure):
+    _fields_ = [("n_parts", ctypes.c_int32), ("channels", ctypes.c_int32 * 4), ("data", ctypes.c_void_p * 4)]
+
+
 _c = ctypes
 _P = ctypes.c_void_p
 _F = ctypes.c_void_p       # float* passed as integer address (tensor.data_ptr())
@@ -40,6 +44,7 @@ SIGNATURES = {
     "offk_missing_weights": (_I, [_P, _c.c_char_p, _c.c_size_t]),
     "offk_workspace_bytes": (_c.c_size_t, [_P]),
     "offk_forward": (_I, [_P, _P, _c.POINTER(_F), _F, _F, _F, _P]),
+    "offk_forward_parts": (_I, [_P, _P, _c.POINTER(OffkFeatParts), _F, _F, _F, _P]),
     "offk_workspace_region": (_I, [_P, _c.c_char_p, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     "offk_set_profiling": (_I, [_P, _I]),
     "offk_stage_times": (_I, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _I]),

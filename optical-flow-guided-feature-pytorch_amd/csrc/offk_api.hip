@@ -242,8 +242,10 @@ int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
   return OFFK_OK;
 }
 
-void fill_pw_site(const offk_handle* h, int site, const float* feat, float* G, float* D, PwSite* o) {
-  o->x = feat; o->w = h->pw_w[site]; o->bias = h->pw_b[site]; o->G = G; o->D = D;
+void fill_pw_site(const offk_handle* h, int site, const offk_feat_parts& fp, float* G, float* D, PwSite* o) {
+  for (int q = 0; q < 4; ++q) { o->xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o->cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
+  o->nparts = fp.n_parts;
+  o->w = h->pw_w[site]; o->bias = h->pw_b[site]; o->G = G; o->D = D;
   o->C = kSites[site].C; o->HW = kSites[site].H * kSites[site].H; o->M = h->N * o->HW;
   o->blk_begin = 0;
 }
@@ -277,7 +279,29 @@ int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo) {
   return OFFK_OK;
 }
 
-int run_off_units(offk_handle* h, hipStream_t st, const float* const feats[], void* ws, hipEvent_t* ev) {
+offk_feat_parts whole_map(int site, const float* p) {
+  offk_feat_parts fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.n_parts = 1; fp.channels[0] = kSites[site].C; fp.data[0] = p;
+  return fp;
+}
+
+int check_parts(offk_handle* h, const offk_feat_parts parts[]) {
+  for (int s = 0; s < kNumSites; ++s) {
+    const offk_feat_parts& fp = parts[s];
+    if (fp.n_parts < 1 || fp.n_parts > 4) return fail(h, OFFK_ERR_INVALID, "feature map must come as 1..4 channel groups");
+    int sum = 0;
+    for (int q = 0; q < fp.n_parts; ++q) {
+      if (!fp.data[q]) return fail(h, OFFK_ERR_INVALID, "null feature map");
+      if (fp.channels[q] <= 0 || fp.channels[q] % 32) return fail(h, OFFK_ERR_INVALID, "channel groups must be multiples of 32 channels");
+      sum += fp.channels[q];
+    }
+    if (sum != kSites[s].C) return fail(h, OFFK_ERR_INVALID, std::string("channel groups of site ") + kSites[s].name + " do not add up to C");
+  }
+  return OFFK_OK;
+}
+
+int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[], void* ws, hipEvent_t* ev) {
   PwParams pp;
   memset(&pp, 0, sizeof(pp));
   pp.nsites = kNumSites; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
@@ -571,7 +595,7 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
   pp.nsites = 1; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
   pp.precision = h->cfg.precision;
-  fill_pw_site(h, site, feat, G, D, &pp.s[0]);
+  fill_pw_site(h, site, whole_map(site, feat), G, D, &pp.s[0]);
   pp.total_blocks = pw_blocks_for(pp.s[0].M);
   HIP_TRY(h, pw_reduce_launch(pp, static_cast<hipStream_t>(stream)));
   return OFFK_OK;
@@ -611,14 +635,26 @@ int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_N
     TRY(site_weights_ready(h, s, true, true));
   }
   DeviceGuard guard(h->cfg.device);
-  return run_off_units(h, static_cast<hipStream_t>(stream), feats, workspace, nullptr);
+  offk_feat_parts parts[kNumSites];
+  for (int s = 0; s < kNumSites; ++s) parts[s] = whole_map(s, feats[s]);
+  return run_off_units(h, static_cast<hipStream_t>(stream), parts, workspace, nullptr);
 }
 
 int offk_forward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], float* out7, float* out14,
                  float* out28, void* workspace) {
-  if (!h || !feats || !out7 || !out14 || !workspace) return fail(h, OFFK_ERR_INVALID, "offk_forward: null argument");
-  for (int s = 0; s < kNumSites; ++s)
+  if (!h || !feats) return fail(h, OFFK_ERR_INVALID, "offk_forward: null argument");
+  offk_feat_parts parts[kNumSites];
+  for (int s = 0; s < kNumSites; ++s) {
     if (!feats[s]) return fail(h, OFFK_ERR_INVALID, "offk_forward: null feature map");
+    parts[s] = whole_map(s, feats[s]);
+  }
+  return offk_forward_parts(h, stream, parts, out7, out14, out28, workspace);
+}
+
+int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats[OFFK_NUM_SITES], float* out7, float* out14,
+                       float* out28, void* workspace) {
+  if (!h || !feats || !out7 || !out14 || !workspace) return fail(h, OFFK_ERR_INVALID, "offk_forward: null argument");
+  TRY(check_parts(h, feats));
   TRY(check_ready(h));
   DeviceGuard guard(h->cfg.device);
   hipStream_t st = static_cast<hipStream_t>(stream);

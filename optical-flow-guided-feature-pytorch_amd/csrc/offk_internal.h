@@ -33,7 +33,11 @@ hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int
 
 // ---- K1 ------------------------------------------------------------------------
 struct PwSite {
-  const float* x;     // feature map, NCHW [N][C][HW] or NHWC [N*HW][C]
+  // feature map as 1..4 channel groups in concat order (the inception block's branches before
+  // torch.cat): part p is NCHW [N][cp[p]][HW] (or NHWC [N*HW][cp[p]]), sum cp = C, each cp % 32 == 0
+  const float* xp[4];
+  int cp[4];
+  int nparts;
   const float* w;     // stacked [160][C]: rows 0-127 motion_conv_gen, 128-159 motion_spatial_down
   const float* bias;  // [160]
   float* G;           // [N*HW][128]

@@ -88,14 +88,17 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   // the by-value kernarg array with a runtime index (or copying a whole entry) goes
   // through scratch memory
   PwSite S;
-  S.x = p.s[0].x; S.w = p.s[0].w; S.bias = p.s[0].bias; S.G = p.s[0].G; S.D = p.s[0].D;
-  S.C = p.s[0].C; S.HW = p.s[0].HW; S.M = p.s[0].M; S.blk_begin = p.s[0].blk_begin;
+#define OFFK_PW_PICK(i)                                                                              \
+  S.w = p.s[i].w; S.bias = p.s[i].bias; S.G = p.s[i].G; S.D = p.s[i].D;                              \
+  S.C = p.s[i].C; S.HW = p.s[i].HW; S.M = p.s[i].M; S.blk_begin = p.s[i].blk_begin;                  \
+  S.nparts = p.s[i].nparts;                                                                          \
+  S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];    \
+  S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
+  OFFK_PW_PICK(0)
 #pragma unroll
   for (int i = 1; i < kNumSites; ++i)
-    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) {
-      S.x = p.s[i].x; S.w = p.s[i].w; S.bias = p.s[i].bias; S.G = p.s[i].G; S.D = p.s[i].D;
-      S.C = p.s[i].C; S.HW = p.s[i].HW; S.M = p.s[i].M; S.blk_begin = p.s[i].blk_begin;
-    }
+    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PW_PICK(i) }
+#undef OFFK_PW_PICK
   const int C = S.C, HW = S.HW, M = S.M;
   const int m0 = ((int)blockIdx.x - S.blk_begin) * PW_BM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,47 +118,60 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   // mode 1: NCHW, any HW      : thread = (pixel i = tid&127, k quads (tid>>7) + 2r)
   // mode 2: channels-last     : thread = (rows (tid>>3)+32r, k quad tid&7)
   const int mode = p.nhwc ? 2 : ((HW & 3) == 0 ? 0 : 1);
-  const float* base;
-  bool row_ok;
+  int fr = 0, pix = 0;       // this thread's frame and pixel (modes 0 / 1)
+  bool row_ok = true;
   if (mode == 0) {
     int m = m0 + 4 * (tid & 31);
     row_ok = m < M;                       // M % 4 == 0 here, so the quad is all-in or all-out
     int mm = row_ok ? m : 0;
-    int n = mm / HW, pix = mm - n * HW;
-    base = S.x + ((size_t)n * C + 4 * (tid >> 5)) * HW + pix;
+    fr = mm / HW; pix = mm - fr * HW;
   } else if (mode == 1) {
     int m = m0 + (tid & 127);
     row_ok = m < M;
     int mm = row_ok ? m : 0;
-    int n = mm / HW, pix = mm - n * HW;
-    base = S.x + ((size_t)n * C + 4 * (tid >> 7)) * HW + pix;
-  } else {
-    base = S.x + (size_t)(m0 + (tid >> 3)) * C + 4 * (tid & 7);
-    row_ok = true;  // checked per row below
+    fr = mm / HW; pix = mm - fr * HW;
   }
+  const int koff = mode == 0 ? 4 * (tid >> 5) : (mode == 1 ? 4 * (tid >> 7) : 4 * (tid & 7));
+  // channel k0 (a multiple of 32) -> (part, channel within the part); parts are whole multiples of 32
+  // channels, so a K-tile never straddles two of them.  Uniform across the block: scalar selects.
+  auto locate = [&](int k0, const float*& xb, int& cpart, int& kl) {
+    xb = S.xp[0]; cpart = S.cp[0]; kl = k0;
+    if (S.nparts > 1 && kl >= S.cp[0]) {
+      kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
+      if (S.nparts > 2 && kl >= S.cp[1]) {
+        kl -= S.cp[1]; xb = S.xp[2]; cpart = S.cp[2];
+        if (S.nparts > 3 && kl >= S.cp[2]) { kl -= S.cp[2]; xb = S.xp[3]; cpart = S.cp[3]; }
+      }
+    }
+  };
 
   float4 rg[4 + PW_TN];   // prefetch registers: 4 x A, then 5 x B (one array: two arrays end up in scratch)
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   auto load_tile = [&](int k0) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xb; int cpart, kl;
+    locate(k0, xb, cpart, kl);
     if (mode == 0) {
+      const float* base = xb + ((size_t)fr * cpart + kl + koff) * HW + pix;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         rg[j] = z;
-        if (row_ok) rg[j] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + j) * HW);
+        if (row_ok) rg[j] = *reinterpret_cast<const float4*>(base + (size_t)j * HW);
       }
     } else if (mode == 1) {
+      const float* base = xb + ((size_t)fr * cpart + kl + koff) * HW + pix;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* q = base + (size_t)(k0 + 8 * r) * HW;
+        const float* q = base + (size_t)(8 * r) * HW;
         rg[r] = z;
         if (row_ok) rg[r] = make_float4(q[0], q[HW], q[2 * (size_t)HW], q[3 * (size_t)HW]);
       }
     } else {
+      const float* base = xb + (size_t)(m0 + (tid >> 3)) * cpart + kl + koff;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         rg[r] = z;
-        if (m0 + (tid >> 3) + 32 * r < M) rg[r] = *reinterpret_cast<const float4*>(base + (size_t)32 * r * C + k0);
+        if (m0 + (tid >> 3) + 32 * r < M) rg[r] = *reinterpret_cast<const float4*>(base + (size_t)32 * r * cpart);
       }
     }
 #pragma unroll

@@ -128,7 +128,35 @@ class OffForward:
                 raise ValueError("feats[%d] has shape %s, expected %s" % (i, tuple(f.shape), tuple(want)))
         return (ctypes.c_void_p * spec.NUM_SITES)(*[f.data_ptr() for f in feats])
 
+    def _parts_array(self, feats):
+        """feats[i] is a tensor or a sequence of 1..4 tensors (channel groups in concat order)."""
+        shapes = spec.feature_shapes(self.batch, self.length)
+        arr = (_lib.OffkFeatParts * spec.NUM_SITES)()
+        for i, (f, s) in enumerate(zip(feats, shapes)):
+            parts = [f] if torch.is_tensor(f) else list(f)
+            if not 1 <= len(parts) <= 4:
+                raise ValueError("feats[%d]: 1..4 channel groups" % i)
+            arr[i].n_parts = len(parts)
+            for q, t in enumerate(parts):
+                _check_dev(t, "feats[%d][%d]" % (i, q), self.device)
+                c = t.shape[1] if self.feat_layout == 0 else t.shape[3]
+                want = (s[0], c, s[2], s[3]) if self.feat_layout == 0 else (s[0], s[2], s[3], c)
+                if tuple(t.shape) != want:
+                    raise ValueError("feats[%d][%d] has shape %s, expected %s" % (i, q, tuple(t.shape), want))
+                arr[i].channels[q] = c
+                arr[i].data[q] = t.data_ptr()
+        return arr
+
     def forward(self, feats, want28=True):
+        if any(not torch.is_tensor(f) for f in feats):
+            arr = self._parts_array(feats)
+            rows = self.out_rows()
+            out7 = torch.empty(rows, self.num_classes, dtype=torch.float32, device=self.device)
+            out14 = torch.empty_like(out7)
+            out28 = torch.empty_like(out7) if want28 else None
+            _lib.check(self.lib.offk_forward_parts(self._h, _stream(), arr, _ptr(out7), _ptr(out14), _ptr(out28),
+                                                   _ptr(self.workspace)), self._h)
+            return out7, out14, out28
         arr = self._feat_array(feats)
         rows = self.out_rows()
         out7 = torch.empty(rows, self.num_classes, dtype=torch.float32, device=self.device)

@@ -18,6 +18,10 @@ SITES = (("3a", 256, 28), ("3b", 320, 28), ("3c", 576, 14),
          ("4a", 576, 14), ("4b", 576, 14), ("4c", 608, 14), ("4d", 608, 14),
          ("5a", 1024, 7), ("5b", 1024, 7))
 SITE_NAMES = tuple(s[0] for s in SITES)
+# branch widths of each inception block in torch.cat order (RGB_OFF.py:395..590 and the layer
+# declarations :43-263): what offk_forward_parts accepts instead of the concatenated map
+SITE_PARTS = ((64, 64, 96, 32), (64, 96, 96, 64), (160, 96, 320), (224, 96, 128, 128), (192, 128, 128, 128),
+              (160, 160, 160, 128), (96, 192, 192, 128), (352, 320, 224, 128), (352, 320, 224, 128))
 GEN_CH = 128      # motion_conv_gen_* output channels   (RGB_OFF.py:266)
 DOWN_CH = 32      # motion_spatial_down_* output channels (RGB_OFF.py:267)
 UNIT_CH = GEN_CH + DOWN_CH   # one OFF unit = [spatial 32 | temporal 128] (RGB_OFF.py:616)

@@ -300,3 +300,29 @@ def test_two_stream_fused_forward(rt):
     ref = w[0] * r[0] + w[2] * r[1] + w[3] * f[0] + w[5] * f[1]
     assert rel_err(fused, ref) < RTOL
     assert torch.equal(pred.cpu().long(), ref.argmax(dim=1))
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_forward_from_inception_branch_parts(rt, prec):
+    """offk_forward_parts: the maps handed over as the inception branches (before torch.cat) give
+    bit-identical results to the concatenated maps."""
+    B, L = 2, 3
+    feats = synth.make_features(B, L, 13)
+    h, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    ref = h.forward([dev(f) for f in feats])
+    parts = []
+    for f, widths in zip(feats, spec.SITE_PARTS):
+        assert sum(widths) == f.shape[1]
+        off, grp = 0, []
+        for wd in widths:
+            grp.append(dev(np.ascontiguousarray(f[:, off:off + wd])))
+            off += wd
+        parts.append(grp)
+    got = h.forward(parts)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    from offk_amd import _lib
+    bad = list(parts)
+    bad[0] = [dev(np.ascontiguousarray(feats[0][:, :48])), dev(np.ascontiguousarray(feats[0][:, 48:]))]
+    with pytest.raises(_lib.OffkError, match="multiples of 32"):
+        h.forward(bad)
