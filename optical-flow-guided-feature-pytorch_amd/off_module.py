@@ -96,12 +96,14 @@ class OFFSubNetwork(nn.Module):
     # -- forward ----------------------------------------------------------------------
     def forward(self, feats, want28=True):
         """feats: the nine ``inception_{3a..5b}_output_out`` maps [B*L, C, H, H] fp32 on a HIP
-        device.  Returns (fc_action_motion_7, fc_action_motion_14, fc_action_motion_28):
+        device -- each either the concatenated tensor or the list of its inception branches in
+        torch.cat order (then the concat never has to exist, offk_forward_parts).  Returns (fc_action_motion_7, fc_action_motion_14, fc_action_motion_28):
         [B*(L-1), classes] each, or [B, classes] with the consensus average."""
-        feats = [f.contiguous() for f in feats]
-        if not feats[0].is_cuda:
+        feats = [f.contiguous() if torch.is_tensor(f) else [g.contiguous() for g in f] for f in feats]
+        first = feats[0] if torch.is_tensor(feats[0]) else feats[0][0]
+        if not first.is_cuda:
             raise runtime._lib.OffkError("OFFSubNetwork has no CPU path: feature maps must live on an MI355X")
-        rt = self._handle(feats[0].device)
+        rt = self._handle(first.device)
         with torch.no_grad():
             return rt.forward(feats, want28=want28)
 
