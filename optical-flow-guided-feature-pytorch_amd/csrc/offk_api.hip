@@ -3,6 +3,7 @@
 #include "../../include/offk.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -94,6 +95,9 @@ struct offk_handle {
   std::map<std::string, int> index;
   // packed device weights
   float* pw_w[kNumSites] = {};   // [160][C]
+  float* pw_wb3[kNumSites] = {}; // bf16x3 mode: the same matrix pre-split per K-tile (hi 32 | lo 32)
+  bool pw_dirty = true;
+  bool pw_presplit = true;
   float* pw_b[kNumSites] = {};   // [160]
   float* dw_w[kNumSites] = {};   // [9][32]
   float* dw_b[kNumSites] = {};   // [32] or null
@@ -245,7 +249,7 @@ int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
 void fill_pw_site(const offk_handle* h, int site, const offk_feat_parts& fp, float* G, float* D, PwSite* o) {
   for (int q = 0; q < 4; ++q) { o->xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o->cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
   o->nparts = fp.n_parts;
-  o->w = h->pw_w[site]; o->bias = h->pw_b[site]; o->G = G; o->D = D;
+  o->w = (h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit) ? h->pw_wb3[site] : h->pw_w[site]; o->bias = h->pw_b[site]; o->G = G; o->D = D;
   o->C = kSites[site].C; o->HW = kSites[site].H * kSites[site].H; o->M = h->N * o->HW;
   o->blk_begin = 0;
 }
@@ -301,12 +305,23 @@ int check_parts(offk_handle* h, const offk_feat_parts parts[]) {
   return OFFK_OK;
 }
 
+int finalize_pw(offk_handle* h, hipStream_t st) {
+  if (!h->pw_dirty) return OFFK_OK;
+  if (h->cfg.precision == OFFK_PRECISION_BF16X3)
+    for (int s = 0; s < kNumSites; ++s)
+      HIP_TRY(h, split_bf16_launch(h->pw_w[s], (size_t)kUnitCh * kSites[s].C, h->pw_wb3[s], st));
+  h->pw_dirty = false;
+  return OFFK_OK;
+}
+
 int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[], void* ws, hipEvent_t* ev) {
+  { int rc = finalize_pw(h, st); if (rc != OFFK_OK) return rc; }
   PwParams pp;
   memset(&pp, 0, sizeof(pp));
   pp.nsites = kNumSites; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
   pp.precision = h->cfg.precision;
+  pp.presplit = h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit;
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
     int s = kPwOrder[i];
@@ -414,6 +429,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->cfg = *cfg;
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
+  { const char* e = getenv("OFFK_PW_PRESPLIT"); if (e && *e == '0') h->pw_presplit = false; }
   for (int c = 0; c < kNumConvs; ++c) {
     const bool b3 = cfg->precision == OFFK_PRECISION_BF16X3;
     const int (*tab)[2] = h->P == 384 ? (b3 ? kTunedP384B3 : kTunedP384) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
@@ -430,6 +446,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     add_slot(h, "motion_spatial_down_" + n + ".weight", {kDownCh, C, 1, 1}, SK_DOWN_W, s);
     add_slot(h, "motion_spatial_down_" + n + ".bias", {kDownCh}, SK_DOWN_B, s);
     rc = dev_alloc(h, &h->pw_w[s], (size_t)kUnitCh * C);
+    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wb3[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
     if (cfg->variant == OFFK_VARIANT_RGB_LEARNED_DW && rc == OFFK_OK) {
       add_slot(h, "motion_spatial_grad_" + n + ".weight", {kDownCh, 1, 3, 3}, SK_DW_W, s);
@@ -536,6 +553,7 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
   }
   if (rc == OFFK_OK) s.set = true;
   if (s.kind == SK_CONV_W || s.kind == SK_CONV_B) h->merged_dirty = true;
+  if (s.kind == SK_GEN_W || s.kind == SK_DOWN_W) h->pw_dirty = true;
   return rc;
 }
 
@@ -595,6 +613,8 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
   pp.nsites = 1; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
   pp.precision = h->cfg.precision;
+  pp.presplit = h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit;
+  TRY(finalize_pw(h, static_cast<hipStream_t>(stream)));
   fill_pw_site(h, site, whole_map(site, feat), G, D, &pp.s[0]);
   pp.total_blocks = pw_blocks_for(pp.s[0].M);
   HIP_TRY(h, pw_reduce_launch(pp, static_cast<hipStream_t>(stream)));

@@ -38,7 +38,8 @@ struct PwSite {
   const float* xp[4];
   int cp[4];
   int nparts;
-  const float* w;     // stacked [160][C]: rows 0-127 motion_conv_gen, 128-159 motion_spatial_down
+  const float* w;     // stacked [160][C]: rows 0-127 motion_conv_gen, 128-159 motion_spatial_down (fp32), or the
+                      // same matrix pre-split for bf16x3: [160][C/32][hi 32 | lo 32] bf16
   const float* bias;  // [160]
   float* G;           // [N*HW][128]
   float* D;           // [P*HW][32]
@@ -50,6 +51,7 @@ struct PwParams {
   int nsites, total_blocks;
   int L, P, slice_mode, nhwc;
   int precision;       // 0 = exact fp32 MFMA, 1 = bf16x3
+  int presplit;        // bf16x3: w is already in the split format
 };
 int pw_blocks_for(int M);
 hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st);

@@ -193,8 +193,15 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b3_store(Ahi, A_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[r]);
       }
+      if (p.presplit) {
+        // weights arrive pre-split: chunks 0-3 of a row's 128-B K-tile line are the hi plane, 4-7 the lo plane
 #pragma unroll
-      for (int r = 0; r < PW_TN; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[4 + r]);
+        for (int r = 0; r < PW_TN; ++r)
+          *reinterpret_cast<float4*>(Bhi + ((tid & 7) >> 2) * B_PLANE + ((tid >> 3) + 32 * r) * B3_ROW + ((tid & 3) << 4)) = rg[4 + r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < PW_TN; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[4 + r]);
+      }
       return;
     }
     if (mode == 0) {
