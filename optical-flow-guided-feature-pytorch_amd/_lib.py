@@ -73,6 +73,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # Load PyTorch's HIP runtime first: liboffk.so then binds to the libamdhip64 already in the
+    # process.  Loaded the other way round the process ends up with two HIP runtimes (the system
+    # one and the one bundled with torch) and the second to initialise sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise OffkError("liboffk.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(or optical-flow-guided-feature-pytorch_amd/build.py); there is no fallback path")
