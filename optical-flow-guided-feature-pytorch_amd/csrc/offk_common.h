@@ -69,9 +69,10 @@ struct WaveAcc {
 // fp32 accumulation (the a_lo*b_lo term, <= 2^-16 relative, is dropped).  Per-operand
 // representation error <= 2^-17, so results agree with the exact-fp32 core to ~1e-5
 // relative -- two orders inside the 1e-3 parity budget -- at 3/16 of its MFMA cycles.
-// LDS image: four planes per stage (A_hi, A_lo, B_hi, B_lo), each [row][32 k] bf16 with an
-// 80-byte row stride: a lane's 8 consecutive k (16 B) are one ds_read_b128 and 16
-// consecutive rows hit 16 distinct 16-B slots of the 256-B bank row (80*i mod 256).
+// LDS image: four planes per stage (A_hi, A_lo, B_hi, B_lo), each [row][32 k] bf16; a lane's 8
+// consecutive k (16 B) are one ds_read_b128.  K1 (pw_reduce.hip) pads rows to 80 bytes (16
+// consecutive rows hit 16 distinct 16-B slots of the 256-B bank row, 80*i mod 256); K4
+// (conv_igemm.hip) uses unpadded 64-B rows with an XOR swizzle of the 16-B chunk index.
 // ---------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -96,34 +97,6 @@ __device__ __forceinline__ void b3_store(char* hi_plane, int plane_bytes, int ro
   char* p = hi_plane + row * B3_ROW + kq * 8;
   *reinterpret_cast<uint2*>(p) = h;
   *reinterpret_cast<uint2*>(p + plane_bytes) = l;
-}
-
-template <int TM, int TN>
-__device__ __forceinline__ void b3_mma_ktile(f32x16 (&acc)[TM][TN], const char* Ahi, int a_plane, const char* Bhi, int b_plane, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int s = 0; s < BK / 16; ++s) {
-    const int off = r * B3_ROW + (16 * s + 8 * h) * 2;
-    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      ah[t] = *reinterpret_cast<const bf16x8*>(Ahi + t * 32 * B3_ROW + off);
-      al[t] = *reinterpret_cast<const bf16x8*>(Ahi + a_plane + t * 32 * B3_ROW + off);
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      bh[t] = *reinterpret_cast<const bf16x8*>(Bhi + t * 32 * B3_ROW + off);
-      bl[t] = *reinterpret_cast<const bf16x8*>(Bhi + b_plane + t * 32 * B3_ROW + off);
-    }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-      }
-  }
 }
 
 // row (M index) of accumulator register `reg` for a lane in half `h` (lane>>5)
