@@ -260,7 +260,7 @@ void fill_st_site(const offk_handle* h, int site, const float* G, const float* D
   o->M = M; o->H = kSites[site].H; o->m_cs = m_cs; o->m_coff = m_coff;
   st_plan(o->H, &o->strips, &o->rows);
   o->tchunks = st_tchunks(o->H);
-  o->s_begin = 0; o->t_begin = 0;
+  o->s_begin = 0; o->t_begin = 0; o->tgroup = 1;
 }
 
 int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo) {
@@ -268,15 +268,26 @@ int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo) {
   memset(&sp, 0, sizeof(sp));
   sp.nsites = kNumSites; sp.B = h->cfg.batch; sp.L = h->cfg.length;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
+  const char* tg = getenv("OFFK_K2_TGROUP");
+  const bool tgrouped = tg ? (*tg != '0') : false;  // tuning knob: T-blocks walk all sites of a fusion buffer (measured slower: profiles/r01/k2_ab.txt)
   int sblk = 0, tblk = 0;
   for (int s = 0; s < kNumSites; ++s) {
     fill_st_site(h, s, region(h, ws, (std::string("G_") + kSites[s].name).c_str()),
                  region(h, ws, (std::string("D_") + kSites[s].name).c_str()), region(h, ws, fus[kSiteFusion[s]]),
                  kFusionC[kSiteFusion[s]], kSiteCoff[s], &sp.s[s]);
     sp.s[s].s_begin = sblk;
-    sp.s[s].t_begin = tblk;
     sblk += h->P * sp.s[s].strips;
-    tblk += h->cfg.batch * sp.s[s].tchunks;
+    const bool group_head = s == 0 || kSiteFusion[s] != kSiteFusion[s - 1];
+    if (!tgrouped || group_head) {
+      int n = 1;
+      if (tgrouped) while (s + n < kNumSites && kSiteFusion[s + n] == kSiteFusion[s]) ++n;
+      sp.s[s].t_begin = tblk;
+      sp.s[s].tgroup = n;
+      tblk += h->cfg.batch * sp.s[s].tchunks;
+    } else {
+      sp.s[s].t_begin = 0x7fffffff;   // covered by its group head's T-blocks
+      sp.s[s].tgroup = 0;
+    }
   }
   sp.total_s = sblk; sp.total_t = tblk;
   HIP_TRY(h, sobel_tdiff_launch(sp, algo, st));

@@ -68,6 +68,7 @@ struct StSite {
   int tchunks;        // T-blocks per clip
   int s_begin;        // first S-block (spatial role) of this site within the S index space
   int t_begin;        // first T-block (temporal role) of this site within the T index space
+  int tgroup;         // sites (this one and the next tgroup-1 table entries) one T-block walks: they share M
 };
 struct StParams {
   StSite s[kNumSites];

@@ -97,13 +97,15 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
   StSite S;
   S.G = p.s[0].G; S.D = p.s[0].D; S.dw = p.s[0].dw; S.db = p.s[0].db; S.M = p.s[0].M; S.H = p.s[0].H;
   S.m_cs = p.s[0].m_cs; S.m_coff = p.s[0].m_coff; S.strips = p.s[0].strips; S.rows = p.s[0].rows;
-  S.s_begin = p.s[0].s_begin; S.t_begin = p.s[0].t_begin; S.tchunks = p.s[0].tchunks;
+  S.s_begin = p.s[0].s_begin; S.t_begin = p.s[0].t_begin; S.tchunks = p.s[0].tchunks; S.tgroup = p.s[0].tgroup;
+  int si = 0;
 #pragma unroll
   for (int i = 1; i < kNumSites; ++i)
     if (i < p.nsites && ridx >= (is_t ? p.s[i].t_begin : p.s[i].s_begin)) {
       S.G = p.s[i].G; S.D = p.s[i].D; S.dw = p.s[i].dw; S.db = p.s[i].db; S.M = p.s[i].M; S.H = p.s[i].H;
       S.m_cs = p.s[i].m_cs; S.m_coff = p.s[i].m_coff; S.strips = p.s[i].strips; S.rows = p.s[i].rows;
-      S.s_begin = p.s[i].s_begin; S.t_begin = p.s[i].t_begin; S.tchunks = p.s[i].tchunks;
+      S.s_begin = p.s[i].s_begin; S.t_begin = p.s[i].t_begin; S.tchunks = p.s[i].tchunks; S.tgroup = p.s[i].tgroup;
+      si = i;
     }
   const int H = S.H, W = S.H, HW = H * H;
   const int L = p.L, T = L - 1;
@@ -118,20 +120,29 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
     const size_t f0 = (size_t)b * L, p0 = (size_t)b * T;
     const size_t gstride = (size_t)HW * kGenCh, mstride = (size_t)HW * S.m_cs;
     if (ALGO != 1) {
-      for (int task = tid; task < npix * 32; task += ST_THREADS) {
-        const int q = q0 + (task >> 5), c4 = (task & 31) * 4;
-        const float* g = S.G + (f0 * HW + q) * kGenCh + c4;
-        float* m = S.M + (p0 * HW + q) * S.m_cs + S.m_coff + kDownCh + c4;
-        float4 prev = ldg4<NTL>(g);
-        for (int t0 = 1; t0 < L; t0 += ST_TGROUP) {
-          float4 v[ST_TGROUP];
+      // one T-block walks every site that lands in the same fusion buffer (tgroup > 1): the 512-B pieces
+      // the sites contribute to one pixel row of M are then written by the same block within microseconds
+      for (int gi = 0; gi < S.tgroup; ++gi) {
+        const float* Gs = p.s[0].G;
+        int coff = p.s[0].m_coff;
 #pragma unroll
-          for (int j = 0; j < ST_TGROUP; ++j)
-            if (t0 + j < L) v[j] = ldg4<NTL>(g + (size_t)(t0 + j) * gstride);
+        for (int j = 1; j < kNumSites; ++j)
+          if (si + gi == j) { Gs = p.s[j].G; coff = p.s[j].m_coff; }
+        for (int task = tid; task < npix * 32; task += ST_THREADS) {
+          const int q = q0 + (task >> 5), c4 = (task & 31) * 4;
+          const float* g = Gs + (f0 * HW + q) * kGenCh + c4;
+          float* m = S.M + (p0 * HW + q) * S.m_cs + coff + kDownCh + c4;
+          float4 prev = ldg4<NTL>(g);
+          for (int t0 = 1; t0 < L; t0 += ST_TGROUP) {
+            float4 v[ST_TGROUP];
 #pragma unroll
-          for (int j = 0; j < ST_TGROUP; ++j)
-            if (t0 + j < L) stg4<NTS>(m + (size_t)(t0 + j - 1) * mstride, sub4(v[j], j ? v[j - 1] : prev));
-          prev = v[ST_TGROUP - 1];
+            for (int j = 0; j < ST_TGROUP; ++j)
+              if (t0 + j < L) v[j] = ldg4<NTL>(g + (size_t)(t0 + j) * gstride);
+#pragma unroll
+            for (int j = 0; j < ST_TGROUP; ++j)
+              if (t0 + j < L) stg4<NTS>(m + (size_t)(t0 + j - 1) * mstride, sub4(v[j], j ? v[j - 1] : prev));
+            prev = v[ST_TGROUP - 1];
+          }
         }
       }
     } else {
