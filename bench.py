@@ -128,14 +128,20 @@ def main():
     arr = h._feat_array(feats)
     rows = h.out_rows()
     out = [torch.empty(rows, spec.NUM_CLASSES, device=dev) for _ in range(3)]
-    gathered = torch.empty(world, 3, rows, spec.NUM_CLASSES, device=dev) if world > 1 else None   # [rank][head][clip][class]
-    local = torch.empty(3, rows, spec.NUM_CLASSES, device=dev) if world > 1 else None
+    # two buffer sets, alternated per step: the collective of step i (RCCL stream) may still be reading
+    # its input while the forward of step i+1 is enqueued on the compute stream
+    gathered = [torch.empty(world, 3, rows, spec.NUM_CLASSES, device=dev) for _ in range(2)] if world > 1 else None
+    local = [torch.empty(3, rows, spec.NUM_CLASSES, device=dev) for _ in range(2)] if world > 1 else None
+    counter = [0]
 
     def step():
         if world > 1:
-            h.forward_into(arr, local[0], local[1], local[2])
-            # config 4: the only exchange on the path -- per-clip consensus scores, one collective
-            dist.all_gather_into_tensor(gathered.view(world * 3 * rows, -1), local.view(3 * rows, -1))
+            i = counter[0] & 1
+            counter[0] += 1
+            h.forward_into(arr, local[i][0], local[i][1], local[i][2])
+            # config 4: the only exchange on the path -- per-clip consensus scores [rank][head][clip][class],
+            # one collective (same call offk_amd.dist.gather_scores makes; tests/test_dist_gloo.py)
+            dist.all_gather_into_tensor(gathered[i].view(world * 3 * rows, -1), local[i].view(3 * rows, -1))
         else:
             h.forward_into(arr, out[0], out[1], out[2])
 

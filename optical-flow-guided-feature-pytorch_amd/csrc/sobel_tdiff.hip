@@ -46,8 +46,10 @@ static int knob(const char* name, int dflt) {
 int st_tpix() { return knob("OFFK_K2_TPIX", 64); }   // pixels per T-block (0 = per-site: 112 / 98 / 49)
 
 void st_plan(int H, int* strips, int* rows) {
-  *rows = H >= 28 ? knob("OFFK_K2_ROWS28", 7) : 7;   // 28x28 planes: four 7-row strips; 14x14 and 7x7: 2 / 1 strips
-  if (*rows < 1 || *rows > 7) *rows = 7;
+  // 28x28 planes: four 7-row strips; 14x14 and 7x7 planes: one whole-plane S-block per pair (OFFK_K2_ROWS14=7
+  // restores two 7-row strips for 14x14)
+  *rows = H >= 28 ? knob("OFFK_K2_ROWS28", 7) : (H > 7 ? knob("OFFK_K2_ROWS14", 14) : 7);
+  if (*rows < 1 || (H >= 28 && *rows > 7) || *rows > 14) *rows = 7;
   *strips = (H + *rows - 1) / *rows;
 }
 int st_tpix_for(int H) { int t = st_tpix(); return t > 0 ? t : (H >= 28 ? 112 : H >= 14 ? 98 : 49); }
