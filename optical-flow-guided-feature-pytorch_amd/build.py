@@ -18,6 +18,11 @@ SOURCES = ("offk_api.hip", "pw_reduce.hip", "sobel_tdiff.hip", "conv_igemm.hip",
 HEADERS = ("offk_common.h", "offk_internal.h", os.path.join("..", "..", "include", "offk.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
+# heads.hip: no SLP vectoriser.  It pairs the FC accumulators of neighbouring classes into v_pk_fma_f32 with
+# op_sel operand swizzles, and on MI355X those produced wrong low-half results whenever the kernel shared
+# CUs with another stream's MFMA kernel (measured); scalar FMAs are exact and the
+# kernels in that file are latency-bound anyway.
+EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -47,7 +52,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc, "-c", s, "-o", o] + FLAGS
+        cmd = [hipcc, "-c", s, "-o", o] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))

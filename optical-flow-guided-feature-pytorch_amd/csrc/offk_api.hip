@@ -113,6 +113,10 @@ struct offk_handle {
   float* merged_b[3] = {};
   int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};
   bool merged_dirty = true;
+  // the 28- and 14-heads only depend on sum_28c / sum_14b: they run on a side stream beside the later
+  // fusion stages and are joined back into the caller's stream before offk_forward returns
+  hipStream_t side = nullptr;   // stays null with OFFK_SIDE_STREAM=0 in the environment at offk_create: heads on the caller's stream
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
 
   int conv_cfg[kNumConvs];       // tile plan per fusion conv (-1 = automatic)
   int conv_splitk[kNumConvs];    // K-split per fusion conv (0 = automatic)
@@ -499,6 +503,16 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     return rc;
   }
   plan_workspace(h);
+  const char* side_env = getenv("OFFK_SIDE_STREAM");
+  if (!(side_env && *side_env == '0') &&
+      (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+       hipEventCreateWithFlags(&h->ev_fork[0], hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&h->ev_fork[1], hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
+    g_err = "offk_create: could not create the side stream";
+    offk_destroy(h);
+    return OFFK_ERR_HIP;
+  }
   *out = h;
   return OFFK_OK;
 }
@@ -507,6 +521,10 @@ int offk_destroy(offk_handle* h) {
   if (!h) return OFFK_OK;
   DeviceGuard guard(h->cfg.device);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+  if (h->ev_fork[0]) (void)hipEventDestroy(h->ev_fork[0]);
+  if (h->ev_fork[1]) (void)hipEventDestroy(h->ev_fork[1]);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return OFFK_OK;
@@ -714,6 +732,21 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   const int RI = OFFK_CONV_RELU_IN_, RP = OFFK_CONV_RELU_PRE_, RO = OFFK_CONV_RELU_POST_;
 
   TRY(finalize_merged(h, st));
+  const bool forked = h->side != nullptr;
+  hipStream_t side = forked ? h->side : st;
+  const bool cons = h->cfg.consensus == OFFK_CONSENSUS_AVG;
+  float* l7 = cons ? region(h, ws, "logit_7") : out7;
+  float* l14 = cons ? region(h, ws, "logit_14") : out14;
+  float* l28 = cons ? region(h, ws, "logit_28") : out28;
+  // each head = a pooling launch (1536 blocks at C = 1024) + a latency-oriented FC launch
+  auto run_head = [&](hipStream_t hs, int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool,
+                      const char* pooled_name, float* logits) -> int {
+    float* pooled = region(h, ws, pooled_name);
+    hipError_t e = pool_launch(x, x_cs, x_coff, P, Hh, Hh, C, maxpool, pooled, hs);
+    if (e == hipSuccess) e = fc_launch(pooled, P, C, h->fc_w[k], h->fc_b[k], ncls, logits, hs);
+    if (e != hipSuccess) return fail_hip(h, e, "head");
+    return OFFK_OK;
+  };
   // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
   // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
   float *xt = region(h, ws, "xt_28"), *t1 = region(h, ws, "t1_28");
@@ -729,6 +762,13 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   TRY(conv(h, st, C2_28C, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :681-682
   TRY(conv(h, st, C3_28C, P, 14, View{xt, 128, 0}, sb, 256, 0, RO, F14, 1056, 800));            // :683-685 -> cat at :760
   if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
+  if (out28) {   // 28-head (:782-787) beside fusion@14: only reads sum_28c
+    if (forked) {
+      HIP_TRY(h, hipEventRecord(h->ev_fork[0], st));
+      HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[0], 0));
+    }
+    TRY(run_head(side, 1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28));
+  }
 
   // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
   float *xu = region(h, ws, "xu_14"), *u1 = region(h, ws, "u1_14"), *s14 = region(h, ws, "sa_14");   // xu = [u2 | x1]
@@ -740,6 +780,13 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   TRY(conv(h, st, C2_14B, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));              // :775-776
   TRY(conv(h, st, C3_14B, P, 7, View{xu, 256, 0}, s14, 512, 0, RP | RO, F7, 832, 320));         // :777-780 -> cat at :832
   if (ev) HIP_TRY(h, hipEventRecord(ev[4], st));
+  {              // 14-head (:789-793) beside fusion@7: only reads sum_14b
+    if (forked) {
+      HIP_TRY(h, hipEventRecord(h->ev_fork[1], st));
+      HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[1], 0));
+    }
+    TRY(run_head(side, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));
+  }
 
   // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
   float *xv = region(h, ws, "xv_7"), *v1 = region(h, ws, "v1_7"), *s7 = region(h, ws, "sum_7");   // xv = [v2 | x2]
@@ -749,23 +796,12 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   TRY(conv_merged(h, st, 2, P, 7, View{xv, 512, 0}, 0, s7, 1024, 0));                            // :839-841 (no ReLU)
   if (ev) HIP_TRY(h, hipEventRecord(ev[5], st));
 
-  // ---- heads (+ consensus) ------------------------------------------------------------
-  const bool cons = h->cfg.consensus == OFFK_CONSENSUS_AVG;
-  float* l7 = cons ? region(h, ws, "logit_7") : out7;
-  float* l14 = cons ? region(h, ws, "logit_14") : out14;
-  float* l28 = cons ? region(h, ws, "logit_28") : out28;
-  // each head = a pooling launch (1536 blocks at C = 1024) + a latency-oriented FC launch
-  auto run_head = [&](int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool, const char* pooled_name,
-                      float* logits) -> int {
-    float* pooled = region(h, ws, pooled_name);
-    hipError_t e = pool_launch(x, x_cs, x_coff, P, Hh, Hh, C, maxpool, pooled, st);
-    if (e == hipSuccess) e = fc_launch(pooled, P, C, h->fc_w[k], h->fc_b[k], ncls, logits, st);
-    if (e != hipSuccess) return fail_hip(h, e, "head");
-    return OFFK_OK;
-  };
-  TRY(run_head(0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7));                                      // :843-847
-  TRY(run_head(2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));                                    // :789-793
-  if (out28) TRY(run_head(1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28));                      // :782-787
+  // ---- 7-head on the caller's stream, join the side-stream heads, consensus -----------------
+  TRY(run_head(st, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7));                                  // :843-847
+  if (forked) {
+    HIP_TRY(h, hipEventRecord(h->ev_join, side));
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+  }
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;
     HIP_TRY(h, consensus_launch(l7, B, T, ncls, out7, st));                                       // Flow_OFF.py:874
