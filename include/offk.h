@@ -16,7 +16,10 @@
  *  - the caller owns every data buffer (device pointers, e.g. torch tensor.data_ptr());
  *    the library owns the handle and its packed weight copies only.
  *  - all work is enqueued asynchronously on the hipStream_t passed as `void* stream`
- *    (NULL = default stream); there is no implicit synchronisation.
+ *    (NULL = default stream); there is no implicit synchronisation.  offk_forward forks its two
+ *    side heads onto a stream the handle owns (event fork / event join, both inside the call):
+ *    seen from the caller everything is ordered on `stream`, and the call can be stream-captured.
+ *    OFFK_SIDE_STREAM=0 in the environment at offk_create disables the fork.
  *  - a handle is not thread-safe; distinct handles are independent.
  *  - fp32 everywhere.  Boundary tensors are NCHW contiguous exactly as the reference
  *    backbone produces them; INTERNAL activations (workspace, stage entry points) are
