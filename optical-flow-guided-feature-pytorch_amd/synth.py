@@ -90,3 +90,33 @@ def make_weights(variant, seed=0xBEEF):
         n = int(np.prod(shape))
         out[key] = uniform_values(seed + li, n, bound).reshape(shape)
     return out
+
+
+# ---- reproducible dropout mask of the OFF units' spatial branch (training) ----------
+DROP_FIELD_BITS = 16
+
+
+def dropout_threshold(p):
+    """16-bit keep threshold: an element is kept iff its 16-bit field >= threshold."""
+    return int(round(float(p) * (1 << DROP_FIELD_BITS)))
+
+
+def dropout_stream(seed, site_index):
+    return ((int(seed) & 0xFFFFFFFFFFFF) << 8) | int(site_index)
+
+
+def dropout_keep(seed, site_index, pairs, H, p):
+    """Keep-mask [P,32,H,H] (bool, NCHW like ``motion_spatial_grad_*`` output, RGB_OFF.py:611-612).
+
+    One 64-bit draw serves the four channels of a (pixel, channel quad): draw index
+    ((pair*H*H + pixel)*8 + quad), channel c of the quad uses bits [16c, 16c+16).  The HIP
+    kernels (sobel_tdiff.hip / units_bwd.hip) evaluate the same integer function.
+    """
+    hw = H * H
+    n = pairs * hw * (spec.DOWN_CH // 4)
+    x = raw_u64(dropout_stream(seed, site_index), 0, n).reshape(pairs, hw, spec.DOWN_CH // 4)
+    thr = np.uint64(dropout_threshold(p))
+    keep = np.empty((pairs, hw, spec.DOWN_CH // 4, 4), dtype=bool)
+    for c in range(4):
+        keep[..., c] = ((x >> np.uint64(16 * c)) & np.uint64(0xFFFF)) >= thr
+    return np.ascontiguousarray(keep.reshape(pairs, H, H, spec.DOWN_CH).transpose(0, 3, 1, 2))

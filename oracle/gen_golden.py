@@ -129,6 +129,106 @@ def run_case(tag, variant, B, L, config_id):
     print(tag, "fc7", out["fc7"].shape, "->", os.path.getsize(path), "bytes")
 
 
+GRAD_CASES = (  # (tag, variant, B, L, config_id, drop_seed or None)
+    ("grad_rgb_b2_l3", spec.VARIANT_RGB, 2, 3, 2, None),
+    ("grad_rgb_b2_l3_drop", spec.VARIANT_RGB, 2, 3, 2, 7),
+    ("grad_rgb_b3_l4_drop", spec.VARIANT_RGB, 3, 4, 3, 11),
+    ("grad_flow_b2_l3", spec.VARIANT_FLOW, 2, 3, 2, None),
+)
+DROP_P = 0.8   # RGB_OFF.py:356
+
+
+def cotangents(P):
+    return [torch.from_numpy(synth.uniform_values(0xC07 + i, P * spec.NUM_CLASSES, 1.0).reshape(P, spec.NUM_CLASSES))
+            for i in range(3)]
+
+
+def run_grad_case(tag, variant, B, L, config_id, drop_seed):
+    """Training-side goldens: gradients of sum_k <fc_k, R_k> w.r.t. every
+    OFF-unit parameter and w.r.t. the fusion buffers, from the reference's own graph + torch
+    autograd (what train_off.py:126-146 runs).  With ``drop_seed`` the reference's single
+    ``self.dropout`` module (RGB_OFF.py:356) is replaced by one that applies the repo's reproducible
+    keep-mask to the nine spatial-gradient calls (:612 ...) and is the identity for the pooled
+    head vectors (:785, :791, :845), so the mask placement is the reference's."""
+    import basic_ops
+    if variant == spec.VARIANT_RGB:
+        import RGB_OFF as ref
+    else:
+        import Flow_OFF as ref
+    torch.manual_seed(0)
+    model = ref.bninception_off(spec.NUM_CLASSES, B, L).eval()
+    weights = synth.make_weights(variant)
+    sd = model.state_dict()
+    for k, v in weights.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    feats = [torch.from_numpy(f) for f in synth.make_features(B, L, config_id)]
+    P = B * (L - 1)
+    cap, gcap = {}, {}
+    for (site, _c, _h), f in zip(spec.SITES, feats):
+        getattr(model, "motion_conv_gen_" + site).register_forward_pre_hook(lambda m, inp, f=f: (f,))
+        getattr(model, "motion_spatial_down_" + site).register_forward_pre_hook(lambda m, inp, f=f: (f[:P],))
+    for key, name in (("motion_conv_trans_28", "fusion_28"), ("motion_conv_trans_14", "fusion_14"),
+                      ("motion_conv_trans", "fusion_7")):
+        def pre(m, inp, name=name):
+            inp[0].register_hook(lambda g, name=name: gcap.__setitem__(name, g.detach().clone()))
+        getattr(model, key).register_forward_pre_hook(pre)
+    for key, name in (("fc_action_motion", "fc7"), ("fc_action_motion_14", "fc14"), ("fc_action_motion_28", "fc28")):
+        getattr(model, key).register_forward_hook(lambda m, inp, out, name=name: cap.__setitem__(name, out))
+    if drop_seed is not None:
+        class MaskDropout(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.calls = 0
+            def forward(self, x):
+                if x.dim() == 4 and x.shape[1] == spec.DOWN_CH and x.shape[2] > 1:
+                    si = self.calls
+                    self.calls += 1
+                    keep = synth.dropout_keep(drop_seed, si, P, spec.SITES[si][2], DROP_P)
+                    return x * (torch.from_numpy(keep).float() / (1.0 - DROP_P))
+                return x
+        model.dropout = MaskDropout()
+    if variant == spec.VARIANT_FLOW:
+        class ConsensusShim(torch.nn.Module):
+            def forward(self, x):
+                return basic_ops.SegmentConsensus("avg", 1).forward(x)
+        model.consensus = ConsensusShim()
+    if variant == spec.VARIANT_RGB:
+        model.RGB_OFF_forward(torch.zeros(B * L, 3, 224, 224))
+    else:
+        model(torch.zeros(B * L, 10, 224, 224))
+    if drop_seed is not None:
+        assert model.dropout.calls == spec.NUM_SITES
+    cot = cotangents(P)
+    loss = (cap["fc7"] * cot[0]).sum() + (cap["fc14"] * cot[1]).sum() + (cap["fc28"] * cot[2]).sum()
+    loss.backward()
+    out = dict(meta=np.array([variant, B, L, config_id, -1 if drop_seed is None else drop_seed], dtype=np.int64))
+    for k, prm in model.named_parameters():
+        if k.startswith(("motion_conv_gen_", "motion_spatial_down_", "motion_spatial_grad_")):
+            g = prm.grad
+            out["cs_" + k], out["sm_" + k] = checksum(g)
+            if g.numel() <= 512 or k == "motion_spatial_down_3c.weight":
+                out["full_" + k] = g.numpy().copy()
+    for name, width in (("fusion_28", 320), ("fusion_14", 800), ("fusion_7", 320)):
+        out["cs_d" + name], out["sm_d" + name] = checksum(gcap[name][:, :width].contiguous())
+    path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+    np.savez_compressed(path, **out)
+    print(tag, "->", os.path.getsize(path), "bytes")
+
+
+def run_consensus_backward():
+    """basic_ops.py:29-36 called directly (the legacy Function object cannot be applied through autograd)."""
+    import basic_ops
+    B, T, C = 3, 6, spec.NUM_CLASSES
+    x = torch.from_numpy(synth.uniform_values(0xC0F, B * T * C, 1.0).reshape(B, T, C))
+    go = torch.from_numpy(synth.uniform_values(0xC10, B * C, 1.0).reshape(B, 1, C))
+    sc = basic_ops.SegmentConsensus("avg", 1)
+    y = sc.forward(x)
+    gi = sc.backward(go)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "consensus_bwd.npz"), y=y.numpy(), grad_in=gi.contiguous().numpy(),
+                        meta=np.array([B, T, C], dtype=np.int64))
+
+
 def dump_state_dict_keys():
     """The weight-interchange contract: every key/shape of the reference state_dicts
     (data only -- names and shapes), so tests can pin the wrapper's key set offline."""
@@ -147,6 +247,12 @@ def dump_state_dict_keys():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for case in CASES:
-        run_case(*case)
-    dump_state_dict_keys()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "forward"):
+        for case in CASES:
+            run_case(*case)
+        dump_state_dict_keys()
+    if which in ("all", "grad"):
+        for case in GRAD_CASES:
+            run_grad_case(*case)
+        run_consensus_backward()

@@ -49,11 +49,13 @@ def spatial_frames(x, batch, length, slice_mode):
     return x.reshape(batch, length, c, h, wd)[:, :length - 1].reshape(p, c, h, wd)
 
 
-def off_unit(x, w, site, batch, length, variant, slice_mode):
+def off_unit(x, w, site, batch, length, variant, slice_mode, drop=None):
     """One OFF unit -> motion_<site> [P,160,H,H] = cat(spatial 32, temporal 128).
 
     RGB_OFF.py:596-616 (site 3a; the other eight sites are identical up to names);
     Flow_OFF.py:606-627 for the diagonal-Sobel variant (util.py:52-77).
+    ``drop``: training mode -- the multiplier nn.Dropout(p) (:356, applied at :612) would use,
+    keep_mask / (1 - p), as a [P,32,H,H] tensor; None = eval (identity).
     """
     g = torch.relu(_conv(x, w, "motion_conv_gen_" + site))                 # :597-598
     t = temporal_diff(g, batch)                                            # :599-604
@@ -62,7 +64,8 @@ def off_unit(x, w, site, batch, length, variant, slice_mode):
         s = _conv(d, w, "motion_spatial_grad_" + site, pad=1, groups=32)   # :611
     else:
         s = F.conv2d(d, w["sobel_edge_diagonal.conv.weight"], None, padding=1, groups=32)  # Flow_OFF.py:622
-    # dropout p=0.8 is the identity in eval mode (:612)
+    if drop is not None:
+        s = s * drop                                                       # :612 (train); identity in eval
     return torch.cat((s, t), dim=1)                                        # :616
 
 
@@ -124,7 +127,7 @@ def segment_consensus(x, batch):
 
 
 def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_FLAT,
-                consensus=None, return_stages=False):
+                consensus=None, return_stages=False, unit_drop=None):
     """The whole OFF sub-network on nine injected feature maps.
 
     feats: list of nine [N,C,H,H] fp32 tensors (inception_{3a..5b}_output_out).
@@ -136,8 +139,9 @@ def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_F
     if consensus is None:
         consensus = (variant == VARIANT_FLOW)
     m = {}
-    for (site, _c, _h), x in zip(SITES, feats):
-        m[site] = off_unit(x, w, site, batch, length, variant, slice_mode)
+    for si, ((site, _c, _h), x) in enumerate(zip(SITES, feats)):
+        m[site] = off_unit(x, w, site, batch, length, variant, slice_mode,
+                           None if unit_drop is None else unit_drop[si])
     f28 = torch.cat((m["3a"], m["3b"]), dim=1)                                      # :656
     sum_28c = fusion_28(f28, w)
     f14 = torch.cat((m["3c"], m["4a"], m["4b"], m["4c"], m["4d"], sum_28c), dim=1)  # :760
@@ -155,6 +159,56 @@ def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_F
                   fusion_7=f7, sum_7=s7)
         return (fc7, fc14, fc28), st
     return fc7, fc14, fc28
+
+
+UNIT_PARAM_PREFIXES = ("motion_conv_gen_", "motion_spatial_down_", "motion_spatial_grad_")
+
+
+def unit_backward(feats, w, batch, length, variant, slice_mode, cotangents, unit_drop=None):
+    """Gradients of loss = sum_k <out_k, cotangent_k> (k = fc7, fc14, fc28, per-pair logits) w.r.t.
+    every OFF-unit parameter and w.r.t. the nine unit outputs, by autograd through this file's own
+    forward -- the same ATen backward kernels the reference's train loop runs
+    (train_off.py:126-146; only ``*motion*`` parameters train, :39-45, so the feature maps get no
+    gradient).  Returns (param_grads: key -> tensor, dM: list of nine [P,160,H,H]).
+    """
+    wl = {}
+    for k, v in w.items():
+        v = v.detach().clone()
+        if k.startswith(UNIT_PARAM_PREFIXES):
+            v.requires_grad_(True)
+        wl[k] = v
+    (fc7, fc14, fc28), st = off_forward(feats, wl, batch, length, variant, slice_mode,
+                                        consensus=False, return_stages=True, unit_drop=unit_drop)
+    ms = [st["motion_" + site] for site, _c, _h in SITES]
+    for m in ms:
+        m.retain_grad()
+    loss = (fc7 * cotangents[0]).sum() + (fc14 * cotangents[1]).sum() + (fc28 * cotangents[2]).sum()
+    loss.backward()
+    grads = dict((k, v.grad) for k, v in wl.items() if v.requires_grad)
+    return grads, [m.grad for m in ms]
+
+
+def unit_param_grads_from_dm(feats, w, batch, length, variant, slice_mode, dm, unit_drop=None):
+    """Unit-parameter gradients for GIVEN output gradients dM (list of nine [P,160,H,H]): the
+    restatement of what offk_off_units_backward computes."""
+    grads = {}
+    for si, ((site, _c, _h), x) in enumerate(zip(SITES, feats)):
+        wl = {}
+        for k, v in w.items():
+            if k.startswith(UNIT_PARAM_PREFIXES) and k.split(".")[0].endswith("_" + site):
+                wl[k] = v.detach().clone().requires_grad_(True)
+        if variant != VARIANT_RGB:
+            wl["sobel_edge_diagonal.conv.weight"] = w["sobel_edge_diagonal.conv.weight"]
+        m = off_unit(x, wl, site, batch, length, variant, slice_mode, None if unit_drop is None else unit_drop[si])
+        m.backward(dm[si])
+        grads.update((k, v.grad) for k, v in wl.items() if v.requires_grad)
+    return grads
+
+
+def segment_consensus_backward(grad_out, length_m1):
+    """basic_ops.py:29-33: grad_in = grad_output.expand(shape) / shape[dim]; grad_out [B,C] -> [B*(L-1),C]."""
+    b, c = grad_out.shape
+    return (grad_out.reshape(b, 1, c).expand(b, length_m1, c) / float(length_m1)).reshape(b * length_m1, c)
 
 
 def to_torch_weights(weights):

@@ -18,7 +18,7 @@ from offk_amd import spec, synth
 from oracle import off_oracle as orc
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(
-    os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    os.path.join(os.path.dirname(__file__), "golden", "*_b?_l?.npz")) if not os.path.basename(p).startswith("grad_"))
 
 
 def sample_idx(n, k=97):
