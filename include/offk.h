@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 2
+#define OFFK_ABI_VERSION 3
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -216,6 +216,52 @@ int offk_segment_consensus(void* stream, const float* x, int B, int T, int C, fl
  * used for the modality_fuse return (Flow_OFF.py:881). */
 int offk_score_fusion(void* stream, const float* const* scores, const float* weights, int n_sets, int videos,
                       int crops, int classes, float* fused, int32_t* pred);
+
+/* ---- Training side of the OFF units ------------------------------
+ * What train_off.py:126-151 needs from the path: the units' forward in training mode (nn.Dropout(p=0.8),
+ * RGB_OFF.py:356, on every spatial gradient, :612 ...), and the gradients of the units' parameters --
+ * the only unit-side tensors train_off.py:39-45 leaves trainable; the feature maps come from the frozen
+ * backbone and get no gradient.  The fusion stages / heads between the units and the loss are ordinary
+ * convolutions and stay with the caller's autograd; the cut is the gradient w.r.t. each unit output
+ * motion_<site> = cat(S 32, T 128) (:616), i.e. the leading channels of the gradients of the three cat
+ * results (:656, :760, :832).
+ *
+ * Dropout is reproducible instead of drawn from the framework's generator: element (pair, c, y, x) of site
+ * s is kept iff a 16-bit field of splitmix64(stream(drop_seed, s), (pair*H*W + y*W + x)*8 + c/4) is
+ * >= round(drop_p * 65536); kept values are scaled by 1/(1-drop_p).  offk_amd/synth.py (dropout_keep)
+ * is the same function in numpy.  drop_p = 0 is eval mode. */
+typedef struct offk_grad_view {
+  const float* data;   /* channels-last rows [P*H*W][cstride] (e.g. a torch channels_last gradient tensor) */
+  int32_t cstride;     /* channels per pixel of that buffer */
+  int32_t coff;        /* first of the unit's 160 channels: [coff, coff+32) = S, [coff+32, coff+160) = T */
+} offk_grad_view;
+
+/* Workspace for the calls below: the offk_workspace_bytes layout followed by the backward regions
+ * ("dG_<site>", "dD_<site>", partial-sum slabs); a superset, usable for offk_forward as well. */
+size_t offk_train_workspace_bytes(const offk_handle* h);
+
+/* offk_off_units in training mode: like offk_off_units, with the dropout above applied to S.  Leaves
+ * G_<site> / D_<site> in the workspace for the backward. */
+int offk_off_units_train(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace,
+                         uint64_t drop_seed, double drop_p);
+
+/* Gradient buffer: one flat fp32 device array the caller owns; offk_unit_grad_slot gives the offset and
+ * element count of a parameter (reference state_dict key, e.g. "motion_conv_gen_3a.weight") in the
+ * reference's own layout ([128,C,1,1], [128], [32,C,1,1], [32], [32,1,3,3], [32]). */
+size_t offk_unit_grad_floats(const offk_handle* h);
+int offk_unit_grad_slot(const offk_handle* h, const char* key, size_t* offset_floats, size_t* count);
+
+/* Backward of the nine units.  Needs the G_<site> / D_<site> regions of `workspace` as the matching
+ * offk_off_units(_train) / offk_forward call on the same feats left them, and the same drop_seed / drop_p.
+ * gm[s]: gradient w.r.t. motion_<site>.  grads: the flat buffer above; accumulate != 0 adds to it (the
+ * reference calls backward three times per step, train_off.py:141-143), otherwise it is overwritten.
+ * Every reduction has a fixed order: results are bit-reproducible.  NCHW feature maps only. */
+int offk_off_units_backward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES],
+                            const offk_grad_view gm[OFFK_NUM_SITES], void* workspace, uint64_t drop_seed, double drop_p,
+                            float* grads, int accumulate);
+
+/* Backward of offk_segment_consensus, basic_ops.py:29-33: grad_in[b*T + t][c] = grad_out[b][c] / T. */
+int offk_segment_consensus_backward(void* stream, const float* grad_out, int B, int T, int C, float* grad_in);
 
 /* NCHW <-> channels-last helpers (device pointers), used by tests and by callers that
  * want a reference-layout view of an internal buffer. */

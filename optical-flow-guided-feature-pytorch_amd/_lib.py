@@ -29,6 +29,10 @@ class OffkFeatParts(ctypes.Structure):
     _fields_ = [("n_parts", ctypes.c_int32), ("channels", ctypes.c_int32 * 4), ("data", ctypes.c_void_p * 4)]
 
 
+class OffkGradView(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("cstride", ctypes.c_int32), ("coff", ctypes.c_int32)]
+
+
 _c = ctypes
 _P = ctypes.c_void_p
 _F = ctypes.c_void_p       # float* passed as integer address (tensor.data_ptr())
@@ -61,6 +65,12 @@ SIGNATURES = {
     "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),
     "offk_segment_consensus": (_I, [_P, _F, _I, _I, _I, _F]),
     "offk_score_fusion": (_I, [_P, _c.POINTER(_F), _c.POINTER(_c.c_float), _I, _I, _I, _I, _F, _F]),
+    "offk_train_workspace_bytes": (_c.c_size_t, [_P]),
+    "offk_off_units_train": (_I, [_P, _P, _c.POINTER(_F), _P, _c.c_uint64, _c.c_double]),
+    "offk_unit_grad_floats": (_c.c_size_t, [_P]),
+    "offk_unit_grad_slot": (_I, [_P, _c.c_char_p, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
+    "offk_off_units_backward": (_I, [_P, _P, _c.POINTER(_F), _c.POINTER(OffkGradView), _P, _c.c_uint64, _c.c_double, _F, _I]),
+    "offk_segment_consensus_backward": (_I, [_P, _F, _I, _I, _I, _F]),
     "offk_nchw_to_nhwc": (_I, [_P, _F, _I, _I, _I, _F]),
     "offk_nhwc_to_nchw": (_I, [_P, _F, _I, _I, _I, _I, _I, _F]),
 }
@@ -85,7 +95,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 2:
+    if lib.offk_abi_version() != 3:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

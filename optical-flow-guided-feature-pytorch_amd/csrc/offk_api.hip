@@ -2,6 +2,8 @@
 // See include/offk.h for the contract and the reference lines each entry point stands for.
 #include "../../include/offk.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -118,6 +120,12 @@ struct offk_handle {
   hipStream_t side = nullptr;   // stays null with OFFK_SIDE_STREAM=0 in the environment at offk_create: heads on the caller's stream
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
 
+  // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
+  size_t train_ws_bytes = 0;
+  int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
+  std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
+  size_t grad_floats = 0;
+
   int conv_cfg[kNumConvs];       // tile plan per fusion conv (-1 = automatic)
   int conv_splitk[kNumConvs];    // K-split per fusion conv (0 = automatic)
   size_t splitk_floats = 0;      // size of the "splitk" workspace region
@@ -176,6 +184,13 @@ float* region(const offk_handle* h, void* ws, const char* name) {
   return reinterpret_cast<float*>(static_cast<char*>(ws) + it->second.first);
 }
 
+// S-blocks of the units' backward: 7-row strips at 28x28, whole planes below (two LDS tiles per block)
+void ub_plan(int H, int* strips, int* rows) {
+  *rows = H >= 28 ? 7 : H;
+  *strips = (H + *rows - 1) / *rows;
+}
+constexpr int kUbTpix = 64;
+
 void plan_workspace(offk_handle* h) {
   const size_t N = h->N, P = h->P;
   for (int s = 0; s < kNumSites; ++s) {
@@ -211,6 +226,42 @@ void plan_workspace(offk_handle* h) {
   h->splitk_floats = 8 * P * 196 * 64;
   add_region(h, "splitk", h->splitk_floats);
   h->ws_bytes = align_up(h->ws_bytes, 256);
+
+  // ---- training side: backward regions behind the forward layout (offk_train_workspace_bytes) ----
+  const size_t fwd_bytes = h->ws_bytes;
+  long long work = 0;   // (K-tile, channel slab) steps of the grouped weight-gradient GEMM
+  for (int s = 0; s < kNumSites; ++s) {
+    const int hw = kSites[s].H * kSites[s].H;
+    work += (long long)N * ((hw + 31) / 32) * ((kSites[s].C + 127) / 128);
+  }
+  h->wg_kpb = (int)std::max<long long>(4, (work + 1535) / 1536);
+  for (int s = 0; s < kNumSites; ++s) {
+    const size_t hw = (size_t)kSites[s].H * kSites[s].H;
+    const std::string n = kSites[s].name;
+    int strips, rows;
+    ub_plan(kSites[s].H, &strips, &rows);
+    const size_t kt_total = N * ((hw + 31) / 32), nchunks = (kt_total + h->wg_kpb - 1) / h->wg_kpb;
+    const size_t cpad = (size_t)((kSites[s].C + 127) / 128) * 128;
+    add_region(h, "dG_" + n, N * hw * kGenCh);
+    add_region(h, "dD_" + n, P * hw * kDownCh);
+    add_region(h, "dwp_" + n, P * strips * 10 * kDownCh);
+    add_region(h, "wgs_" + n, nchunks * kUnitCh * cpad);
+    add_region(h, "wgb_" + n, nchunks * kUnitCh);
+    auto slot = [&](const std::string& key, size_t count) {
+      h->grad_slots[key] = std::make_pair(h->grad_floats, count);
+      h->grad_floats += count;
+    };
+    slot("motion_conv_gen_" + n + ".weight", (size_t)kGenCh * kSites[s].C);
+    slot("motion_conv_gen_" + n + ".bias", kGenCh);
+    slot("motion_spatial_down_" + n + ".weight", (size_t)kDownCh * kSites[s].C);
+    slot("motion_spatial_down_" + n + ".bias", kDownCh);
+    if (h->cfg.variant != OFFK_VARIANT_DIAG_SOBEL) {
+      slot("motion_spatial_grad_" + n + ".weight", (size_t)kDownCh * 9);
+      slot("motion_spatial_grad_" + n + ".bias", kDownCh);
+    }
+  }
+  h->train_ws_bytes = align_up(h->ws_bytes, 256);
+  h->ws_bytes = fwd_bytes;
 }
 
 struct DeviceGuard {
@@ -267,10 +318,20 @@ void fill_st_site(const offk_handle* h, int site, const float* G, const float* D
   o->s_begin = 0; o->t_begin = 0; o->tgroup = 1;
 }
 
-int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo) {
+struct DropCfg { unsigned thresh = 0; float scale = 1.f; unsigned long long seed = 0; };
+int make_drop(offk_handle* h, unsigned long long seed, double p, DropCfg* d) {
+  if (!(p >= 0.0) || p >= 1.0) return fail(h, OFFK_ERR_INVALID, "dropout probability must be in [0, 1)");
+  d->thresh = (unsigned)llround(p * 65536.0);
+  d->scale = (float)(1.0 / (1.0 - p));
+  d->seed = seed;
+  return OFFK_OK;
+}
+
+int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo, const DropCfg& drop = DropCfg()) {
   StParams sp;
   memset(&sp, 0, sizeof(sp));
   sp.nsites = kNumSites; sp.B = h->cfg.batch; sp.L = h->cfg.length;
+  sp.drop_thresh = drop.thresh; sp.drop_scale = drop.scale;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   const char* tg = getenv("OFFK_K2_TGROUP");
   const bool tgrouped = tg ? (*tg != '0') : false;  // tuning knob: T-blocks walk all sites of a fusion buffer (measured slower: profiles/r01/k2_ab.txt)
@@ -280,6 +341,7 @@ int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo) {
                  region(h, ws, (std::string("D_") + kSites[s].name).c_str()), region(h, ws, fus[kSiteFusion[s]]),
                  kFusionC[kSiteFusion[s]], kSiteCoff[s], &sp.s[s]);
     sp.s[s].s_begin = sblk;
+    sp.s[s].drop_base = drop_stream_base(drop.seed, s);
     sblk += h->P * sp.s[s].strips;
     const bool group_head = s == 0 || kSiteFusion[s] != kSiteFusion[s - 1];
     if (!tgrouped || group_head) {
@@ -329,7 +391,8 @@ int finalize_pw(offk_handle* h, hipStream_t st) {
   return OFFK_OK;
 }
 
-int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[], void* ws, hipEvent_t* ev) {
+int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[], void* ws, hipEvent_t* ev,
+                  const DropCfg& drop = DropCfg()) {
   { int rc = finalize_pw(h, st); if (rc != OFFK_OK) return rc; }
   PwParams pp;
   memset(&pp, 0, sizeof(pp));
@@ -350,7 +413,7 @@ int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[],
   HIP_TRY(h, pw_reduce_launch(pp, st));
   if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
 
-  { int rc = run_sobel_tdiff_all(h, st, ws, 0); if (rc != OFFK_OK) return rc; }
+  { int rc = run_sobel_tdiff_all(h, st, ws, 0, drop); if (rc != OFFK_OK) return rc; }
   if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
   return OFFK_OK;
 }
@@ -809,6 +872,122 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     if (out28) HIP_TRY(h, consensus_launch(l28, B, T, ncls, out28, st));                          // Flow_OFF.py:875
   }
   if (ev) HIP_TRY(h, hipEventRecord(ev[6], st));
+  return OFFK_OK;
+}
+
+// ---- training side of the OFF units -----------------------------------
+size_t offk_train_workspace_bytes(const offk_handle* h) { return h ? h->train_ws_bytes : 0; }
+
+size_t offk_unit_grad_floats(const offk_handle* h) { return h ? h->grad_floats : 0; }
+
+int offk_unit_grad_slot(const offk_handle* h, const char* key, size_t* offset_floats, size_t* count) {
+  if (!h || !key) return OFFK_ERR_INVALID;
+  std::string k(key);
+  if (k.rfind("module.", 0) == 0) k = k.substr(7);
+  auto it = h->grad_slots.find(k);
+  if (it == h->grad_slots.end()) { h->err = "no unit gradient for key: " + k; return OFFK_ERR_INVALID; }
+  if (offset_floats) *offset_floats = it->second.first;
+  if (count) *count = it->second.second;
+  return OFFK_OK;
+}
+
+int offk_off_units_train(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace,
+                         uint64_t drop_seed, double drop_p) {
+  if (!h || !feats || !workspace) return fail(h, OFFK_ERR_INVALID, "offk_off_units_train: null argument");
+  DropCfg drop;
+  TRY(make_drop(h, drop_seed, drop_p, &drop));
+  for (int s = 0; s < kNumSites; ++s) {
+    if (!feats[s]) return fail(h, OFFK_ERR_INVALID, "offk_off_units_train: null feature map");
+    TRY(site_weights_ready(h, s, true, true));
+  }
+  DeviceGuard guard(h->cfg.device);
+  offk_feat_parts parts[kNumSites];
+  for (int s = 0; s < kNumSites; ++s) parts[s] = whole_map(s, feats[s]);
+  return run_off_units(h, static_cast<hipStream_t>(stream), parts, workspace, nullptr, drop);
+}
+
+int offk_off_units_backward(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES],
+                            const offk_grad_view gm[OFFK_NUM_SITES], void* workspace, uint64_t drop_seed, double drop_p,
+                            float* grads, int accumulate) {
+  if (!h || !feats || !gm || !workspace || !grads) return fail(h, OFFK_ERR_INVALID, "offk_off_units_backward: null argument");
+  if (h->cfg.feat_layout == OFFK_FEAT_NHWC) return fail(h, OFFK_ERR_INVALID, "offk_off_units_backward: NCHW feature maps only");
+  DropCfg drop;
+  TRY(make_drop(h, drop_seed, drop_p, &drop));
+  for (int s = 0; s < kNumSites; ++s) {
+    if (!feats[s] || !gm[s].data) return fail(h, OFFK_ERR_INVALID, "offk_off_units_backward: null feature map or gradient");
+    if (gm[s].cstride < gm[s].coff + kUnitCh || (gm[s].cstride & 3) || (gm[s].coff & 3) || gm[s].coff < 0)
+      return fail(h, OFFK_ERR_INVALID, "offk_off_units_backward: gradient view needs 16-byte aligned 160 channels inside cstride");
+    TRY(site_weights_ready(h, s, false, true));
+  }
+  DeviceGuard guard(h->cfg.device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  void* ws = workspace;
+  const bool learned_dw = h->cfg.variant != OFFK_VARIANT_DIAG_SOBEL;
+  auto reg = [&](const char* prefix, int s) { return region(h, ws, (std::string(prefix) + kSites[s].name).c_str()); };
+
+  // K2b: dM -> dGpre, dD, depthwise partials
+  UbParams up;
+  memset(&up, 0, sizeof(up));
+  up.nsites = kNumSites; up.B = h->cfg.batch; up.L = h->cfg.length; up.tpix = kUbTpix;
+  up.drop_thresh = drop.thresh; up.drop_scale = drop.scale;
+  int sblk = 0, tblk = 0;
+  int nsblocks[kNumSites];
+  for (int s = 0; s < kNumSites; ++s) {
+    UbSite& u = up.s[s];
+    u.G = reg("G_", s); u.D = reg("D_", s);
+    u.dw = learned_dw ? h->dw_w[s] : h->sobel_w;
+    u.gm = gm[s].data; u.gm_cs = gm[s].cstride; u.gm_coff = gm[s].coff;
+    u.dG = reg("dG_", s); u.dD = reg("dD_", s);
+    u.dw_part = learned_dw ? reg("dwp_", s) : nullptr;
+    u.drop_base = drop_stream_base(drop.seed, s);
+    u.H = kSites[s].H;
+    ub_plan(u.H, &u.strips, &u.rows);
+    u.tchunks = (u.H * u.H + kUbTpix - 1) / kUbTpix;
+    u.s_begin = sblk; u.t_begin = tblk;
+    nsblocks[s] = h->P * u.strips;
+    sblk += nsblocks[s];
+    tblk += h->cfg.batch * u.tchunks;
+  }
+  up.total_s = sblk; up.total_t = tblk;
+  HIP_TRY(h, units_bwd_launch(up, st));
+
+  // K1b: weight-gradient GEMM, per-chunk slabs
+  WgParams wp;
+  memset(&wp, 0, sizeof(wp));
+  wp.nsites = kNumSites; wp.L = h->cfg.length; wp.P = h->P; wp.slice_mode = h->cfg.slice_mode; wp.kt_per_blk = h->wg_kpb;
+  WrParams rp;
+  memset(&rp, 0, sizeof(rp));
+  rp.nsites = kNumSites; rp.accumulate = accumulate ? 1 : 0;
+  int blk = 0;
+  for (int i = 0; i < kNumSites; ++i) {
+    const int s = kPwOrder[i];
+    WgSite& w = wp.s[i];
+    w.xp[0] = feats[s]; w.cp[0] = kSites[s].C; w.nparts = 1;
+    w.dG = reg("dG_", s); w.dD = reg("dD_", s); w.slab = reg("wgs_", s); w.bpart = reg("wgb_", s);
+    w.C = kSites[s].C; w.HW = kSites[s].H * kSites[s].H;
+    w.tpf = (w.HW + 31) / 32; w.kt_total = h->N * w.tpf;
+    w.ntiles = (w.C + 127) / 128; w.nchunks = (w.kt_total + h->wg_kpb - 1) / h->wg_kpb;
+    w.blk_begin = blk;
+    blk += w.nchunks * w.ntiles;
+    WrSite& r = rp.s[i];
+    r.slab = w.slab; r.bpart = w.bpart; r.dw_part = learned_dw ? reg("dwp_", s) : nullptr;
+    const std::string n = kSites[s].name;
+    auto dst = [&](const std::string& key) { return grads + h->grad_slots[key].first; };
+    r.gen_w = dst("motion_conv_gen_" + n + ".weight"); r.gen_b = dst("motion_conv_gen_" + n + ".bias");
+    r.down_w = dst("motion_spatial_down_" + n + ".weight"); r.down_b = dst("motion_spatial_down_" + n + ".bias");
+    if (learned_dw) { r.dw_w = dst("motion_spatial_grad_" + n + ".weight"); r.dw_b = dst("motion_spatial_grad_" + n + ".bias"); }
+    r.C = w.C; r.cpad = w.ntiles * 128; r.nchunks = w.nchunks; r.nsblocks = nsblocks[s];
+  }
+  wp.total_blocks = blk;
+  HIP_TRY(h, pw_wgrad_launch(wp, st));
+  HIP_TRY(h, wgrad_reduce_launch(rp, st));
+  return OFFK_OK;
+}
+
+int offk_segment_consensus_backward(void* stream, const float* grad_out, int B, int T, int C, float* grad_in) {
+  if (!grad_out || !grad_in || B < 1 || T < 1 || C < 1) return fail(nullptr, OFFK_ERR_INVALID, "offk_segment_consensus_backward: bad argument");
+  hipError_t e = consensus_bwd_launch(grad_out, B, T, C, grad_in, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, OFFK_ERR_HIP, hipGetErrorString(e));
   return OFFK_OK;
 }
 

@@ -106,4 +106,18 @@ __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
+// ---- reproducible dropout multiplier of the units' spatial branch (training) ------------------------
+// splitmix64 finaliser, the same integer function as offk_amd/synth.py (raw_u64 / dropout_keep): draw
+// q = (pair*HW + pixel)*8 + channel quad of the site's stream serves the quad's four channels, 16 bits each.
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ float4 drop_mul(unsigned long long base, unsigned long long q, unsigned thresh, float scale) {
+  const unsigned long long u = mix64(base + (q + 1) * 0x9E3779B97F4A7C15ull);
+  return make_float4(((unsigned)u & 0xFFFFu) >= thresh ? scale : 0.f, ((unsigned)(u >> 16) & 0xFFFFu) >= thresh ? scale : 0.f,
+                     ((unsigned)(u >> 32) & 0xFFFFu) >= thresh ? scale : 0.f, (unsigned)(u >> 48) >= thresh ? scale : 0.f);
+}
+
 }  // namespace offk

@@ -69,16 +69,74 @@ struct StSite {
   int s_begin;        // first S-block (spatial role) of this site within the S index space
   int t_begin;        // first T-block (temporal role) of this site within the T index space
   int tgroup;         // sites (this one and the next tgroup-1 table entries) one T-block walks: they share M
+  unsigned long long drop_base;   // training: mixed base of this site's dropout stream (drop_stream_base)
 };
 struct StParams {
   StSite s[kNumSites];
   int nsites;
   int total_s, total_t;   // S-blocks = sum P*strips, T-blocks = sum B*tchunks
   int B, L, tpix;         // tpix = pixels per T-block
+  unsigned drop_thresh;   // training: 16-bit keep threshold of nn.Dropout(p) on the spatial branch, 0 = eval (identity)
+  float drop_scale;       // 1 / (1 - p)
 };
 void st_plan(int H, int* strips, int* rows);
 int st_tchunks(int H);
 hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st);
+
+// ---- training side of the OFF units (units_bwd.hip) ----------------------------------
+unsigned long long drop_stream_base(unsigned long long seed, int site);
+struct UbSite {
+  const float* G;     // saved post-ReLU gen output [N*HW][128]
+  const float* D;     // saved down output [P*HW][32]
+  const float* dw;    // [9][32] tap-major depthwise weights (or the Sobel taps)
+  const float* gm;    // gradient w.r.t. motion_<site>: channels-last rows [P*HW][gm_cs], the unit's 160 channels at gm_coff
+  int gm_cs, gm_coff;
+  float* dG;          // out: gradient w.r.t. the gen conv output (pre-ReLU) [N*HW][128]
+  float* dD;          // out: gradient w.r.t. the down conv output [P*HW][32]
+  float* dw_part;     // out: [P*strips][10][32] per-S-block partial sums (9 taps + bias); nullptr = frozen Sobel
+  unsigned long long drop_base;
+  int H, strips, rows, tchunks, s_begin, t_begin;
+};
+struct UbParams {
+  UbSite s[kNumSites];
+  int nsites, total_s, total_t, B, L, tpix;
+  unsigned drop_thresh;
+  float drop_scale;
+};
+hipError_t units_bwd_launch(const UbParams& p, hipStream_t st);
+
+struct WgSite {
+  const float* xp[4];   // feature map parts, NCHW (as PwSite)
+  int cp[4];
+  int nparts;
+  const float* dG;      // [N*HW][128]
+  const float* dD;      // [P*HW][32]
+  float* slab;          // [nchunks][160][ntiles*128] partial weight-gradient tiles
+  float* bpart;         // [nchunks][160] partial bias gradients
+  int C, HW;
+  int tpf;              // 32-pixel K-tiles per frame = ceil(HW / 32)
+  int kt_total;         // N * tpf
+  int ntiles;           // 128-channel slabs = ceil(C / 128)
+  int nchunks;          // ceil(kt_total / kt_per_blk)
+  int blk_begin;
+};
+struct WgParams {
+  WgSite s[kNumSites];
+  int nsites, total_blocks, L, P, slice_mode, kt_per_blk;
+};
+hipError_t pw_wgrad_launch(const WgParams& p, hipStream_t st);
+
+struct WrSite {
+  const float* slab; const float* bpart; const float* dw_part;
+  float *gen_w, *gen_b, *down_w, *down_b, *dw_w, *dw_b;   // destinations in the caller's gradient buffer
+  int C, cpad, nchunks, nsblocks;
+};
+struct WrParams {
+  WrSite s[kNumSites];
+  int nsites, accumulate;
+};
+hipError_t wgrad_reduce_launch(const WrParams& p, hipStream_t st);
+hipError_t consensus_bwd_launch(const float* go, int B, int T, int C, float* gi, hipStream_t st);
 
 // ---- K5 / K6 / layout helpers ----------------------------------------------------
 hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, const float* fw,

@@ -7,7 +7,8 @@
 //   motion_s = cat(S, T); fusion = cat(motion_*, carried)     :616, :656, :760, :832
 // The kernel writes [S | T] straight into channels [m_coff, m_coff+160) of the fusion
 // buffer, so neither concat ever exists as a copy.  dropout(p=0.8) (:612) is the
-// identity in eval mode.
+// identity in eval mode; in training mode (StParams.drop_thresh != 0, offk_off_units_train) the S half is
+// multiplied by the reproducible keep-mask / (1 - p) of units_bwd.hip.
 //
 // Layout: everything channels-last.  G [N*HW][128], D [P*HW][32], M [P*HW][m_cs].
 // All nine sites share ONE grouped launch made of two block roles, interleaved in block-id
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
   S.G = p.s[0].G; S.D = p.s[0].D; S.dw = p.s[0].dw; S.db = p.s[0].db; S.M = p.s[0].M; S.H = p.s[0].H;
   S.m_cs = p.s[0].m_cs; S.m_coff = p.s[0].m_coff; S.strips = p.s[0].strips; S.rows = p.s[0].rows;
   S.s_begin = p.s[0].s_begin; S.t_begin = p.s[0].t_begin; S.tchunks = p.s[0].tchunks; S.tgroup = p.s[0].tgroup;
+  S.drop_base = p.s[0].drop_base;
   int si = 0;
 #pragma unroll
   for (int i = 1; i < kNumSites; ++i)
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
       S.G = p.s[i].G; S.D = p.s[i].D; S.dw = p.s[i].dw; S.db = p.s[i].db; S.M = p.s[i].M; S.H = p.s[i].H;
       S.m_cs = p.s[i].m_cs; S.m_coff = p.s[i].m_coff; S.strips = p.s[i].strips; S.rows = p.s[i].rows;
       S.s_begin = p.s[i].s_begin; S.t_begin = p.s[i].t_begin; S.tchunks = p.s[i].tchunks; S.tgroup = p.s[i].tgroup;
+      S.drop_base = p.s[i].drop_base;
       si = i;
     }
   const int H = S.H, W = S.H, HW = H * H;
@@ -221,6 +224,15 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
         if (coff[j] >= 0) acc[j] = fma4(w4, *reinterpret_cast<const float4*>(tile + coff[j] + toff), acc[j]);
     }
   float* mrow = S.M + (size_t)pr * HW * S.m_cs + S.m_coff + cq4;
+  if (p.drop_thresh) {   // training: nn.Dropout on the spatial gradient (:612)
+#pragma unroll
+    for (int j = 0; j < ST_OUT_MAX; ++j)
+      if (coff[j] >= 0) {
+        const float4 k4 = drop_mul(S.drop_base, ((unsigned long long)pr * HW + q0 + (tid >> 3) + 32 * j) * 8 + (tid & 7),
+                                   p.drop_thresh, p.drop_scale);
+        acc[j] = make_float4(acc[j].x * k4.x, acc[j].y * k4.y, acc[j].z * k4.z, acc[j].w * k4.w);
+      }
+  }
 #pragma unroll
   for (int j = 0; j < ST_OUT_MAX; ++j)
     if (coff[j] >= 0) stg4<NTS>(mrow + (size_t)(q0 + (tid >> 3) + 32 * j) * S.m_cs, acc[j]);

@@ -35,7 +35,8 @@ class OffForward:
     """
 
     def __init__(self, batch, length, variant=spec.VARIANT_RGB, slice_mode=spec.SLICE_FLAT,
-                 consensus=None, num_classes=spec.NUM_CLASSES, feat_layout=0, device=None, precision=0):
+                 consensus=None, num_classes=spec.NUM_CLASSES, feat_layout=0, device=None, precision=0,
+                 training=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.OffkError("no HIP device visible: the OFF forward has no CPU path")
@@ -54,6 +55,7 @@ class OffForward:
         _lib.check(self.lib.offk_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
         self._ws = None
+        self.training = bool(training)   # allocate the workspace superset the units' backward needs
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -98,6 +100,8 @@ class OffForward:
     # ---- workspace ----------------------------------------------------------------
     @property
     def workspace_bytes(self):
+        if self.training:
+            return int(self.lib.offk_train_workspace_bytes(self._h))
         return int(self.lib.offk_workspace_bytes(self._h))
 
     @property
@@ -175,6 +179,53 @@ class OffForward:
         arr = self._feat_array(feats)
         _lib.check(self.lib.offk_off_units(self._h, _stream(), arr, _ptr(self.workspace)), self._h)
 
+    # ---- training side of the units ----------------------------
+    def off_units_train(self, feats, drop_seed=0, drop_p=0.8):
+        """K1+K2 in training mode: nn.Dropout(p) (RGB_OFF.py:356, :612) on the spatial gradients with the
+        reproducible mask of synth.dropout_keep; leaves G/D in the workspace for off_units_backward."""
+        arr = self._feat_array(feats)
+        _lib.check(self.lib.offk_off_units_train(self._h, _stream(), arr, _ptr(self.workspace),
+                                                 ctypes.c_uint64(int(drop_seed)), float(drop_p)), self._h)
+
+    def unit_grad_slots(self):
+        """OrderedDict key -> (offset, shape) of every unit parameter in the flat gradient buffer."""
+        from collections import OrderedDict
+        out = OrderedDict()
+        for key, shape in spec.weight_shapes(self.variant).items():
+            if not key.startswith(spec.UNIT_PARAM_PREFIXES):
+                continue
+            off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(self.lib.offk_unit_grad_slot(self._h, key.encode(), ctypes.byref(off), ctypes.byref(cnt)), self._h)
+            assert cnt.value == int(np.prod(shape))
+            out[key] = (off.value, shape)
+        return out
+
+    def new_unit_grads(self):
+        return torch.zeros(int(self.lib.offk_unit_grad_floats(self._h)), dtype=torch.float32, device=self.device)
+
+    def off_units_backward(self, feats, grad_views, drop_seed=0, drop_p=0.0, grads=None, accumulate=False):
+        """Gradients of the units' parameters.  grad_views: nine (tensor, coff) pairs -- a channels-last
+        gradient buffer [P, H, W, Cs] (or [P*H*W, Cs]) and the first of the unit's 160 channels in it.
+        Needs training=True (workspace superset) and the G/D state of the matching forward call.
+        Returns (flat grads tensor, dict key -> view in the reference's parameter shape)."""
+        if not self.training:
+            raise _lib.OffkError("create the handle with training=True for the units' backward")
+        arr = self._feat_array(feats)
+        gv = (_lib.OffkGradView * spec.NUM_SITES)()
+        for i, ((t, coff), (_n, _c, H)) in enumerate(zip(grad_views, spec.SITES)):
+            _check_dev(t, "grad_views[%d]" % i, self.device)
+            if t.numel() != self.P * H * H * t.shape[-1]:
+                raise ValueError("grad_views[%d] has %d elements, expected P*H*W*%d" % (i, t.numel(), t.shape[-1]))
+            gv[i].data, gv[i].cstride, gv[i].coff = t.data_ptr(), t.shape[-1], int(coff)
+        if grads is None:
+            grads = self.new_unit_grads()
+        _check_dev(grads, "grads", self.device)
+        _lib.check(self.lib.offk_off_units_backward(self._h, _stream(), arr, gv, _ptr(self.workspace),
+                                                    ctypes.c_uint64(int(drop_seed)), float(drop_p), _ptr(grads),
+                                                    int(bool(accumulate))), self._h)
+        views = dict((k, grads[off:off + int(np.prod(shape))].view(shape)) for k, (off, shape) in self.unit_grad_slots().items())
+        return grads, views
+
     # ---- stage entry points -----------------------------------------------------------
     def pw_reduce(self, site, feat):
         _name, _C, H = spec.SITES[site]
@@ -207,6 +258,15 @@ class OffForward:
         calls = (ctypes.c_int64 * _lib.NUM_STAGES)()
         _lib.check(self.lib.offk_stage_times(self._h, ms, calls, int(reset)), self._h)
         return dict((n, (ms[i], int(calls[i]))) for i, n in enumerate(_lib.STAGE_NAMES))
+
+
+def segment_consensus_backward(grad_out, length_m1):
+    """basic_ops.py:29-33: grad_out [B, C] -> grad_in [B*(L-1), C] = grad_out / (L-1), repeated."""
+    lib = _lib.load()
+    B, C = grad_out.shape
+    gi = torch.empty(B * length_m1, C, dtype=torch.float32, device=grad_out.device)
+    _lib.check(lib.offk_segment_consensus_backward(_stream(), _ptr(grad_out.contiguous()), B, int(length_m1), C, _ptr(gi)))
+    return gi
 
 
 # ---- handle-less stage kernels (channels-last tensors) ----------------------------------

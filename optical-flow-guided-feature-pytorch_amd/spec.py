@@ -71,6 +71,8 @@ FUSION_CONVS = (
 )
 HEADS = (("fc_action_motion", 1024), ("fc_action_motion_28", 256), ("fc_action_motion_14", 512))
 SOBEL_KEY = "sobel_edge_diagonal.conv.weight"
+# parameters of the OFF units themselves (trainable per train_off.py:39-45; the Sobel weight is frozen, util.py:72)
+UNIT_PARAM_PREFIXES = ("motion_conv_gen_", "motion_spatial_down_", "motion_spatial_grad_")
 
 
 def weight_shapes(variant):

@@ -49,15 +49,21 @@ def spatial_frames(x, batch, length, slice_mode):
     return x.reshape(batch, length, c, h, wd)[:, :length - 1].reshape(p, c, h, wd)
 
 
-def off_unit(x, w, site, batch, length, variant, slice_mode, drop=None):
+def off_unit(x, w, site, batch, length, variant, slice_mode, drop=None, gen_mask=None):
     """One OFF unit -> motion_<site> [P,160,H,H] = cat(spatial 32, temporal 128).
 
     RGB_OFF.py:596-616 (site 3a; the other eight sites are identical up to names);
     Flow_OFF.py:606-627 for the diagonal-Sobel variant (util.py:52-77).
     ``drop``: training mode -- the multiplier nn.Dropout(p) (:356, applied at :612) would use,
     keep_mask / (1 - p), as a [P,32,H,H] tensor; None = eval (identity).
+    ``gen_mask``: gradient tests only -- a [N,128,H,H] 0/1 tensor that replaces the ReLU's own decision
+    (g = pre * mask).  Which side of the kink a pre-activation within rounding distance of zero falls on is
+    implementation-defined, and one flipped element moves a whole row of the weight gradient; the tests
+    pass the device's decision (after checking it differs from this file's only where |pre| ~ 1e-6) so both
+    sides differentiate the same piecewise-linear function.
     """
-    g = torch.relu(_conv(x, w, "motion_conv_gen_" + site))                 # :597-598
+    g = _conv(x, w, "motion_conv_gen_" + site)                             # :597
+    g = torch.relu(g) if gen_mask is None else g * gen_mask                # :598
     t = temporal_diff(g, batch)                                            # :599-604
     d = _conv(spatial_frames(x, batch, length, slice_mode), w, "motion_spatial_down_" + site)  # :609-610
     if variant == VARIANT_RGB:
@@ -127,7 +133,7 @@ def segment_consensus(x, batch):
 
 
 def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_FLAT,
-                consensus=None, return_stages=False, unit_drop=None):
+                consensus=None, return_stages=False, unit_drop=None, unit_gen_mask=None):
     """The whole OFF sub-network on nine injected feature maps.
 
     feats: list of nine [N,C,H,H] fp32 tensors (inception_{3a..5b}_output_out).
@@ -141,7 +147,8 @@ def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_F
     m = {}
     for si, ((site, _c, _h), x) in enumerate(zip(SITES, feats)):
         m[site] = off_unit(x, w, site, batch, length, variant, slice_mode,
-                           None if unit_drop is None else unit_drop[si])
+                           None if unit_drop is None else unit_drop[si],
+                           None if unit_gen_mask is None else unit_gen_mask[si])
     f28 = torch.cat((m["3a"], m["3b"]), dim=1)                                      # :656
     sum_28c = fusion_28(f28, w)
     f14 = torch.cat((m["3c"], m["4a"], m["4b"], m["4c"], m["4d"], sum_28c), dim=1)  # :760
@@ -164,7 +171,7 @@ def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_F
 UNIT_PARAM_PREFIXES = ("motion_conv_gen_", "motion_spatial_down_", "motion_spatial_grad_")
 
 
-def unit_backward(feats, w, batch, length, variant, slice_mode, cotangents, unit_drop=None):
+def unit_backward(feats, w, batch, length, variant, slice_mode, cotangents, unit_drop=None, unit_gen_mask=None):
     """Gradients of loss = sum_k <out_k, cotangent_k> (k = fc7, fc14, fc28, per-pair logits) w.r.t.
     every OFF-unit parameter and w.r.t. the nine unit outputs, by autograd through this file's own
     forward -- the same ATen backward kernels the reference's train loop runs
@@ -178,7 +185,8 @@ def unit_backward(feats, w, batch, length, variant, slice_mode, cotangents, unit
             v.requires_grad_(True)
         wl[k] = v
     (fc7, fc14, fc28), st = off_forward(feats, wl, batch, length, variant, slice_mode,
-                                        consensus=False, return_stages=True, unit_drop=unit_drop)
+                                        consensus=False, return_stages=True, unit_drop=unit_drop,
+                                        unit_gen_mask=unit_gen_mask)
     ms = [st["motion_" + site] for site, _c, _h in SITES]
     for m in ms:
         m.retain_grad()
@@ -188,7 +196,7 @@ def unit_backward(feats, w, batch, length, variant, slice_mode, cotangents, unit
     return grads, [m.grad for m in ms]
 
 
-def unit_param_grads_from_dm(feats, w, batch, length, variant, slice_mode, dm, unit_drop=None):
+def unit_param_grads_from_dm(feats, w, batch, length, variant, slice_mode, dm, unit_drop=None, unit_gen_mask=None):
     """Unit-parameter gradients for GIVEN output gradients dM (list of nine [P,160,H,H]): the
     restatement of what offk_off_units_backward computes."""
     grads = {}
@@ -199,7 +207,8 @@ def unit_param_grads_from_dm(feats, w, batch, length, variant, slice_mode, dm, u
                 wl[k] = v.detach().clone().requires_grad_(True)
         if variant != VARIANT_RGB:
             wl["sobel_edge_diagonal.conv.weight"] = w["sobel_edge_diagonal.conv.weight"]
-        m = off_unit(x, wl, site, batch, length, variant, slice_mode, None if unit_drop is None else unit_drop[si])
+        m = off_unit(x, wl, site, batch, length, variant, slice_mode, None if unit_drop is None else unit_drop[si],
+                     None if unit_gen_mask is None else unit_gen_mask[si])
         m.backward(dm[si])
         grads.update((k, v.grad) for k, v in wl.items() if v.requires_grad)
     return grads
