@@ -955,6 +955,7 @@ int offk_off_units_backward(offk_handle* h, void* stream, const float* const fea
   WgParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.nsites = kNumSites; wp.L = h->cfg.length; wp.P = h->P; wp.slice_mode = h->cfg.slice_mode; wp.kt_per_blk = h->wg_kpb;
+  wp.precision = h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0;
   WrParams rp;
   memset(&rp, 0, sizeof(rp));
   rp.nsites = kNumSites; rp.accumulate = accumulate ? 1 : 0;

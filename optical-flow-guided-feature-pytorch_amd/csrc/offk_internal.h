@@ -123,6 +123,7 @@ struct WgSite {
 struct WgParams {
   WgSite s[kNumSites];
   int nsites, total_blocks, L, P, slice_mode, kt_per_blk;
+  int precision;        // 0 = exact fp32 MFMA, 1 = bf16x3
 };
 hipError_t pw_wgrad_launch(const WgParams& p, hipStream_t st);
 

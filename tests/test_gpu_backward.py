@@ -58,7 +58,7 @@ def grad_views(dm):
     return views
 
 
-def device_relu_masks(h, feats_cpu, w, B, L):
+def device_relu_masks(h, feats_cpu, w, B, L, slack=1e-5):
     """The ReLU decisions the device took (saved G > 0) as nine [N,128,H,H] 0/1 tensors, after checking that
     they differ from the oracle's own only for pre-activations within rounding distance of zero."""
     masks = []
@@ -68,9 +68,9 @@ def device_relu_masks(h, feats_cpu, w, B, L):
             pre = torch.nn.functional.conv2d(x, w["motion_conv_gen_%s.weight" % site], w["motion_conv_gen_%s.bias" % site])
         mask = (G > 0)
         flip = mask != (pre > 0)
-        assert int(flip.sum()) <= 5 + 1e-5 * flip.numel(), site
+        assert int(flip.sum()) <= 5 + slack * flip.numel(), site
         if flip.any():
-            assert float(pre[flip].abs().max()) < 1e-5 * max(1.0, float(pre.abs().max())), site
+            assert float(pre[flip].abs().max()) < slack * max(1.0, float(pre.abs().max())), site
         masks.append(mask.float())
     return masks
 
@@ -82,19 +82,26 @@ def make(rt, B, L, variant, slice_mode=spec.SLICE_FLAT, precision="fp32"):
     return h, orc.to_torch_weights(w)
 
 
-@pytest.mark.parametrize("variant,B,L,slice_mode,seed", [
-    (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, None),
-    (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, 7),
-    (spec.VARIANT_RGB, 3, 4, spec.SLICE_FLAT, 11),
-    (spec.VARIANT_RGB, 3, 4, spec.SLICE_PER_CLIP, 5),
-    (spec.VARIANT_FLOW, 2, 3, spec.SLICE_FLAT, None),
-    (spec.VARIANT_FLOW, 2, 7, spec.SLICE_FLAT, 3),
+@pytest.mark.parametrize("variant,B,L,slice_mode,seed,prec", [
+    (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, None, "fp32"),
+    (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, 7, "fp32"),
+    (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, 7, "bf16x3"),
+    (spec.VARIANT_RGB, 3, 4, spec.SLICE_FLAT, 11, "fp32"),
+    (spec.VARIANT_RGB, 3, 4, spec.SLICE_FLAT, 11, "bf16x3"),
+    (spec.VARIANT_RGB, 3, 4, spec.SLICE_PER_CLIP, 5, "fp32"),
+    (spec.VARIANT_RGB, 3, 4, spec.SLICE_PER_CLIP, 5, "bf16x3"),
+    (spec.VARIANT_FLOW, 2, 3, spec.SLICE_FLAT, None, "fp32"),
+    (spec.VARIANT_FLOW, 2, 7, spec.SLICE_FLAT, 3, "fp32"),
+    (spec.VARIANT_FLOW, 2, 7, spec.SLICE_FLAT, 3, "bf16x3"),
 ])
-def test_units_backward_vs_oracle(rt, variant, B, L, slice_mode, seed):
+def test_units_backward_vs_oracle(rt, variant, B, L, slice_mode, seed, prec):
+    """fp32: exact-fp32 MFMA weight-gradient GEMM; bf16x3: the split-bf16 core (offk_common.h), both operands
+    split on the fly -- same RTOL."""
     P = B * (L - 1)
     cfg = 2 if B == 2 else 3
     feats = synth.make_features(B, L, cfg)
-    h, w = make(rt, B, L, variant, slice_mode)
+    h, w = make(rt, B, L, variant, slice_mode, precision=prec)
+    slack = 1e-5 if prec == "fp32" else 1e-4
     drops = None if seed is None else unit_drop(seed, P)
     tf = [torch.from_numpy(f) for f in feats]
     dfeats = [dev(f) for f in feats]
@@ -102,7 +109,8 @@ def test_units_backward_vs_oracle(rt, variant, B, L, slice_mode, seed):
         h.off_units(dfeats)
     else:
         h.off_units_train(dfeats, seed, DROP_P)
-    ref, dm = orc.unit_backward(tf, w, B, L, variant, slice_mode, cotangents(P), drops, device_relu_masks(h, tf, w, B, L))
+    ref, dm = orc.unit_backward(tf, w, B, L, variant, slice_mode, cotangents(P), drops,
+                                device_relu_masks(h, tf, w, B, L, slack))
     # training-mode forward: the fusion buffers hold [dropout(S) | T]
     with torch.no_grad():
         m_ref = [orc.off_unit(x, w, site, B, L, variant, slice_mode, None if drops is None else drops[si])
@@ -165,7 +173,7 @@ def test_units_backward_full_size_properties(rt):
     zero dM, bias gradient = column sums of the kernel's own dGpre / dD, bitwise reproducibility."""
     B, L = 64, 7
     P = B * (L - 1)
-    h, _w = make(rt, B, L, spec.VARIANT_RGB)
+    h, _w = make(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
     feats = [dev(f) for f in synth.make_features(B, L, 2)]
     h.off_units_train(feats, 21, DROP_P)
     gen = torch.Generator(device="cuda").manual_seed(5)
