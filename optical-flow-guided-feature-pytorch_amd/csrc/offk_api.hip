@@ -121,6 +121,7 @@ struct offk_handle {
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
 
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
+  float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
   std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
@@ -565,6 +566,11 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     offk_destroy(h);
     return rc;
   }
+  if (dev_alloc(h, &h->zero_page, 64) != OFFK_OK) {
+    g_err = h->err;
+    offk_destroy(h);
+    return OFFK_ERR_HIP;
+  }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&
@@ -956,6 +962,8 @@ int offk_off_units_backward(offk_handle* h, void* stream, const float* const fea
   memset(&wp, 0, sizeof(wp));
   wp.nsites = kNumSites; wp.L = h->cfg.length; wp.P = h->P; wp.slice_mode = h->cfg.slice_mode; wp.kt_per_blk = h->wg_kpb;
   wp.precision = h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0;
+  { const char* e = getenv("OFFK_WG_DBG"); wp.dbg = e ? atoi(e) : 0; }
+  wp.zeros = h->zero_page;
   WrParams rp;
   memset(&rp, 0, sizeof(rp));
   rp.nsites = kNumSites; rp.accumulate = accumulate ? 1 : 0;

@@ -124,6 +124,8 @@ struct WgParams {
   WgSite s[kNumSites];
   int nsites, total_blocks, L, P, slice_mode, kt_per_blk;
   int precision;        // 0 = exact fp32 MFMA, 1 = bf16x3
+  int dbg;              // ablation bits for tools (1: no X loads, 2: no dG loads)
+  const float* zeros;   // >= 16 bytes of zeros in device memory: what a masked-out load reads
 };
 hipError_t pw_wgrad_launch(const WgParams& p, hipStream_t st);
 

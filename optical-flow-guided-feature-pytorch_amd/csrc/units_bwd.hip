@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
       }
     }
     xok[r] = cb < C;
-    xrow[r] = xb + (size_t)(kl + (tid >> 3)) * HW + 4 * (tid & 7);
+    xrow[r] = xb + (size_t)(kl + (tid >> 3)) * HW;
     xfs[r] = (size_t)cpart * HW;
   }
   const bool wave_on = nt * WG_BN + 32 * wave < C;
@@ -306,35 +306,47 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
   float4 bs_g = make_float4(0.f, 0.f, 0.f, 0.f), bs_d = make_float4(0.f, 0.f, 0.f, 0.f);
 
   int frame = kt0 / S.tpf, kin = (kt0 - frame * S.tpf) * BK;
+  int kin_ld = kin;   // k offset of the tile currently held in rg[]
+  // Branch-free loads: an out-of-range piece reads the handle's zero page instead of being skipped.  With
+  // `if (ok) v = load` the compiler serialises the loads of one tile (s_waitcnt vmcnt(0) in front of every
+  // load whose destination registers are also written on another control-flow path).
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 7x7 maps: rows are only 4-byte aligned
   auto load_tile = [&]() {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* ga = S.dG + ((size_t)frame * HW + kin + 4 * pq) * kGenCh + 4 * cq;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      rg[j] = z;
-      if (kin + 4 * pq + j < HW) rg[j] = *reinterpret_cast<const float4*>(ga + (size_t)j * kGenCh);
+      const float* q = (!(p.dbg & 2) && kin + 4 * pq + j < HW) ? ga + (size_t)j * kGenCh : p.zeros;
+      rg[j] = *reinterpret_cast<const float4*>(q);
     }
     const int dr = wg_down_row(frame, p.L, p.P, p.slice_mode);
-    rg[4] = z;
-    if (dr >= 0 && kin + dpx < HW) rg[4] = *reinterpret_cast<const float4*>(S.dD + ((size_t)dr * HW + kin + dpx) * kDownCh + 4 * dcq);
-    const int k = kin + 4 * (tid & 7);
+    {
+      const float* q = (dr >= 0 && kin + dpx < HW) ? S.dD + ((size_t)dr * HW + kin + dpx) * kDownCh + 4 * dcq : p.zeros;
+      rg[4] = *reinterpret_cast<const float4*>(q);
+    }
+    // X quad k..k+3 of the row; a quad that straddles the row end (HW % 4 != 0) is read from HW-4 and shifted
+    // into place by store_tile
+    const int k = kin + 4 * (tid & 7), kk = min(k, HW - 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      rg[5 + r] = z;
-      if (xok[r]) {
-        const float* q = xrow[r] + (size_t)frame * xfs[r] + kin;
-        if (vec) {
-          if (k < HW) rg[5 + r] = *reinterpret_cast<const float4*>(q);
-        } else {
-          if (k < HW) rg[5 + r].x = q[0];
-          if (k + 1 < HW) rg[5 + r].y = q[1];
-          if (k + 2 < HW) rg[5 + r].z = q[2];
-          if (k + 3 < HW) rg[5 + r].w = q[3];
-        }
+      const float* q = (xok[r] && k < HW && !(p.dbg & 1)) ? xrow[r] + (size_t)frame * xfs[r] + kk : p.zeros;
+      const f4u v = *reinterpret_cast<const f4u*>(q);
+      rg[5 + r] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    kin_ld = kin;
+  };
+  auto fix_x_tail = [&]() {   // HW % 4 != 0 only: the quad was loaded `sh` floats early
+    const int k = kin_ld + 4 * (tid & 7);
+    const int sh = k < HW ? k - min(k, HW - 4) : 0;
+    if (sh) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 v = rg[5 + r];
+        rg[5 + r] = sh == 1 ? make_float4(v.y, v.z, v.w, 0.f) : (sh == 2 ? make_float4(v.z, v.w, 0.f, 0.f) : make_float4(v.w, 0.f, 0.f, 0.f));
       }
     }
   };
   auto store_tile = [&]() {
+    if (!vec) fix_x_tail();
     bs_g.x += (rg[0].x + rg[1].x) + (rg[2].x + rg[3].x); bs_g.y += (rg[0].y + rg[1].y) + (rg[2].y + rg[3].y);
     bs_g.z += (rg[0].z + rg[1].z) + (rg[2].z + rg[3].z); bs_g.w += (rg[0].w + rg[1].w) + (rg[2].w + rg[3].w);
     bs_d.x += rg[4].x; bs_d.y += rg[4].y; bs_d.z += rg[4].z; bs_d.w += rg[4].w;
