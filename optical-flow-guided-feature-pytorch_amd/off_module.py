@@ -108,6 +108,97 @@ class OFFSubNetwork(nn.Module):
             return rt.forward(feats, want28=want28)
 
 
+class _OFFUnitsFn(torch.autograd.Function):
+    """autograd node around offk_off_units(_train) / offk_off_units_backward.  Inputs after the three
+    bookkeeping arguments are the unit parameters in ``OFFUnits.param_keys`` order; the feature maps come from
+    the frozen backbone (train_off.py:39-56) and get no gradient."""
+
+    @staticmethod
+    def forward(ctx, mod, feats, drop, *params):
+        rt = mod._handle(feats[0].device, params)
+        seed, p = drop
+        if p > 0.0:
+            rt.off_units_train(feats, seed, p)
+        else:
+            rt.off_units(feats)
+        ctx.mod, ctx.feats, ctx.drop = mod, feats, drop
+        P = rt.P
+        # copies: the workspace is rewritten by the next forward, autograd consumers may outlive it
+        outs = []
+        for name, H, C, width in (("fusion_28", 28, 320, 320), ("fusion_14", 14, 1056, 800), ("fusion_7", 7, 832, 320)):
+            buf = rt.region(name, C).view(P, H, H, C)[..., :width].contiguous()
+            outs.append(buf.permute(0, 3, 1, 2))       # NCHW view of channels-last memory
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g28, g14, g7):
+        mod, feats, (seed, p) = ctx.mod, ctx.feats, ctx.drop
+        rt = mod._rt
+        bufs = [g.permute(0, 2, 3, 1).contiguous() for g in (g28, g14, g7)]      # channels-last rows
+        views = [(bufs[0], 0), (bufs[0], 160)] + [(bufs[1], 160 * k) for k in range(5)] + [(bufs[2], 0), (bufs[2], 160)]
+        _flat, grads = rt.off_units_backward(feats, views, seed, p)
+        return (None, None, None) + tuple(grads[k] for k in mod.param_keys)
+
+
+class OFFUnits(nn.Module):
+    """The nine OFF units as a trainable module on liboffk: parameters under the
+    reference's state_dict keys (``motion_conv_gen_*``, ``motion_spatial_down_*``, ``motion_spatial_grad_*``;
+    the Sobel weight of the Flow variant is frozen, util.py:72), forward = K1 + K2 (in ``train()`` mode with
+    nn.Dropout(p=0.8) on the spatial gradients, RGB_OFF.py:356/:612, reproducible from ``drop_seed``), backward
+    = offk_off_units_backward.  Returns the three motion maps the fusion stages start from
+    (cat(motion_3a, motion_3b) [P,320,28,28], cat(motion_3c..4d) [P,800,14,14], cat(motion_5a, motion_5b)
+    [P,320,7,7]; RGB_OFF.py:656, :760, :832), channels-last in memory.  The reference's fusion convolutions
+    and heads stay ordinary PyTorch modules in training."""
+
+    def __init__(self, batch=16, length=7, variant="rgb", slice_mode=spec.SLICE_FLAT, precision="fp32", drop_p=0.8):
+        super().__init__()
+        if variant not in _VARIANTS:
+            raise ValueError("variant must be one of %s" % sorted(_VARIANTS))
+        self.variant = _VARIANTS[variant]
+        self.batch, self.length, self.slice_mode, self.precision, self.drop_p = batch, length, slice_mode, precision, float(drop_p)
+        for name, C, _H in spec.SITES:
+            setattr(self, "motion_conv_gen_" + name, nn.Conv2d(C, spec.GEN_CH, 1, 1))
+            setattr(self, "motion_spatial_down_" + name, nn.Conv2d(C, spec.DOWN_CH, 1, 1))
+            if self.variant == spec.VARIANT_RGB:
+                setattr(self, "motion_spatial_grad_" + name,
+                        nn.Conv2d(spec.DOWN_CH, spec.DOWN_CH, 3, 1, 1, groups=spec.DOWN_CH, bias=True))
+        if self.variant == spec.VARIANT_FLOW:
+            self.sobel_edge_diagonal = _SobelHolder()
+        self.param_keys = [k for k in spec.weight_shapes(self.variant) if k.startswith(spec.UNIT_PARAM_PREFIXES)]
+        self._rt, self._versions, self.drop_seed = None, {}, 0
+
+    def _param(self, key):
+        mod, attr = key.rsplit(".", 1)
+        return getattr(getattr(self, mod), attr)
+
+    def _handle(self, device, params):
+        if self._rt is None or self._rt.device != torch.device(device):
+            self._rt = runtime.OffForward(self.batch, self.length, self.variant, self.slice_mode, False,
+                                          device=device, precision=self.precision, training=True)
+            self._versions = {}
+            if self.variant == spec.VARIANT_FLOW:
+                self._rt.set_weight(spec.SOBEL_KEY, self.sobel_edge_diagonal.conv.weight)
+        for key, prm in zip(self.param_keys, params):   # push what an optimizer step (or a load) changed
+            tag = (prm.data_ptr(), prm._version)
+            if self._versions.get(key) != tag:
+                self._rt.set_weight(key, prm)
+                self._versions[key] = tag
+        return self._rt
+
+    def forward(self, feats, drop_seed=None):
+        feats = tuple(f.contiguous() for f in feats)
+        if not feats[0].is_cuda:
+            raise runtime._lib.OffkError("OFFUnits has no CPU path: feature maps must live on an MI355X")
+        if self.training and self.drop_p > 0.0:
+            if drop_seed is None:
+                self.drop_seed += 1
+                drop_seed = self.drop_seed
+            drop = (int(drop_seed), self.drop_p)
+        else:
+            drop = (0, 0.0)
+        return _OFFUnitsFn.apply(self, feats, drop, *[self._param(k) for k in self.param_keys])
+
+
 class BNInception_OFF(nn.Module):
     """Drop-in for the reference class of the same name, OFF part on liboffk.
 

@@ -213,3 +213,66 @@ def test_backward_argument_checks(rt):
     feats = [dev(f) for f in synth.make_features(2, 3, 2)]
     with pytest.raises(_lib.OffkError, match="dropout probability"):
         ht.off_units_train(feats, 1, 1.0)
+
+
+@pytest.mark.parametrize("variant", ["rgb", "flow"])
+def test_off_units_module_autograd(rt, variant):
+    """OFFUnits (the trainable host-side mirror): loss.backward() through torch's own fusion stages fills
+    param.grad of every unit parameter with what the oracle's graph gives, and an optimizer step is picked up
+    by the next forward."""
+    from offk_amd.off_module import OFFUnits
+    B, L = 2, 3
+    P = B * (L - 1)
+    v = spec.VARIANT_RGB if variant == "rgb" else spec.VARIANT_FLOW
+    wnp = synth.make_weights(v)
+    w = orc.to_torch_weights(wnp)
+    units = OFFUnits(B, L, variant).cuda()
+    units.load_state_dict({k: torch.from_numpy(a) for k, a in wnp.items() if k in units.state_dict()}, strict=True)
+    units.train()
+    feats_np = synth.make_features(B, L, 2)
+    feats = [dev(f) for f in feats_np]
+    wg = {k: t.cuda() for k, t in w.items()}
+    m28, m14, m7 = units(feats, drop_seed=7)
+    for m in (m28, m14, m7):
+        m.retain_grad()
+    assert m28.shape == (P, 320, 28, 28) and m14.shape == (P, 800, 14, 14) and m7.shape == (P, 320, 7, 7)
+    # the reference's fusion stages and heads as ordinary torch ops on the GPU (the oracle's functions are plain torch)
+    s28 = orc.fusion_28(m28, wg)
+    s14 = orc.fusion_14(torch.cat((m14, s28), 1), wg)
+    s7 = orc.fusion_7(torch.cat((m7, s14), 1), wg)
+    cot = [c.cuda() for c in cotangents(P)]
+    loss = (orc.head(s7, wg, "fc_action_motion", False) * cot[0]).sum() + (orc.head(s14, wg, "fc_action_motion_14", False) * cot[1]).sum() \
+        + (orc.head(s28, wg, "fc_action_motion_28", True) * cot[2]).sum()
+    loss.backward()
+    tf = [torch.from_numpy(f) for f in feats_np]
+    drops = unit_drop(7, P)
+    # the gradient that reached the units came through torch's GPU convolutions (MIOpen; its own ReLU kinks):
+    # compare the units' part on that same dM, and the whole chain against the oracle's CPU graph more loosely
+    dm = [g.detach().cpu() for g in (m28.grad[:, :160], m28.grad[:, 160:])] + \
+         [m14.grad[:, 160 * k:160 * k + 160].detach().cpu() for k in range(5)] + \
+         [g.detach().cpu() for g in (m7.grad[:, :160], m7.grad[:, 160:])]
+    masks = device_relu_masks(units._rt, tf, w, B, L)
+    ref = orc.unit_param_grads_from_dm(tf, w, B, L, v, orc.SLICE_FLAT, dm, drops, masks)
+    whole, _dm = orc.unit_backward(tf, w, B, L, v, orc.SLICE_FLAT, cotangents(P), drops, masks)
+    n = 0
+    for k, prm in units.named_parameters():
+        if k == spec.SOBEL_KEY:
+            assert prm.grad is None
+            continue
+        assert rel_err(prm.grad, ref[k]) < RTOL, k
+        assert rel_err(prm.grad, whole[k]) < 1e-2, k
+        n += 1
+    assert n == len(ref)
+    # an SGD step changes the parameters in place; the next forward must run with the new values
+    before = m7.detach().clone()
+    with torch.no_grad():
+        for prm in units.parameters():
+            if prm.grad is not None:
+                prm -= 10.0 * prm.grad
+    units.eval()
+    m28b, m14b, m7b = units(feats)
+    w2 = dict(w)
+    w2.update((k, prm.detach().cpu()) for k, prm in units.named_parameters())
+    with torch.no_grad():
+        want = orc.off_unit(tf[8], w2, "5b", B, L, v, orc.SLICE_FLAT)
+    assert rel_err(m7b[:, 160:], want) < RTOL and not torch.equal(before, m7b)
