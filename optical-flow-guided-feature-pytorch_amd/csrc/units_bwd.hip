@@ -280,9 +280,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
   const bool vec = (HW & 3) == 0;
 
   // B loader: rows (tid>>3) + 32r of the slab, k quad tid&7; the four 32-channel groups may sit in different parts
-  const float* xrow[4];
-  size_t xfs[4];      // frame stride of the part
+  const float* xrow[4];   // block-uniform (SGPRs): first row of the 32-channel group inside its part
+  int xfs[4];             // frame stride of the part, in floats
   bool xok[4];
+  const int rowoff = (tid >> 3) * HW;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int cb = nt * WG_BN + 32 * r;
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
       }
     }
     xok[r] = cb < C;
-    xrow[r] = xb + (size_t)(kl + (tid >> 3)) * HW;
-    xfs[r] = (size_t)cpart * HW;
+    xrow[r] = xb + (size_t)kl * HW;
+    xfs[r] = cpart * HW;
   }
   const bool wave_on = nt * WG_BN + 32 * wave < C;
 
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
     const int k = kin + 4 * (tid & 7), kk = min(k, HW - 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float* q = (xok[r] && k < HW && !(p.dbg & 1)) ? xrow[r] + (size_t)frame * xfs[r] + kk : p.zeros;
+      const float* q = (xok[r] && k < HW && !(p.dbg & 1)) ? xrow[r] + (size_t)frame * xfs[r] + (rowoff + kk) : p.zeros;
       const f4u v = *reinterpret_cast<const f4u*>(q);
       rg[5 + r] = make_float4(v.x, v.y, v.z, v.w);
     }
@@ -404,17 +405,13 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
         const int off = r32 * B3_ROW + (16 * s2 + 8 * h) * 2;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + wave * 32 * B3_ROW + off);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + wave * 32 * B3_ROW + off);
-        bf16x8 ah[5], al[5];
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-          ah[t] = *reinterpret_cast<const bf16x8*>(Ahi + t * 32 * B3_ROW + off);
-          al[t] = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + t * 32 * B3_ROW + off);
-        }
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[t], 0, 0, 0);
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + t * 32 * B3_ROW + off);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + t * 32 * B3_ROW + off);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
         }
       }
     } else if (wave_on) {
