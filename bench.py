@@ -91,6 +91,37 @@ def measured_traffic(batch, length, variant):
     return None
 
 
+def units_training(_unused, B, L, variant, weights, feats, dev, precision, iters=10):
+    """Secondary figure: train-mode forward of the nine units (dropout 0.8) and their
+    backward (dM -> parameter gradients) at the bench size; random dM, same synthetic maps."""
+    P = B * (L - 1)
+    ht = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, False, device=dev, precision=precision, training=True)
+    ht.load_state_dict(weights)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    bufs = [torch.randn(P, H, H, C, device=dev, generator=gen) for H, C in ((28, 320), (14, 1056), (7, 832))]
+    views = [(bufs[0], 0), (bufs[0], 160)] + [(bufs[1], 160 * k) for k in range(5)] + [(bufs[2], 0), (bufs[2], 160)]
+    grads = ht.new_unit_grads()
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    fwd = timed(lambda: ht.off_units_train(feats, 21, 0.8))
+    bwd = timed(lambda: ht.off_units_backward(feats, views, 21, 0.8, grads=grads))
+    hw = sum(H * H for _n, _c, H in spec.SITES)
+    k2b = B * hw * 4 * ((160 + 32 + 32) * (L - 1) + 256 * L)
+    k1b = sum(B * L * C * H * H * 4 for _n, C, H in spec.SITES) + B * hw * 4 * (128 * L + 32 * (L - 1))
+    return {"train_forward_ms": fwd, "backward_ms": bwd, "clips_per_s_forward_plus_backward": B / (fwd + bwd) * 1e3,
+            "backward_algorithmic_bytes": k2b + k1b, "backward_hbm_floor_ms_at_8TBs": (k2b + k1b) / 8e12 * 1e3,
+            "note": "units only (K1+K2 train mode; K2b + weight-gradient GEMM + reductions); fusion stages / heads train on the caller's autograd"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +247,9 @@ def main():
             d32 = time.perf_counter() - t1
             res["fp32_mode"] = {"value": B * n32 / d32, "unit": "clips/s", "ms_per_step": d32 / n32 * 1e3, "steps": n32,
                                 "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        if world == 1:
+            res["units_training"] = units_training(None, B, L, variant, weights, feats, dev,
+                                                   args.precision)
         if world == 1 and args.cpu_clips > 0:
             res["cpu_baseline"] = cpu_baseline(feats_np, weights, L, variant, min(args.cpu_clips, B))
             res["gpu_over_cpu"] = clips_s / res["cpu_baseline"]["value"]
