@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboffk.so")
+LIB_PATH = os.environ.get("OFFK_LIB") or os.path.join(HERE, "liboffk.so")   # OFFK_LIB: A/B builds in tools
 NUM_SITES = 9
 NUM_STAGES = 6
 STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7", "heads")

@@ -334,6 +334,7 @@ int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo, cons
   memset(&sp, 0, sizeof(sp));
   sp.nsites = kNumSites; sp.B = h->cfg.batch; sp.L = h->cfg.length;
   sp.drop_thresh = drop.thresh; sp.drop_scale = drop.scale;
+  sp.zeros = h->zero_page;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   const char* tg = getenv("OFFK_K2_TGROUP");
   const bool tgrouped = tg ? (*tg != '0') : false;  // tuning knob: T-blocks walk all sites of a fusion buffer (measured slower: profiles/r01/k2_ab.txt)
@@ -730,6 +731,7 @@ int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, con
   StParams sp;
   memset(&sp, 0, sizeof(sp));
   sp.nsites = 1; sp.B = h->cfg.batch; sp.L = h->cfg.length;
+  sp.zeros = h->zero_page; sp.drop_scale = 1.f;
   fill_st_site(h, site, G, D, M, m_cstride, m_coff, &sp.s[0]);
   sp.total_s = h->P * sp.s[0].strips;
   sp.total_t = h->cfg.batch * sp.s[0].tchunks;
@@ -936,7 +938,7 @@ int offk_off_units_backward(offk_handle* h, void* stream, const float* const fea
   UbParams up;
   memset(&up, 0, sizeof(up));
   up.nsites = kNumSites; up.B = h->cfg.batch; up.L = h->cfg.length; up.tpix = kUbTpix;
-  up.drop_thresh = drop.thresh; up.drop_scale = drop.scale;
+  up.drop_thresh = drop.thresh; up.drop_scale = drop.scale; up.zeros = h->zero_page;
   int sblk = 0, tblk = 0;
   int nsblocks[kNumSites];
   for (int s = 0; s < kNumSites; ++s) {

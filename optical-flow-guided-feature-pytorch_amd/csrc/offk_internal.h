@@ -78,6 +78,7 @@ struct StParams {
   int B, L, tpix;         // tpix = pixels per T-block
   unsigned drop_thresh;   // training: 16-bit keep threshold of nn.Dropout(p) on the spatial branch, 0 = eval (identity)
   float drop_scale;       // 1 / (1 - p)
+  const float* zeros;     // >= 16 bytes of zeros in device memory: what a halo / masked-out load reads
 };
 void st_plan(int H, int* strips, int* rows);
 int st_tchunks(int H);
@@ -102,6 +103,7 @@ struct UbParams {
   int nsites, total_s, total_t, B, L, tpix;
   unsigned drop_thresh;
   float drop_scale;
+  const float* zeros;   // device zero page for halo / masked-out loads
 };
 hipError_t units_bwd_launch(const UbParams& p, hipStream_t st);
 

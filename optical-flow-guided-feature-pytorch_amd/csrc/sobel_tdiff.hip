@@ -182,20 +182,29 @@ __global__ __launch_bounds__(ST_THREADS) void sobel_tdiff_kernel(StParams p) {
   const int TW = W + 2, nstage = (R + 2) * TW;
   float* wl = tile + (S.rows + 2) * TW * kDownCh;   // tap weights [9][32] + bias [32] behind the tile
   const float* d = S.D + (size_t)pr * HW * kDownCh;
-  // stage rows y0-1 .. y0+R with the zero halo: this thread's tile pixels are (tid>>3) + 32*j,
-  // all of its loads are issued before the first LDS write
+  // stage rows y0-1 .. y0+R with the zero halo: this thread's tile pixels are (tid>>3) + 32*j.  Every load of
+  // the block (tap weights first) is issued before the first wait: halo / out-of-tile pieces read the handle's
+  // zero page through a selected pointer -- with `if (inside) v = load` the compiler waited for the first loads
+  // before issuing the rest and fetched the weights only after the tile had arrived (three latencies per block)
+  float wreg[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = tid + ST_THREADS * r;
+    const float* wsrc = i < 9 * kDownCh ? S.dw + i : ((S.db && i < 10 * kDownCh) ? S.db + (i - 9 * kDownCh) : p.zeros);
+    wreg[r] = *wsrc;
+  }
   float4 st[ST_STAGE_MAX];
 #pragma unroll
   for (int j = 0; j < ST_STAGE_MAX; ++j) {
     const int tp = (tid >> 3) + 32 * j;
     const int ty = tp / TW, tx = tp - ty * TW;
     const int y = y0 - 1 + ty, x = tx - 1;
-    st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-      st[j] = ldg4<NTL>(d + (size_t)(y * W + x) * kDownCh + cq4);
+    const bool inside = tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    st[j] = ldg4<NTL>(inside ? d + (size_t)(y * W + x) * kDownCh + cq4 : p.zeros);
   }
-  for (int i = tid; i < 10 * kDownCh; i += ST_THREADS)
-    wl[i] = i < 9 * kDownCh ? S.dw[i] : (S.db ? S.db[i - 9 * kDownCh] : 0.f);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (tid + ST_THREADS * r < 10 * kDownCh) wl[tid + ST_THREADS * r] = wreg[r];
 #pragma unroll
   for (int j = 0; j < ST_STAGE_MAX; ++j) {
     const int tp = (tid >> 3) + 32 * j;

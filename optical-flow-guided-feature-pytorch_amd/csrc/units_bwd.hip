@@ -46,7 +46,7 @@ __device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
 // =====================================================================================================
 // K2b
 // =====================================================================================================
-__global__ __launch_bounds__(UB_THREADS) void units_bwd_kernel(UbParams p) {
+__global__ __launch_bounds__(UB_THREADS, 2) void units_bwd_kernel(UbParams p) {   // two LDS tiles: 2 blocks per CU anyway
   extern __shared__ __attribute__((aligned(16))) float tile[];   // dS tile | D tile | taps [9][32] | wave partials [4][10][32]
 
   const unsigned bid = blockIdx.x, total = (unsigned)(p.total_s + p.total_t);
@@ -86,10 +86,9 @@ __global__ __launch_bounds__(UB_THREADS) void units_bwd_kernel(UbParams p) {
       for (int t0 = 0; t0 < L; t0 += UB_TGROUP) {
         float4 gv[UB_TGROUP], dt[UB_TGROUP];
 #pragma unroll
-        for (int j = 0; j < UB_TGROUP; ++j) {
-          gv[j] = zero4(); dt[j] = zero4();
-          if (t0 + j < L) gv[j] = *reinterpret_cast<const float4*>(g + (size_t)(t0 + j) * gstride);
-          if (t0 + j < T) dt[j] = *reinterpret_cast<const float4*>(m + (size_t)(t0 + j) * mstride);
+        for (int j = 0; j < UB_TGROUP; ++j) {   // branch-free (see the S-blocks): frames past the clip read the zero page
+          gv[j] = *reinterpret_cast<const float4*>(t0 + j < L ? g + (size_t)(t0 + j) * gstride : p.zeros);
+          dt[j] = *reinterpret_cast<const float4*>(t0 + j < T ? m + (size_t)(t0 + j) * mstride : p.zeros);
         }
 #pragma unroll
         for (int j = 0; j < UB_TGROUP; ++j)
@@ -121,26 +120,39 @@ __global__ __launch_bounds__(UB_THREADS) void units_bwd_kernel(UbParams p) {
   float* wp = wl + 9 * kDownCh;           // wave partials [4][10][32]
   const float* gm = S.gm + (size_t)pr * HW * S.gm_cs + S.gm_coff + cq4;
   const float* d = S.D + (size_t)pr * HW * kDownCh + cq4;
-  float4 sg[UB_STAGE_MAX], sd[UB_STAGE_MAX];
+  // every load of the block in flight before the first wait (branch-free: halo pieces read the zero page)
+  float wreg[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = tid + UB_THREADS * r;
+    wreg[r] = *(i < 9 * kDownCh ? S.dw + i : p.zeros);
+  }
+  float4 sgd[2 * UB_STAGE_MAX];   // dS pieces, then D pieces (one array: two arrays end up in scratch)
+  float4* const sg = sgd;
+  float4* const sd = sgd + UB_STAGE_MAX;
 #pragma unroll
   for (int j = 0; j < UB_STAGE_MAX; ++j) {
     const int tp = (tid >> 3) + 32 * j;
     const int ty = tp / TW, tx = tp - ty * TW;
     const int y = y0 - 1 + ty, x = tx - 1;
-    sg[j] = zero4(); sd[j] = zero4();
-    if (tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-      const int px = y * W + x;
-      sg[j] = *reinterpret_cast<const float4*>(gm + (size_t)px * S.gm_cs);
-      if (wgrad) sd[j] = *reinterpret_cast<const float4*>(d + (size_t)px * kDownCh);
-      if (p.drop_thresh)
-        sg[j] = mul4(sg[j], drop_mul(S.drop_base, ((unsigned long long)pr * HW + px) * 8 + cq, p.drop_thresh, p.drop_scale));
-    }
+    const bool inside = tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const int px = y * W + x;
+    sg[j] = *reinterpret_cast<const float4*>(inside ? gm + (size_t)px * S.gm_cs : p.zeros);
+    sd[j] = *reinterpret_cast<const float4*>((inside && wgrad) ? d + (size_t)px * kDownCh : p.zeros);
   }
-  for (int i = tid; i < 9 * kDownCh; i += UB_THREADS) wl[i] = S.dw[i];
+  __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking the D loads behind the first LDS stores
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (tid + UB_THREADS * r < 9 * kDownCh) wl[tid + UB_THREADS * r] = wreg[r];
 #pragma unroll
   for (int j = 0; j < UB_STAGE_MAX; ++j) {
     const int tp = (tid >> 3) + 32 * j;
     if (tp < nstage) {
+      if (p.drop_thresh) {
+        const int ty = tp / TW, tx = tp - ty * TW;
+        const int px = (y0 - 1 + ty) * W + (tx - 1);     // halo pieces are zero whatever the multiplier
+        sg[j] = mul4(sg[j], drop_mul(S.drop_base, ((unsigned long long)pr * HW + (unsigned)px) * 8 + cq, p.drop_thresh, p.drop_scale));
+      }
       *reinterpret_cast<float4*>(tg + tp * kDownCh + cq4) = sg[j];
       if (wgrad) *reinterpret_cast<float4*>(td + tp * kDownCh + cq4) = sd[j];
     }
