@@ -104,20 +104,23 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvA
   // prefetch registers: A rows then B rows (one array per set: separate A / B arrays end up in scratch).
   // rg0 is the only set of the fp32 path; the bf16x3 producers alternate rg0 / rg1 (loads two tiles ahead).
   float4 rg0[NRG], rg1[PREC == 0 ? 1 : NRG];
-  auto load_tile = [&](float4 (&rg)[NRG], int kt) {
+  unsigned okm0 = 0, okm1 = 0;   // bit r: activation row r of the set is inside the image (else it reads as zero)
+  // Loads are branch-free and nothing touches the loaded values here: a padding tap reads pixel 0 through a
+  // selected pointer and is zeroed by store_tile, ReLU-on-load is applied there as well.  With
+  // `t = 0; if (ok) t = load; rg = relu_in ? relu(t) : t` every load was followed by s_waitcnt vmcnt(0): the
+  // row visits of a tile went out one memory latency after the other.
+  auto load_tile = [&](float4 (&rg)[NRG], unsigned& okm, int kt) {
     int chunk = kt / TAPS, tap = kt - chunk * TAPS, c0 = chunk * BK;
     int kh = tap / KW, kw = tap - kh * KW;
+    unsigned mask = 0;
 #pragma unroll
     for (int r = 0; r < NRA; ++r) {
       int hi = hi0[r] + kh, wi = wi0[r] + kw;
       bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-#pragma unroll
-      for (int v = 0; v < VA; ++v) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) t = *reinterpret_cast<const float4*>(xbase + (size_t)(pix0[r] + hi * p.W + wi) * p.x_cs + c0 + 4 * v);
-        rg[r * VA + v] = relu_in ? relu4(t) : t;
-      }
+      mask |= ok ? (1u << r) : 0u;
+      rg[r] = *reinterpret_cast<const float4*>(ok ? xbase + (size_t)(pix0[r] + hi * p.W + wi) * p.x_cs + c0 : xbase);
     }
+    okm = mask;
 #pragma unroll
     for (int r = 0; r < NRB; ++r)
       rg[NRA * VA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
@@ -129,12 +132,17 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvA
   constexpr int B3R = 64;
   constexpr int A_PLANE = BM * B3R, B_PLANE = BN * B3R, B3_STAGE = 2 * (A_PLANE + B_PLANE);
   char* smem_c = reinterpret_cast<char*>(smem);
-  auto store_tile = [&](const float4 (&rg)[NRG], int stage) {
+  auto a_value = [&](const float4 (&rg)[NRG], unsigned okm, int r) {
+    float4 t = rg[r];
+    if (!((okm >> r) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
+    return relu_in ? relu4(t) : t;
+  };
+  auto store_tile = [&](const float4 (&rg)[NRG], unsigned okm, int stage) {
     if (PREC == 0) {
       float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
       for (int r = 0; r < NRA; ++r)
-        *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[r];
+        *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = a_value(rg, okm, r);
       float* Bs = Bs0 + stage * BN * LDS_K;
 #pragma unroll
       for (int r = 0; r < NRB; ++r)
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvA
       for (int r = 0; r < NRA; ++r) {
         const int row = (tid >> 3) + 32 * r;
         uint2 h, l;
-        split4(rg[r], h, l);
+        split4(a_value(rg, okm, r), h, l);
         char* q = st + row * B3R + ((((c8 >> 1) ^ ((row >> 2) & 3)) << 4) | ((c8 & 1) << 3));
         *reinterpret_cast<uint2*>(q) = h;
         *reinterpret_cast<uint2*>(q + A_PLANE) = l;
@@ -192,32 +200,32 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvA
   WaveAcc<TM, TN> acc;
   acc.zero();
   if constexpr (PREC == 0) {
-    load_tile(rg0, kt_begin);
-    store_tile(rg0, 0);
+    load_tile(rg0, okm0, kt_begin);
+    store_tile(rg0, okm0, 0);
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int st = (kt - kt_begin) & 1;
-      if (kt + 1 < kt_end) load_tile(rg0, kt + 1);
+      if (kt + 1 < kt_end) load_tile(rg0, okm0, kt + 1);
       acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
                     Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
-      if (kt + 1 < kt_end) store_tile(rg0, st ^ 1);
+      if (kt + 1 < kt_end) store_tile(rg0, okm0, st ^ 1);
       __syncthreads();
     }
   } else {
     if (wave >= 4) {
       // ---- producers: tile t is stored one step before it is consumed and loaded two steps before that
-      load_tile(rg0, kt_begin);
-      store_tile(rg0, 0);
-      if (kt_begin + 1 < kt_end) load_tile(rg0, kt_begin + 1);
-      if (kt_begin + 2 < kt_end) load_tile(rg1, kt_begin + 2);
+      load_tile(rg0, okm0, kt_begin);
+      store_tile(rg0, okm0, 0);
+      if (kt_begin + 1 < kt_end) load_tile(rg0, okm0, kt_begin + 1);
+      if (kt_begin + 2 < kt_end) load_tile(rg1, okm1, kt_begin + 2);
       __syncthreads();
       int kt = kt_begin;
       for (; kt + 1 < kt_end; kt += 2) {
-        store_tile(rg0, 1);                                    // tile kt+1 while tile kt is multiplied
-        if (kt + 3 < kt_end) load_tile(rg0, kt + 3);
+        store_tile(rg0, okm0, 1);                              // tile kt+1 while tile kt is multiplied
+        if (kt + 3 < kt_end) load_tile(rg0, okm0, kt + 3);
         __syncthreads();
-        if (kt + 2 < kt_end) store_tile(rg1, 0);      // tile kt+2 while tile kt+1 is multiplied
-        if (kt + 4 < kt_end) load_tile(rg1, kt + 4);
+        if (kt + 2 < kt_end) store_tile(rg1, okm1, 0);         // tile kt+2 while tile kt+1 is multiplied
+        if (kt + 4 < kt_end) load_tile(rg1, okm1, kt + 4);
         __syncthreads();
       }
       if (kt < kt_end) __syncthreads();
@@ -253,16 +261,36 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvA
     const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      // the 16 residual values of this accumulator tile first, branch-free (a load per element in front of its
+      // use costs one L2 latency per element: the compiler waits after each)
+      float rv[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
+      if (p.res) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = m0 + wm * 32 * TM + tm * 32 + acc_row(reg, h);
+          const bool ok = m < p.M && co < p.co_limit;
+          rv[reg] = *(ok ? p.res + (size_t)m * p.res_cs + p.res_coff + co : p.res);
+        }
+      }
+      // values first, in straight-line code (one wait for the residuals), conditional stores afterwards: a loaded
+      // value used inside the `if (row in range)` blocks makes every block start with s_waitcnt vmcnt(0), which
+      // also waits for the previous block's store
+      float ov[16];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        int m = m0 + wm * 32 * TM + tm * 32 + acc_row(reg, h);
-        if (m < p.M && co < p.co_limit) {
-          float v = acc.acc[tm][tn][reg] + bv;
-          if (relu_pre) v = fmaxf(v, 0.f);
-          if (p.res) v += p.res[(size_t)m * p.res_cs + p.res_coff + co];
-          if (relu_post) v = fmaxf(v, 0.f);
-          p.y[(size_t)m * p.y_cs + p.y_coff + co] = v;
-        }
+        float v = acc.acc[tm][tn][reg] + bv;
+        if (relu_pre) v = fmaxf(v, 0.f);
+        v += rv[reg];
+        if (relu_post) v = fmaxf(v, 0.f);
+        asm volatile("" : "+v"(v));   // keep the arithmetic out of the conditional blocks below
+        ov[reg] = v;
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 32 * TM + tm * 32 + acc_row(reg, h);
+        if (m < p.M && co < p.co_limit) p.y[(size_t)m * p.y_cs + p.y_coff + co] = ov[reg];
       }
     }
   }
