@@ -353,3 +353,29 @@ def test_forward_from_inception_branch_parts(rt, prec):
     bad[0] = [dev(np.ascontiguousarray(feats[0][:, :48])), dev(np.ascontiguousarray(feats[0][:, 48:]))]
     with pytest.raises(_lib.OffkError, match="multiples of 32"):
         h.forward(bad)
+
+
+def test_forward_is_stream_capturable(rt):
+    """include/offk.h: offk_forward (side-stream fork/join included) can be captured into a HIP graph;
+    replaying the graph reproduces the eager bits."""
+    B, L = 2, 3
+    h, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    arr = h._feat_array(feats)
+    out = [torch.empty(h.out_rows(), spec.NUM_CLASSES, device="cuda") for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):           # warm-up off the default stream (weight packing, function attributes)
+        h.forward_into(arr, *out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref = [o.clone() for o in out]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        h.forward_into(arr, *out)
+    for _ in range(3):
+        for o in out:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))

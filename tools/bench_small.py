@@ -27,4 +27,34 @@ for B, L in ((1, 7), (4, 7), (10, 25)):
             h.forward_into(arr, *out)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print("B=%2d L=%2d %-7s %8.3f ms/forward  %9.1f clips/s" % (B, L, prec, dt * 1e3, B / dt), flush=True)
+        # the same forward captured once into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed:
+        # ~32 launches + the side-stream fork/join become one graph launch
+        gdt = float("nan")
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                h.forward_into(arr, *out)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ref = [o.clone() for o in out]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                h.forward_into(arr, *out)
+            for o in out:
+                o.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            same = all(torch.equal(a, b) for a, b in zip(ref, out))
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                g.replay()
+            torch.cuda.synchronize()
+            gdt = (time.perf_counter() - t0) / n
+        except Exception as e:   # noqa: BLE001
+            same = "capture failed: %s" % str(e)[:80]
+        print("B=%2d L=%2d %-7s %8.3f ms/forward  %9.1f clips/s   | hipGraph replay %8.3f ms (bit-identical: %s)"
+              % (B, L, prec, dt * 1e3, B / dt, gdt * 1e3, same), flush=True)
