@@ -251,17 +251,31 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   float bv[PW_TN];
 #pragma unroll
   for (int t = 0; t < PW_TN; ++t) bv[t] = S.bias[t * 32 + r32];
+  // bias / ReLU in straight-line code first: a loaded value (the bias) used inside the `if (row in range)` blocks
+  // makes every block start with an s_waitcnt that also throttles the stores of the blocks before it
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = fmaxf(acc[t][reg] + bv[t], 0.f);
+      asm volatile("" : "+v"(v));
+      acc[t][reg] = v;
+    }
+    float d = acc[4][reg] + bv[4];
+    asm volatile("" : "+v"(d));
+    acc[4][reg] = d;
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int m = m0 + wave * 32 + acc_row(reg, h);
     if (m < M) {
       float* g = S.G + (size_t)m * kGenCh + r32;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) g[t * 32] = fmaxf(acc[t][reg] + bv[t], 0.f);
+      for (int t = 0; t < 4; ++t) g[t * 32] = acc[t][reg];
       if (down_active) {
         int f = m / HW, pix = m - f * HW;
         int dr = down_row(f, p.L, p.P, p.slice_mode);
-        if (dr >= 0) S.D[((size_t)dr * HW + pix) * kDownCh + r32] = acc[4][reg] + bv[4];
+        if (dr >= 0) S.D[((size_t)dr * HW + pix) * kDownCh + r32] = acc[4][reg];
       }
     }
   }
