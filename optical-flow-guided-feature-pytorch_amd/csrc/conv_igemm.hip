@@ -47,7 +47,9 @@ struct ConvArgs {
 // them (measured before the split: 39 % matrix-pipe busy with 20 % VALU and 26 % LDS time serialised
 // in the same waves).  One s_barrier per K-tile hands a filled LDS stage over.
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
-__global__ __launch_bounds__(PREC == 0 ? 256 : 512) void conv_igemm_kernel(ConvArgs p) {
+// second launch-bound = waves per SIMD (HIP), 4 = two 8-wave blocks per CU: keeps the bf16x3 tiles within 128 VGPRs
+// (the 128x128 tile compiled to 131 and ran one block per CU)
+__global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;                         // fp32: [2][BM][LDS_K]

@@ -56,11 +56,11 @@ const int kTunedP384[kNumConvs][2] = {
     {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
-    {1, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
-    {4, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {4, 1},                           // fusion @14
-    {5, 3}, {4, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
-// (the @14 / @7 rows were re-tuned inside the whole forward with tools/tune_forward.py after the loader became
-// branch-free: 64x128 tiles replaced 128x128 for the 5x5 and the 3x3 256->256)
+    {1, 6}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},   // fusion @28
+    {0, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {4, 1},                           // fusion @14
+    {5, 3}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+// (re-tuned inside the whole forward with tools/tune_forward.py after the bf16x3 kernels were bounded to 128
+// VGPRs: the 128x128 tile now runs two blocks per CU and wins the 5x5 back from 64x128)
 // (main 1x1, branch 1x1) pairs whose outputs are summed: RGB_OFF.py:663-666, :768-770, :839-841
 struct MergedSpec { const char* name; int main_id, branch_id; };
 const MergedSpec kMerged[3] = {{"merged_28a", C3_28A, CB_28A}, {"merged_14a", C3_14A, CE_14A}, {"merged_7", C3_7, CB_7}};

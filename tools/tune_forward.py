@@ -16,10 +16,10 @@ from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
     "motion_conv_trans_28": [(1, 6), (1, 4), (1, 8), (3, 3), (3, 6), (0, 6), (4, 6)],
-    "motion_conv_trans_14": [(0, 6), (4, 6), (4, 12), (0, 12), (4, 8), (1, 6), (5, 6)],
-    "motion_conv_trans": [(5, 3), (4, 3), (5, 6), (0, 6), (0, 3), (4, 6)],
-    "motion_conv3_trans_14b": [(4, 1), (1, 1), (3, 1), (0, 1), (4, 2)],
-    "motion_conv2_trans": [(0, 3), (4, 3), (5, 3), (4, 2), (3, 1), (1, 2)],
+    "motion_conv_trans_14": [(0, 3), (0, 6), (0, 4), (0, 12), (4, 6), (0, 2)],
+    "motion_conv_trans": [(5, 3), (0, 6), (0, 3), (0, 4), (4, 3)],
+    "motion_conv3_trans_14b": [(4, 1), (1, 1), (3, 1), (0, 1), (0, 2)],
+    "motion_conv2_trans": [(0, 3), (4, 3), (5, 3), (0, 4), (0, 2)],
     "motion_conv2_trans_14a": [(3, 1), (4, 1), (0, 1), (4, 3)],
     "motion_conv2_trans_14b": [(3, 1), (4, 1), (0, 1), (4, 3)],
     "motion_conv2_trans_28a": [(3, 1), (1, 1)],
