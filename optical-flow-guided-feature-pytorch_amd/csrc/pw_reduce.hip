@@ -114,14 +114,16 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   }
 
   // ---- loader setup -----------------------------------------------------------
-  // mode 0: NCHW, HW % 4 == 0 : thread = (pixel quad pq = tid&31, k quad kq = tid>>5)
+  // mode 0: NCHW, HW % 4 == 0 : thread = (k quad kq = tid&7, pixel quad pq = tid>>3): the lanes of a 16-lane LDS
+  //         store group cover the whole 32-k span of two rows (conflict-free); with pq on the low lane bits the
+  //         8-byte bf16 stores of a group fell into 4 bank positions (60 % of the LDS cycles were conflicts)
   // mode 1: NCHW, any HW      : thread = (pixel i = tid&127, k quads (tid>>7) + 2r)
   // mode 2: channels-last     : thread = (rows (tid>>3)+32r, k quad tid&7)
   const int mode = p.nhwc ? 2 : ((HW & 3) == 0 ? 0 : 1);
   int fr = 0, pix = 0;       // this thread's frame and pixel (modes 0 / 1)
   bool row_ok = true;
   if (mode == 0) {
-    int m = m0 + 4 * (tid & 31);
+    int m = m0 + 4 * (tid >> 3);
     row_ok = m < M;                       // M % 4 == 0 here, so the quad is all-in or all-out
     int mm = row_ok ? m : 0;
     fr = mm / HW; pix = mm - fr * HW;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     int mm = row_ok ? m : 0;
     fr = mm / HW; pix = mm - fr * HW;
   }
-  const int koff = mode == 0 ? 4 * (tid >> 5) : (mode == 1 ? 4 * (tid >> 7) : 4 * (tid & 7));
+  const int koff = mode == 0 ? 4 * (tid & 7) : (mode == 1 ? 4 * (tid >> 7) : 4 * (tid & 7));
   // channel k0 (a multiple of 32) -> (part, channel within the part); parts are whole multiples of 32
   // channels, so a K-tile never straddles two of them.  Uniform across the block: scalar selects.
   auto locate = [&](int k0, const float*& xb, int& cpart, int& kl) {
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   auto store_tile = [&]() {
     if (PREC == 1) {
       if (mode == 0) {
-        const int row = 4 * (tid & 31), kq = tid >> 5;
+        const int row = 4 * (tid >> 3), kq = tid & 7;
         b3_store(Ahi, A_PLANE, row, kq, make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x));
         b3_store(Ahi, A_PLANE, row + 1, kq, make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y));
         b3_store(Ahi, A_PLANE, row + 2, kq, make_float4(rg[0].z, rg[1].z, rg[2].z, rg[3].z));
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
       return;
     }
     if (mode == 0) {
-      float* dst = As + 4 * (tid & 31) * LDS_K + 4 * (tid >> 5);
+      float* dst = As + 4 * (tid >> 3) * LDS_K + 4 * (tid & 7);
       *reinterpret_cast<float4*>(dst) = make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x);
       *reinterpret_cast<float4*>(dst + LDS_K) = make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y);
       *reinterpret_cast<float4*>(dst + 2 * LDS_K) = make_float4(rg[0].z, rg[1].z, rg[2].z, rg[3].z);
