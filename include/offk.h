@@ -176,7 +176,10 @@ int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_i
                 const float* res, int res_cstride, int res_coff, int flags,
                 float* y, int y_cstride, int y_coff);
 /* Same with an explicit plan (tuning / micro-benchmarks): tile_cfg 0..5 = block tile 128x128,
- * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), < 0 = automatic; splitk >= 1
+ * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), 6 / 7 = the LDS-patch kernel (bf16x3, k x k
+ * convs whose 196-pixel output groups come from a 28x28 / four 14x14 / one 14x14 / four 7x7 input patch: 7x7s2@28,
+ * 5x5s2@14, 3x3s1@14, 3x3s1@7; 128 / 64 output channels per block; splitk then splits the channel chunks),
+ * < 0 = automatic; splitk >= 1
  * K-slices whose fp32 partial slabs [splitk][M][Co] go to `partial` (summed in slice order by
  * a second launch, so results are bit-reproducible); splitk < 1 = automatic; precision = enum
  * offk_precision. */

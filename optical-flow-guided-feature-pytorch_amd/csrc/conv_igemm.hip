@@ -321,6 +321,287 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Patch" variant of the bf16x3 kernel (tile_cfg 6: 128 output channels per block, 7: 64) for the k x k convs.
+// Every k x k conv of the fusion stages produces 196 output pixels per image (14x14) or per four images (7x7), from
+// 784 or 196 input pixels.  A block owns one such 196-pixel output group (seven 32-row MFMA tiles) and, per 32-channel
+// chunk, keeps the WHOLE input patch of the group in LDS (split into bf16 hi / lo once): the KH*KW taps then read
+// their A operand straight from that patch at shifted pixel slots, so an input value crosses L2 -> LDS once per chunk
+// instead of once per tap, and only the weight tile of the (chunk, tap) streams through the two-stage LDS ring.
+// Operand traffic per FLOP drops ~4x against the 128x128 im2col tile; the generic kernel was bound by exactly that
+// traffic (PMC: 45-55 % of the wave cycles waiting, the 7x7 conv fetching 3.4x its input from HBM because the
+// per-block windows of the resident blocks do not fit the XCD's L2).
+//   patch slot of input pixel (img, y, x) = img*W*W + y*W + xperm(x); for stride 2 xperm puts the even columns of a
+//   row first, so the 32 consecutive output pixels of an MFMA row tile read consecutive slots for every tap (the
+//   16-B chunk swizzle of the generic kernel then keeps the ds_read_b128 conflict-free); slot NP is a zero pixel
+//   that out-of-image taps read.
+// Waves 0-3 multiply (wave = one 32-column tile x all seven row tiles for 128 channels; column tile x alternate row
+// tiles for 64), waves 4-7 stream the weight tiles two steps ahead and hold the next chunk's patch in registers.
+// ---------------------------------------------------------------------------------------------------
+template <int KH, int S, int W, int NT>
+__global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
+  constexpr int KW = KH, TAPS = KH * KW, PAD = KH / 2, H = W, HW = H * W;
+  constexpr int WO = (W + 2 * PAD - KW) / S + 1, HOWO = WO * WO, IMG = 196 / HOWO, NP = IMG * HW;
+  static_assert(196 % HOWO == 0 && (S == 1 || (W % 2) == 0), "196-pixel output groups only");
+  constexpr int BN = 32 * NT, RT = NT == 4 ? 7 : 4, B3R = 64;
+  constexpr int PATCH_PLANE = ((NP + 1) * B3R + 127) / 128 * 128, B_PLANE = BN * B3R, B_STAGE = 2 * B_PLANE;
+  constexpr int NJ = (NP + 31) / 32;   // patch pixels per producer thread
+  extern __shared__ __attribute__((aligned(16))) char lds_c[];
+  char* const patch = lds_c;                        // hi plane, then lo plane
+  char* const bst = lds_c + 2 * PATCH_PLANE;         // two stages of (B_hi | B_lo)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x & 255;
+  int lid;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = lid % p.gn, mt = (lid / p.gn) % p.gm, zs = lid / (p.gn * p.gm);
+  const int n0 = nt * BN;
+  const int K = TAPS * p.Ci, nch = p.Ci / BK;
+  const int c_begin = (int)((long long)nch * zs / p.splitk), c_end = (int)((long long)nch * (zs + 1) / p.splitk);
+  const int G = (c_end - c_begin) * TAPS;           // (chunk, tap) steps of this block
+  const bool relu_in = p.flags & OFFK_CONV_RELU_IN_;
+
+  if (wave >= 4) {
+    // ================================ producers ================================
+    const int c8 = tid & 7;
+    const float* wbase = p.w + (size_t)(n0 + (tid >> 3)) * K + 4 * c8;
+    const float* xbase = p.x + p.x_coff + 4 * c8;
+    const long long npix_all = (long long)p.n_img * HW;
+    float4 rgP[NJ + 2 * NT];   // patch pieces, then the two weight-tile sets (one array: separate ones go to scratch)
+    constexpr int B0 = NJ, B1 = NJ + NT;
+    unsigned okp = 0;
+    auto load_patch = [&](int chunk) {
+      unsigned m = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int pp = (tid >> 3) + 32 * j;
+        const long long gp = (long long)mt * NP + pp;
+        const bool ok = pp < NP && gp < npix_all;
+        m |= ok ? (1u << j) : 0u;
+        rgP[j] = *reinterpret_cast<const float4*>(ok ? xbase + (size_t)gp * p.x_cs + chunk * BK : xbase);
+      }
+      okp = m;
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int pp = (tid >> 3) + 32 * j;
+        if (pp < NP) {
+          float4 t = rgP[j];
+          if (!((okp >> j) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (relu_in) t = relu4(t);
+          const int img = pp / HW, rem = pp - img * HW, y = rem / W, x = rem - y * W;
+          const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
+          const int slot = img * HW + y * W + xp;
+          uint2 hh, ll;
+          split4(t, hh, ll);
+          char* q = patch + slot * B3R + ((((c8 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c8 & 1) << 3));
+          *reinterpret_cast<uint2*>(q) = hh;
+          *reinterpret_cast<uint2*>(q + PATCH_PLANE) = ll;
+        }
+      }
+    };
+    auto load_b = [&](const int set, int g) {
+      const int cl = g / TAPS, tap = g - cl * TAPS;
+      const size_t koff = (size_t)((c_begin + cl) * TAPS + tap) * BK;
+#pragma unroll
+      for (int r = 0; r < NT; ++r) rgP[set + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + koff);
+    };
+    auto store_b = [&](const int set, int stage) {
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        const int row = (tid >> 3) + 32 * r;
+        *reinterpret_cast<float4*>(bst + stage * B_STAGE + (c8 >> 2) * B_PLANE + row * B3R + (((c8 & 3) ^ ((row >> 2) & 3)) << 4)) = rgP[set + r];
+      }
+    };
+    if (tid < 8) {   // the zero pixel
+      *reinterpret_cast<uint2*>(patch + NP * B3R + tid * 8) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(patch + PATCH_PLANE + NP * B3R + tid * 8) = make_uint2(0u, 0u);
+    }
+    load_patch(c_begin);
+    load_b(B0, 0);
+    store_patch();
+    store_b(B0, 0);
+    if (c_begin + 1 < c_end) load_patch(c_begin + 1);
+    if (1 < G) load_b(B0, 1);
+    if (2 < G) load_b(B1, 2);
+    __syncthreads();
+    int g = 0, chunk = c_begin;
+#define OFFK_PATCH_PRODUCER_STEP(RG)                                                                    \
+    if (g >= G) break;                                                                                  \
+    if (g + 1 < G) store_b(RG, (g + 1) & 1);          /* weight tile g+1 while step g is multiplied */  \
+    if (g + 3 < G) load_b(RG, g + 3);                                                                   \
+    __syncthreads();                                  /* end of step g */                               \
+    ++g;                                                                                                \
+    if (g < G && g % TAPS == 0) {                     /* next step starts a chunk: swap the patch */     \
+      ++chunk;                                                                                          \
+      store_patch();                                                                                    \
+      if (chunk + 1 < c_end) load_patch(chunk + 1);                                                     \
+      __syncthreads();                                                                                  \
+    }
+    for (;;) {
+      OFFK_PATCH_PRODUCER_STEP(B0)
+      OFFK_PATCH_PRODUCER_STEP(B1)
+    }
+#undef OFFK_PATCH_PRODUCER_STEP
+    return;
+  }
+
+  // ================================ consumers ================================
+  const int r32 = lane & 31, h = lane >> 5;
+  const int ct = NT == 4 ? wave : (wave & 1);
+  int geo[4 * RT];   // per row tile: y0, x0, image base, A offset of the current tap (one array: separate ones go to scratch)
+#define y0(i) geo[4 * (i)]
+#define x0(i) geo[4 * (i) + 1]
+#define ib(i) geo[4 * (i) + 2]
+#define aoff(i) geo[4 * (i) + 3]
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int rt = NT == 4 ? i : (wave >> 1) + 2 * i;
+    const int ml = rt * 32 + r32;
+    const bool mv = rt < 7 && ml < 196 && (long long)mt * 196 + ml < p.M;
+    const int img = ml / HOWO, rem = ml - img * HOWO, ho = rem / WO, wo = rem - ho * WO;
+    y0(i) = mv ? ho * S - PAD : -100000;
+    x0(i) = wo * S - PAD;
+    ib(i) = img * HW;
+    aoff(i) = 0;
+  }
+  f32x16 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int bbase = (ct * 32 + r32) * B3R + ((h ^ ((r32 >> 2) & 3)) << 4);
+  __syncthreads();
+  int tap = 0;
+  for (int g = 0; g < G; ++g) {
+    const int kh = tap / KW, kw = tap - kh * KW;
+    const char* bh_p = bst + (g & 1) * B_STAGE + bbase;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int y = y0(i) + kh, x = x0(i) + kw;
+      const bool inb = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
+      const int slot = inb ? ib(i) + y * W + xp : NP;
+      aoff(i) = slot * B3R + ((h ^ ((slot >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int boff = (bbase ^ (s2 << 5)) - bbase;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bh_p + boff);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bh_p + B_PLANE + boff);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        if (NT == 4 || (wave >> 1) + 2 * i < 7) {
+          const int off = aoff(i) ^ (s2 << 5);
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(patch + off);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(patch + PATCH_PLANE + off);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                   // end of step g
+    if (++tap == TAPS) {
+      tap = 0;
+      if (g + 1 < G) __syncthreads();                  // the next chunk's patch is in place
+    }
+  }
+
+#undef y0
+#undef x0
+#undef ib
+#undef aoff
+  // ---- epilogue (as conv_igemm_kernel) -------------------------------------------------------------
+  const int co = n0 + ct * 32 + r32;
+  if (p.splitk > 1) {
+    float* part = p.partial + (size_t)zs * p.M * p.Co;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int rt = NT == 4 ? i : (wave >> 1) + 2 * i;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int ml = rt * 32 + acc_row(reg, h);
+        const long long m = (long long)mt * 196 + ml;
+        if (rt < 7 && ml < 196 && m < p.M) part[(size_t)m * p.Co + co] = acc[i][reg];
+      }
+    }
+    return;
+  }
+  const bool relu_pre = p.flags & OFFK_CONV_RELU_PRE_, relu_post = p.flags & OFFK_CONV_RELU_POST_;
+  const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int rt = NT == 4 ? i : (wave >> 1) + 2 * i;
+    float rv[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
+    if (p.res) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int ml = rt * 32 + acc_row(reg, h);
+        const long long m = (long long)mt * 196 + ml;
+        const bool ok = rt < 7 && ml < 196 && m < p.M;
+        rv[reg] = *(ok ? p.res + (size_t)m * p.res_cs + p.res_coff + co : p.res);
+      }
+    }
+    float ov[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      float v = acc[i][reg] + bv;
+      if (relu_pre) v = fmaxf(v, 0.f);
+      v += rv[reg];
+      if (relu_post) v = fmaxf(v, 0.f);
+      asm volatile("" : "+v"(v));
+      ov[reg] = v;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int ml = rt * 32 + acc_row(reg, h);
+      const long long m = (long long)mt * 196 + ml;
+      if (rt < 7 && ml < 196 && m < p.M) p.y[(size_t)m * p.y_cs + p.y_coff + co] = ov[reg];
+    }
+  }
+}
+
+template <int KH, int S, int W, int NT>
+static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
+  constexpr int PAD = KH / 2, WO = (W + 2 * PAD - KH) / S + 1, IMG = 196 / (WO * WO), NP = IMG * W * W, BN = 32 * NT;
+  constexpr size_t lds = 2 * (size_t)(((NP + 1) * 64 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 64);
+  if (a.Co % BN) return hipErrorInvalidConfiguration;
+  auto kern = conv_patch_kernel<KH, S, W, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  a.gm = (a.M + 195) / 196;
+  a.gn = a.Co / BN;
+  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(512), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || a.splitk == 1) return e;
+  size_t n4 = (size_t)a.M * (a.Co / 4);
+  int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+// shapes the patch kernel covers: (k, stride, W) = (7, 2, 28), (5, 2, 14), (3, 1, 14), (3, 1, 7), pad = k / 2, square maps
+static hipError_t launch_patch_shape(const ConvArgs& a, int KH, int S, int W, int nt, hipStream_t st) {
+#define OFFK_PATCH_CASE(k, s, w)                                                        \
+  if (KH == k && S == s && W == w) return nt == 4 ? launch_patch<k, s, w, 4>(a, st) : launch_patch<k, s, w, 2>(a, st);
+  OFFK_PATCH_CASE(7, 2, 28)
+  OFFK_PATCH_CASE(5, 2, 14)
+  OFFK_PATCH_CASE(3, 1, 14)
+  OFFK_PATCH_CASE(3, 1, 7)
+#undef OFFK_PATCH_CASE
+  return hipErrorInvalidConfiguration;
+}
+
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -418,6 +699,17 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.splitk = sk; a.partial = d.partial; a.gm = a.gn = 0;
   const int key = d.KH * 100 + d.KW * 10 + d.stride;
   hipError_t e;
+  if (cfg == 6 || cfg == 7) {   // patch kernel: bf16x3, square map, pad = k / 2, one of its four shapes
+    if (d.precision != 1 || narrow || d.KH != d.KW || d.H != d.W || d.pad != d.KH / 2) {
+      *why = "conv2d: the patch kernel (tile_cfg 6 / 7) needs bf16x3, a square map and pad = k / 2";
+      return hipErrorInvalidValue;
+    }
+    if (sk > d.Ci / 32) sk = d.Ci / 32;   // it splits over channel chunks
+    a.splitk = sk;
+    e = launch_patch_shape(a, d.KH, d.stride, d.H, cfg == 6 ? 4 : 2, st);
+    if (e == hipErrorInvalidConfiguration) *why = "conv2d: the patch kernel covers 7x7s2@28, 5x5s2@14, 3x3s1@14, 3x3s1@7 with Co % 128 (cfg 6) / % 64 (cfg 7)";
+    return e;
+  }
   switch (key) {
     case 111: e = launch_shape<1, 1, 1>(a, cfg, d.precision, st); break;
     case 331: e = launch_shape<3, 3, 1>(a, cfg, d.precision, st); break;

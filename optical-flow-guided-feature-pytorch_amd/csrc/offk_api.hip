@@ -57,8 +57,10 @@ const int kTunedP384[kNumConvs][2] = {
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
     {1, 6}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},   // fusion @28
-    {0, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {4, 1},                           // fusion @14
-    {5, 3}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+    {0, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {7, 1},                           // fusion @14
+    {7, 4}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+// tile_cfg 7 = the LDS-patch kernel (64 channels per block): wins the two 3x3 convs whose patch is small enough
+// for two blocks per CU (3x3 128->512 and 3x3 832->256 at 7x7)
 // (re-tuned inside the whole forward with tools/tune_forward.py after the bf16x3 kernels were bounded to 128
 // VGPRs: the 128x128 tile now runs two blocks per CU and wins the 5x5 back from 64x128)
 // (main 1x1, branch 1x1) pairs whose outputs are summed: RGB_OFF.py:663-666, :768-770, :839-841

@@ -121,6 +121,52 @@ def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk, prec):
     assert torch.equal(y, y2)      # split-K sums slabs in a fixed order: bit-reproducible
 
 
+PATCH_CASES = [  # (k, stride, H, Ci, Co, n_img, cfg, splitk): the four shapes of the LDS-patch kernel, partial last groups
+    (7, 2, 28, 320, 64, 3, 7, 1), (7, 2, 28, 64, 128, 2, 6, 2), (5, 2, 14, 1056, 128, 6, 6, 3), (5, 2, 14, 96, 64, 9, 7, 1),
+    (3, 1, 14, 64, 64, 3, 7, 2), (3, 1, 14, 128, 256, 2, 6, 1), (3, 1, 7, 832, 256, 7, 6, 4), (3, 1, 7, 128, 128, 5, 7, 1),
+    (3, 1, 7, 256, 256, 8, 6, 3),
+]
+
+
+@pytest.mark.parametrize("k,stride,H,Ci,Co,n,cfg,splitk", PATCH_CASES)
+def test_conv2d_patch_kernel_vs_torch(rt, k, stride, H, Ci, Co, n, cfg, splitk):
+    """tile_cfg 6 / 7: the input patch of a 196-pixel output group stays in LDS across the taps (conv_igemm.hip).
+    Same conv, same epilogue flags, channel-sliced input / output views, bit-reproducible."""
+    from offk_amd import _lib
+    g = torch.Generator().manual_seed(k * 1000 + Ci + Co + n)
+    pad = k // 2
+    xs = torch.randn(n, Ci + 32, H, H, generator=g)          # the conv reads channels 32.. of a wider buffer
+    x = xs[:, 32:]
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = torch.randn(n, Co, Ho, Ho, generator=g)
+    flags = _lib.CONV_RELU_IN | _lib.CONV_RELU_PRE | _lib.CONV_RELU_POST
+    ref = torch.relu(torch.relu(F.conv2d(torch.relu(x), w, b, stride=stride, padding=pad)) + res)
+    ybuf = torch.full((n, Ho, Ho, Co + 64), 7.0, device="cuda")
+    rt.conv2d_nhwc(nhwc(xs), dev(w), dev(b), stride, pad, res=nhwc(res), flags=flags, x_coff=32, ci=Ci, y=ybuf, y_coff=32,
+                   tile_cfg=cfg, splitk=splitk, precision=1)
+    assert rel_err(ybuf[..., 32:32 + Co].permute(0, 3, 1, 2), ref) < RTOL
+    assert torch.all(ybuf[..., :32] == 7.0) and torch.all(ybuf[..., 32 + Co:] == 7.0)
+    y2 = torch.full_like(ybuf, 7.0)
+    rt.conv2d_nhwc(nhwc(xs), dev(w), dev(b), stride, pad, res=nhwc(res), flags=flags, x_coff=32, ci=Ci, y=y2, y_coff=32,
+                   tile_cfg=cfg, splitk=splitk, precision=1)
+    assert torch.equal(ybuf, y2)
+    # plain conv (no flags, no residual) through the same kernel
+    y3 = rt.conv2d_nhwc(nhwc(x.contiguous()), dev(w), dev(b), stride, pad, tile_cfg=cfg, splitk=1, precision=1)
+    assert rel_err(y3.permute(0, 3, 1, 2), F.conv2d(x, w, b, stride=stride, padding=pad)) < RTOL
+
+
+def test_conv2d_patch_kernel_rejects_other_shapes(rt):
+    from offk_amd import _lib
+    x = torch.randn(2, 10, 10, 64, device="cuda")
+    w = torch.randn(64, 64, 3, 3)
+    with pytest.raises(_lib.OffkError, match="patch kernel"):
+        rt.conv2d_nhwc(x, dev(w), None, 1, 1, tile_cfg=7, splitk=1, precision=1)
+    with pytest.raises(_lib.OffkError, match="patch kernel"):
+        rt.conv2d_nhwc(torch.randn(2, 7, 7, 64, device="cuda"), dev(w), None, 1, 1, tile_cfg=7, splitk=1, precision=0)
+
+
 def test_head_and_consensus(rt):
     g = torch.Generator().manual_seed(9)
     for C, H, mp in ((256, 14, True), (512, 7, False), (1024, 7, False)):

@@ -14,8 +14,8 @@ import torch  # noqa: E402
 import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec  # noqa: E402
 
-TILE_BN = (128, 64, 64, 64, 128, 256)
-TILE_BM = (128, 128, 256, 64, 64, 128)
+TILE_BN = (128, 64, 64, 64, 128, 256, 128, 64)   # 6 / 7: the LDS-patch kernel (bf16x3, k x k convs)
+TILE_BM = (128, 128, 256, 64, 64, 128, 196, 196)
 
 
 def in_hw(key):
@@ -57,11 +57,15 @@ def main():
         nkt = k * k * ci // 32
         ref = None
         rows = []
-        for cfg in range(6):
+        for cfg in range(8):
             if co % TILE_BN[cfg]:
+                continue
+            if cfg >= 6 and (args.precision != 1 or k == 1):
                 continue
             for sk in (1, 2, 3, 4, 6, 8, 12):
                 if sk > 1 and (nkt // sk < 8 or sk * M * co * 4 > 1.2e9):
+                    continue
+                if cfg >= 6 and sk > ci // 32:
                     continue
                 y = None
                 try:

@@ -15,23 +15,16 @@ import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
-    "motion_conv_trans_28": [(1, 6), (1, 4), (1, 8), (3, 3), (3, 6), (0, 6), (4, 6)],
-    "motion_conv_trans_14": [(0, 3), (0, 6), (0, 4), (0, 12), (4, 6), (0, 2)],
-    "motion_conv_trans": [(5, 3), (0, 6), (0, 3), (0, 4), (4, 3)],
-    "motion_conv3_trans_14b": [(4, 1), (1, 1), (3, 1), (0, 1), (0, 2)],
-    "motion_conv2_trans": [(0, 3), (4, 3), (5, 3), (0, 4), (0, 2)],
-    "motion_conv2_trans_14a": [(3, 1), (4, 1), (0, 1), (4, 3)],
-    "motion_conv2_trans_14b": [(3, 1), (4, 1), (0, 1), (4, 3)],
-    "motion_conv2_trans_28a": [(3, 1), (1, 1)],
-    "motion_conv2_trans_28b": [(3, 1), (1, 1)],
-    "motion_conv2_trans_28c": [(3, 1), (1, 1)],
-    "motion_conv3_trans_28b": [(3, 1), (1, 1), (4, 1), (0, 1)],
-    "motion_conv3_trans_28c": [(3, 1), (1, 1), (4, 1), (0, 1)],
-    "merged_28a": [(3, 1), (1, 1), (4, 1), (0, 1)],
-    "merged_14a": [(3, 1), (1, 1), (4, 1), (0, 1)],
-    "merged_7": [(3, 1), (1, 1), (4, 1), (0, 1), (5, 1)],
-    "motion_conv1_trans_14b": [(3, 1), (4, 1)],
-    "motion_conv1_trans": [(3, 1), (4, 1), (1, 1)],
+    "motion_conv_trans_28": [(1, 6), (7, 2), (7, 4), (7, 1)],
+    "motion_conv2_trans_28a": [(1, 1), (7, 1)],
+    "motion_conv2_trans_28b": [(1, 1), (7, 1)],
+    "motion_conv2_trans_28c": [(1, 1), (7, 1)],
+    "motion_conv_trans_14": [(0, 6), (6, 8), (6, 4)],
+    "motion_conv2_trans_14a": [(4, 1), (7, 1), (6, 1)],
+    "motion_conv2_trans_14b": [(4, 1), (7, 1), (6, 1)],
+    "motion_conv3_trans_14b": [(4, 1), (7, 1), (7, 2), (6, 1)],
+    "motion_conv_trans": [(5, 3), (0, 6), (7, 2), (7, 4), (6, 4)],
+    "motion_conv2_trans": [(0, 3), (7, 1), (7, 2), (6, 1)],
 }
 
 
