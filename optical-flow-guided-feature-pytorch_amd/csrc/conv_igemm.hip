@@ -18,6 +18,7 @@
 //   partial slabs that splitk_reduce_kernel sums in a fixed order (deterministic).
 //   M = pixels sits on the MFMA row axis, N = out-channels on the lane axis, so each
 //   accumulator register stores 32 consecutive channels of one pixel (128-B runs).
+#include <cstdio>
 #include <cstdlib>
 
 #include "offk_common.h"
@@ -37,6 +38,9 @@ struct ConvArgs {
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   float* partial;      // [splitk][M][Co] when splitk > 1
+#ifdef OFFK_CONV_TIMING
+  unsigned long long* dbg;   // [8] timing sums of the bf16x3 producer / consumer waves (tools only)
+#endif
 };
 
 // PREC 0: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
@@ -222,23 +226,46 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
       if (kt_begin + 2 < kt_end) load_tile(rg1, okm1, kt_begin + 2);
       __syncthreads();
       int kt = kt_begin;
+#ifdef OFFK_CONV_TIMING
+      unsigned long long t_st = 0, t_ld = 0, t_pb = 0;
+#define OFFK_T(var, stmt) { const unsigned long long q0 = __builtin_readcyclecounter(); stmt; var += __builtin_readcyclecounter() - q0; }
+#else
+#define OFFK_T(var, stmt) stmt;
+#endif
       for (; kt + 1 < kt_end; kt += 2) {
-        store_tile(rg0, okm0, 1);                              // tile kt+1 while tile kt is multiplied
-        if (kt + 3 < kt_end) load_tile(rg0, okm0, kt + 3);
-        __syncthreads();
-        if (kt + 2 < kt_end) store_tile(rg1, okm1, 0);         // tile kt+2 while tile kt+1 is multiplied
-        if (kt + 4 < kt_end) load_tile(rg1, okm1, kt + 4);
-        __syncthreads();
+        OFFK_T(t_st, store_tile(rg0, okm0, 1))                 // tile kt+1 while tile kt is multiplied
+        OFFK_T(t_ld, if (kt + 3 < kt_end) load_tile(rg0, okm0, kt + 3))
+        OFFK_T(t_pb, __syncthreads())
+        OFFK_T(t_st, if (kt + 2 < kt_end) store_tile(rg1, okm1, 0))   // tile kt+2 while tile kt+1 is multiplied
+        OFFK_T(t_ld, if (kt + 4 < kt_end) load_tile(rg1, okm1, kt + 4))
+        OFFK_T(t_pb, __syncthreads())
       }
+#undef OFFK_T
       if (kt < kt_end) __syncthreads();
+#ifdef OFFK_CONV_TIMING
+      if (p.dbg && threadIdx.x == 256) { atomicAdd(p.dbg + 3, t_st); atomicAdd(p.dbg + 4, t_ld); atomicAdd(p.dbg + 5, t_pb); }
+#endif
       return;
     }
     // ---- consumers
     __syncthreads();
+#ifdef OFFK_CONV_TIMING
+    unsigned long long t_mma = 0, t_bar = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const unsigned long long a0 = __builtin_readcyclecounter();
+      mma_b3(acc.acc, (kt - kt_begin) & 1);
+      const unsigned long long a1 = __builtin_readcyclecounter();
+      __syncthreads();
+      const unsigned long long a2 = __builtin_readcyclecounter();
+      t_mma += a1 - a0; t_bar += a2 - a1;
+    }
+    if (p.dbg && threadIdx.x == 0) { atomicAdd(p.dbg + 0, t_mma); atomicAdd(p.dbg + 1, t_bar); atomicAdd(p.dbg + 2, (unsigned long long)(kt_end - kt_begin)); }
+#else
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       mma_b3(acc.acc, (kt - kt_begin) & 1);
       __syncthreads();
     }
+#endif
   }
 
   const int r32 = lane & 31, h = lane >> 5;
@@ -697,6 +724,19 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.co_limit = narrow ? d.co_limit : d.Co;
   if (sk > 1 && (!d.partial || d.partial_floats < (size_t)sk * (size_t)M * d.Co)) sk = 1;   // no slab space: unsplit
   a.splitk = sk; a.partial = d.partial; a.gm = a.gn = 0;
+#ifdef OFFK_CONV_TIMING
+  {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64); (void)hipMemset(dbg, 0, 64); }
+    a.dbg = dbg;
+    if (getenv("OFFK_CONV_TIMING_DUMP")) {
+      unsigned long long h[8];
+      (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[conv timing] consumer mma %llu barrier %llu ktiles %llu | producer store %llu load-issue %llu barrier %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+      (void)hipMemset(dbg, 0, 64);
+    }
+  }
+#endif
   const int key = d.KH * 100 + d.KW * 10 + d.stride;
   hipError_t e;
   if (cfg == 6 || cfg == 7) {   // patch kernel: bf16x3, square map, pad = k / 2, one of its four shapes
