@@ -15,16 +15,9 @@ import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
-    "motion_conv_trans_28": [(1, 6), (7, 2), (7, 4), (7, 1)],
-    "motion_conv2_trans_28a": [(1, 1), (7, 1)],
-    "motion_conv2_trans_28b": [(1, 1), (7, 1)],
-    "motion_conv2_trans_28c": [(1, 1), (7, 1)],
-    "motion_conv_trans_14": [(0, 6), (6, 8), (6, 4)],
-    "motion_conv2_trans_14a": [(4, 1), (7, 1), (6, 1)],
-    "motion_conv2_trans_14b": [(4, 1), (7, 1), (6, 1)],
-    "motion_conv3_trans_14b": [(4, 1), (7, 1), (7, 2), (6, 1)],
-    "motion_conv_trans": [(5, 3), (0, 6), (7, 2), (7, 4), (6, 4)],
-    "motion_conv2_trans": [(0, 3), (7, 1), (7, 2), (6, 1)],
+    "motion_conv_trans_28": [(1, 6), (9, 6), (9, 4), (9, 8), (9, 5)],
+    "motion_conv_trans_14": [(0, 6), (8, 6), (8, 4)],
+    "motion_conv_trans": [(7, 4), (8, 3), (5, 3)],
 }
 
 
