@@ -276,3 +276,33 @@ def test_off_units_module_autograd(rt, variant):
     with torch.no_grad():
         want = orc.off_unit(tf[8], w2, "5b", B, L, v, orc.SLICE_FLAT)
     assert rel_err(m7b[:, 160:], want) < RTOL and not torch.equal(before, m7b)
+
+
+@pytest.mark.parametrize("B,L,variant,prec,slice_mode,cons", [
+    (3, 2, spec.VARIANT_RGB, "fp32", spec.SLICE_FLAT, True),          # L = 2: one pair per clip
+    (5, 9, spec.VARIANT_FLOW, "bf16x3", spec.SLICE_PER_CLIP, False),  # L > 7: two temporal steps per T-block
+    (1, 8, spec.VARIANT_RGB, "bf16x3", spec.SLICE_FLAT, True),        # one clip
+    (5, 3, spec.VARIANT_RGB, "fp32", spec.SLICE_PER_CLIP, False),     # P % 4 != 0: partial 196-pixel groups in the patch conv
+])
+def test_odd_shapes_forward_and_backward(rt, B, L, variant, prec, slice_mode, cons):
+    """Shapes off the benchmark grid (tools/fuzz_shapes.py draws more of them): whole forward and units backward."""
+    P = B * (L - 1)
+    feats = synth.make_features(B, L, 9)
+    wnp = synth.make_weights(variant, seed=0xBEEF + B + L)
+    w = orc.to_torch_weights(wnp)
+    h = rt.OffForward(B, L, variant, slice_mode, cons, precision=prec, training=True)
+    h.load_state_dict(wnp)
+    df = [dev(f) for f in feats]
+    tf = [torch.from_numpy(f) for f in feats]
+    out = h.forward(df)
+    with torch.no_grad():
+        ref = orc.off_forward(tf, w, B, L, variant, slice_mode, consensus=cons)
+    for a, b in zip(out, ref):
+        assert rel_err(a, b.reshape(a.shape)) < RTOL
+    h.off_units_train(df, 5, DROP_P)
+    drops = unit_drop(5, P)
+    g, dm = orc.unit_backward(tf, w, B, L, variant, slice_mode, cotangents(P), drops,
+                              device_relu_masks(h, tf, w, B, L, 1e-5 if prec == "fp32" else 1e-4))
+    _flat, got = h.off_units_backward(df, grad_views(dm), 5, DROP_P)
+    for k in g:
+        assert rel_err(got[k], g[k]) < RTOL, k
