@@ -126,6 +126,7 @@ struct offk_handle {
 
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
+  bool fused_units = false;      // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS at offk_create)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
   std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
@@ -425,6 +426,43 @@ int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[],
   return OFFK_OK;
 }
 
+// Inference path of the units: K1 fused with the temporal difference (pw_tdiff.hip), then the S-blocks of K2 alone.
+int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts feats[], void* ws, hipEvent_t* ev) {
+  { int rc = finalize_pw(h, st); if (rc != OFFK_OK) return rc; }
+  PtParams pt;
+  memset(&pt, 0, sizeof(pt));
+  pt.nsites = kNumSites; pt.B = h->cfg.batch; pt.L = h->cfg.length; pt.P = h->P; pt.slice_mode = h->cfg.slice_mode;
+  pt.tgroups = pt_tgroups(h->cfg.length);
+  pt.precision = h->cfg.precision;
+  pt.presplit = h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit;
+  pt.zeros = h->zero_page;
+  const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
+  int blk = 0;
+  for (int i = 0; i < kNumSites; ++i) {
+    const int s = kPwOrder[i];
+    PtSite& o = pt.s[i];
+    const offk_feat_parts& fp = feats[s];
+    for (int q = 0; q < 4; ++q) { o.xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o.cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
+    o.nparts = fp.n_parts;
+    o.w = pt.presplit ? h->pw_wb3[s] : h->pw_w[s];
+    o.bias = h->pw_b[s];
+    o.D = region(h, ws, (std::string("D_") + kSites[s].name).c_str());
+    o.M = region(h, ws, fus[kSiteFusion[s]]);
+    o.m_cs = kFusionC[kSiteFusion[s]]; o.m_coff = kSiteCoff[s];
+    o.C = kSites[s].C; o.HW = kSites[s].H * kSites[s].H;
+    o.chunks = (o.HW + 31) / 32;
+    o.blk_begin = blk;
+    blk += h->cfg.batch * o.chunks * pt.tgroups;
+  }
+  pt.total_blocks = blk;
+  if (ev) HIP_TRY(h, hipEventRecord(ev[0], st));
+  HIP_TRY(h, pw_tdiff_launch(pt, st));
+  if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
+  { int rc = run_sobel_tdiff_all(h, st, ws, 3); if (rc != OFFK_OK) return rc; }   // S-blocks only: M[.., coff .. coff+32)
+  if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
+  return OFFK_OK;
+}
+
 struct View { const float* p; int cs, coff; };
 
 int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, int K, int stride, int pad, const float* w,
@@ -577,6 +615,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     offk_destroy(h);
     return OFFK_ERR_HIP;
   }
+  { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = e && *e == '1'; }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&
@@ -799,7 +838,8 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     if ((h->ev_used + 1) * per <= h->events.size()) ev = &h->events[h->ev_used++ * per];
   }
 
-  TRY(run_off_units(h, st, feats, ws, ev));
+  if (h->fused_units && h->cfg.feat_layout != OFFK_FEAT_NHWC) TRY(run_off_units_fused(h, st, feats, ws, ev));
+  else TRY(run_off_units(h, st, feats, ws, ev));
 
   h->cur_splitk = region(h, ws, "splitk");
   float* F28 = region(h, ws, "fusion_28");

@@ -56,6 +56,30 @@ struct PwParams {
 int pw_blocks_for(int M);
 hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st);
 
+// ---- K1T: K1 fused with the temporal difference (pw_tdiff.hip) -------------------------
+struct PtSite {
+  const float* xp[4];   // feature map parts, NCHW (as PwSite)
+  int cp[4];
+  int nparts;
+  const float* w;       // stacked [160][C] fp32, or pre-split for bf16x3 (as PwSite)
+  const float* bias;    // [160]
+  float* D;             // [P*HW][32]
+  float* M;             // fusion buffer: T goes to channels [m_coff + 32, m_coff + 160)
+  int m_cs, m_coff;
+  int C, HW;
+  int chunks;           // ceil(HW / 32) pixel chunks per clip
+  int blk_begin;
+};
+struct PtParams {
+  PtSite s[kNumSites];
+  int nsites, total_blocks;
+  int B, L, P, slice_mode, tgroups;
+  int precision, presplit;
+  const float* zeros;
+};
+int pt_tgroups(int L);
+hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);
+
 // ---- K2 ------------------------------------------------------------------------
 struct StSite {
   const float* G;     // [N*HW][128]

@@ -1,0 +1,277 @@
+// K1T: the OFF units' 1x1 reduce convolutions FUSED with the temporal difference (inference path).
+//
+// Stands for, per tap site (reference RGB_OFF.py, site 3a lines):
+//   G = relu(motion_conv_gen_s(X))                         :597-598
+//   T[b*(L-1)+t] = G[b*L+t+1] - G[b*L+t]                   :599-604
+//   D = motion_spatial_down_s(X[:B*(L-1)])                 :609-610  (quirk Q1 via down_row)
+// K1 (pw_reduce.hip) writes G to HBM and K2 (sobel_tdiff.hip) reads it back to subtract neighbouring frames:
+// 2 x 128 x N x HW floats that exist only to be differenced.  Here a block owns a (clip, 32-pixel chunk) and ALL
+// frames of it: seven 32-row MFMA tiles = seven frames, so the frames t and t+1 of a pixel sit in the same lane
+// and register index of two accumulator tiles and T is a register subtraction in the epilogue.  G never leaves the
+// chip; per clip the units then move X (31.6 MB) + T (8.1 MB) + D (2.0 MB) + S (2.0 MB) = SURVEY.md 8(d)'s
+// "fully fused" 45.4 MB instead of 68.4 MB.  D still goes to HBM: the 3x3 on it needs a spatial halo, the S half
+// of K2 (its S-blocks alone) runs behind this kernel.
+//
+// GEMM view per block: rows = (frame j, pixel) = 7 x 32, K = C, N = 160 (128 gen + 32 down).  Wave w owns gen
+// columns [32w, 32w+32) for all seven frames (7 accumulator tiles) and the down columns for frames w and w+4.
+// X is NCHW: per (frame, channel) the 32 pixels are one 128-byte run; 4 k-rows x 4 pixels per thread, register
+// transpose into the [row][k] LDS image as in K1.  L > 7: temporal groups of 7 frames overlapping by one.
+// Training keeps the unfused pair (the backward needs G for the ReLU mask).
+#include "offk_common.h"
+#include "offk_internal.h"
+
+namespace offk {
+
+namespace {
+constexpr int PT_FT = 7;                 // frames (row tiles) per block
+constexpr int PT_BM = 32 * PT_FT, PT_BN = 160;
+
+__device__ __forceinline__ int pt_down_row(int f, int L, int P, int slice_mode) {
+  if (slice_mode == 0) return f < P ? f : -1;
+  const int b = f / L, t = f - b * L;
+  return t < L - 1 ? b * (L - 1) + t : -1;
+}
+}  // namespace
+
+int pt_tgroups(int L) { return L <= PT_FT ? 1 : (L - 2) / (PT_FT - 1) + 1; }
+
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
+  constexpr int A_PLANE = PT_BM * B3_ROW, B_PLANE = PT_BN * B3_ROW;
+  constexpr int LDS_BYTES = PREC == 0 ? (PT_BM + PT_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  float* As = reinterpret_cast<float*>(lds);                    // fp32: [224][LDS_K] then [160][LDS_K]
+  float* Bs = As + PT_BM * LDS_K;
+  char* Ahi = lds;                                              // bf16x3: A_hi | A_lo | B_hi | B_lo
+  char* Bhi = lds + 2 * A_PLANE;
+
+  PtSite S;
+#define OFFK_PT_PICK(i)                                                                                \
+  S.w = p.s[i].w; S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;           \
+  S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
+  S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
+  S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
+  S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
+  OFFK_PT_PICK(0)
+#pragma unroll
+  for (int i = 1; i < kNumSites; ++i)
+    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PT_PICK(i) }
+#undef OFFK_PT_PICK
+  const int C = S.C, HW = S.HW, L = p.L;
+  int local = (int)blockIdx.x - S.blk_begin;
+  const int tg = local % p.tgroups; local /= p.tgroups;
+  const int chunk = local % S.chunks, b = local / S.chunks;
+  const int q0 = chunk * 32;
+  const int t0 = tg * (PT_FT - 1);
+  const int nf = min(PT_FT, L - t0);          // frames of this block (>= 2)
+  const bool last_group = tg == p.tgroups - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- loader: thread = (k quad kq, pixel quad pq, frame select fs): frames fs and fs + 4 --------------------
+  const int kq = tid & 7, pq = (tid >> 3) & 7, fs = tid >> 6;
+  const int k0px = q0 + 4 * pq, kkpx = min(k0px, HW - 4);       // a quad that straddles the plane end is read from HW-4
+  const int sh = k0px < HW ? k0px - kkpx : 0;                    // and shifted into place (HW % 4 != 0 only)
+  const bool px_ok = k0px < HW;
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  auto locate = [&](int k0, const float*& xb, int& cpart, int& kl) {
+    xb = S.xp[0]; cpart = S.cp[0]; kl = k0;
+    if (S.nparts > 1 && kl >= S.cp[0]) {
+      kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
+      if (S.nparts > 2 && kl >= S.cp[1]) {
+        kl -= S.cp[1]; xb = S.xp[2]; cpart = S.cp[2];
+        if (S.nparts > 3 && kl >= S.cp[2]) { kl -= S.cp[2]; xb = S.xp[3]; cpart = S.cp[3]; }
+      }
+    }
+  };
+  float4 rg[8 + 5];   // A: frame fs (4 k-rows), frame fs+4 (4 k-rows); B: 5 weight rows
+  const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
+  auto load_tile = [&](int k0) {
+    const float* xb; int cpart, kl;
+    locate(k0, xb, cpart, kl);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int j = fs + 4 * half;
+      const bool ok = px_ok && j < nf;
+      const float* base = xb + ((size_t)(b * L + t0 + (ok ? j : 0)) * cpart + kl + 4 * kq) * HW + kkpx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f4u v = *reinterpret_cast<const f4u*>(ok ? base + (size_t)i * HW : p.zeros);
+        rg[4 * half + i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) rg[8 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
+  };
+  auto shifted = [&](float4 v) {
+    if (sh == 0) return v;
+    return sh == 1 ? make_float4(v.y, v.z, v.w, 0.f) : (sh == 2 ? make_float4(v.z, v.w, 0.f, 0.f) : make_float4(v.w, 0.f, 0.f, 0.f));
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int j = fs + 4 * half;
+      if (j < PT_FT) {
+        const float4 a0 = shifted(rg[4 * half]), a1 = shifted(rg[4 * half + 1]), a2 = shifted(rg[4 * half + 2]), a3 = shifted(rg[4 * half + 3]);
+        const int row = j * 32 + 4 * pq;
+        if (PREC == 1) {
+          b3_store(Ahi, A_PLANE, row, kq, make_float4(a0.x, a1.x, a2.x, a3.x));
+          b3_store(Ahi, A_PLANE, row + 1, kq, make_float4(a0.y, a1.y, a2.y, a3.y));
+          b3_store(Ahi, A_PLANE, row + 2, kq, make_float4(a0.z, a1.z, a2.z, a3.z));
+          b3_store(Ahi, A_PLANE, row + 3, kq, make_float4(a0.w, a1.w, a2.w, a3.w));
+        } else {
+          float* dst = As + row * LDS_K + 4 * kq;
+          *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a1.x, a2.x, a3.x);
+          *reinterpret_cast<float4*>(dst + LDS_K) = make_float4(a0.y, a1.y, a2.y, a3.y);
+          *reinterpret_cast<float4*>(dst + 2 * LDS_K) = make_float4(a0.z, a1.z, a2.z, a3.z);
+          *reinterpret_cast<float4*>(dst + 3 * LDS_K) = make_float4(a0.w, a1.w, a2.w, a3.w);
+        }
+      }
+    }
+    if (PREC == 1) {
+      if (p.presplit) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+          *reinterpret_cast<float4*>(Bhi + ((tid & 7) >> 2) * B_PLANE + ((tid >> 3) + 32 * r) * B3_ROW + ((tid & 3) << 4)) = rg[8 + r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 5; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[8 + r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[8 + r];
+    }
+  };
+
+  f32x16 acc[PT_FT + 2];   // 0..6: gen tile of frame j; 7, 8: down tiles of frames wave and wave + 4
+#pragma unroll
+  for (int t = 0; t < PT_FT + 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int r32 = lane & 31, h = lane >> 5;
+  const bool d1 = wave + 4 < PT_FT;          // waves 0-2 own a second down tile
+  const int nkt = C / BK;
+  load_tile(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+    if (PREC == 1) {
+#pragma unroll 1
+      for (int s2 = 0; s2 < BK / 16; ++s2) {
+        const int off = r32 * B3_ROW + (16 * s2 + 8 * h) * 2;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + wave * 32 * B3_ROW + off);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + wave * 32 * B3_ROW + off);
+        const bf16x8 dh = *reinterpret_cast<const bf16x8*>(Bhi + kGenCh * B3_ROW + off);
+        const bf16x8 dl = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + kGenCh * B3_ROW + off);
+#pragma unroll
+        for (int j = 0; j < PT_FT; ++j) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + j * 32 * B3_ROW + off);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + j * 32 * B3_ROW + off);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        }
+        {   // down tile of frame `wave` (its rows are read again: a runtime row offset, not a runtime register index)
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + wave * 32 * B3_ROW + off);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + wave * 32 * B3_ROW + off);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, dh, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dl, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dh, acc[PT_FT], 0, 0, 0);
+        }
+        if (d1) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + (wave + 4) * 32 * B3_ROW + off);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + (wave + 4) * 32 * B3_ROW + off);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, dh, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dl, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dh, acc[PT_FT + 1], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int g = 0; g < BK / 8; ++g) {
+        const float4 bw = *reinterpret_cast<const float4*>(Bs + (wave * 32 + r32) * LDS_K + 8 * g + 4 * h);
+        const float4 dw = *reinterpret_cast<const float4*>(Bs + (kGenCh + r32) * LDS_K + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < PT_FT; ++j) {
+          const float4 a = *reinterpret_cast<const float4*>(As + (j * 32 + r32) * LDS_K + 8 * g + 4 * h);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw.x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw.y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw.z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw.w, acc[j], 0, 0, 0);
+        }
+        {
+          const float4 a = *reinterpret_cast<const float4*>(As + (wave * 32 + r32) * LDS_K + 8 * g + 4 * h);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dw.x, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dw.y, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dw.z, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dw.w, acc[PT_FT], 0, 0, 0);
+        }
+        if (d1) {
+          const float4 a = *reinterpret_cast<const float4*>(As + ((wave + 4) * 32 + r32) * LDS_K + 8 * g + 4 * h);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dw.x, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dw.y, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dw.z, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dw.w, acc[PT_FT + 1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: G = relu(acc + bias) in registers, T = G[j+1] - G[j] -> M; D -> HBM -------------------------
+  const float bg = S.bias[wave * 32 + r32], bd = S.bias[kGenCh + r32];
+#pragma unroll
+  for (int j = 0; j < PT_FT; ++j)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      float v = fmaxf(acc[j][reg] + bg, 0.f);
+      asm volatile("" : "+v"(v));
+      acc[j][reg] = v;
+    }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    float d0v = acc[PT_FT][reg] + bd, d1v = acc[PT_FT + 1][reg] + bd;
+    asm volatile("" : "+v"(d0v));
+    asm volatile("" : "+v"(d1v));
+    acc[PT_FT][reg] = d0v; acc[PT_FT + 1][reg] = d1v;
+  }
+  const size_t pair0 = (size_t)b * (L - 1) + t0;
+#pragma unroll
+  for (int j = 0; j + 1 < PT_FT; ++j) {
+    if (j + 1 < nf) {
+      float* mrow = S.M + ((pair0 + j) * HW + q0) * S.m_cs + S.m_coff + kDownCh + wave * 32 + r32;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int px = acc_row(reg, h);
+        if (q0 + px < HW) mrow[(size_t)px * S.m_cs] = acc[j + 1][reg] - acc[j][reg];
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int j = wave + 4 * half;
+    // the frame shared with the next temporal group belongs to that group
+    if (j < nf && (last_group || j < PT_FT - 1)) {
+      const int dr = pt_down_row(b * L + t0 + j, L, p.P, p.slice_mode);
+      if (dr >= 0) {
+        float* drow = S.D + ((size_t)dr * HW + q0) * kDownCh + r32;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int px = acc_row(reg, h);
+          if (q0 + px < HW) drow[(size_t)px * kDownCh] = acc[PT_FT + half][reg];
+        }
+      }
+    }
+  }
+}
+
+hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st) {
+  if (p.total_blocks <= 0) return hipSuccess;
+  if (p.precision == 0) hipLaunchKernelGGL(pw_tdiff_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(pw_tdiff_kernel<1>, dim3(p.total_blocks), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace offk

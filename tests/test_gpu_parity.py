@@ -425,3 +425,29 @@ def test_forward_is_stream_capturable(rt):
         g.replay()
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("B,L", [(2, 3), (3, 9)])
+def test_fused_units_path_bit_identical(rt, prec, B, L, monkeypatch):
+    """OFFK_FUSED_UNITS=1 (pw_tdiff.hip): K1 fused with the temporal difference, G never written to HBM.  Same k order
+    per output element, so the logits are the unfused path's bits (also with two temporal groups, L = 9)."""
+    feats = [dev(f) for f in synth.make_features(B, L, 4)]
+    h0, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    monkeypatch.setenv("OFFK_FUSED_UNITS", "1")
+    h1, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    monkeypatch.delenv("OFFK_FUSED_UNITS")
+    ref = h0.forward(feats)
+    got = h1.forward(feats)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # the branches-as-parts entry point takes the same path
+    parts = []
+    for f, widths in zip(synth.make_features(B, L, 4), spec.SITE_PARTS):
+        off, grp = 0, []
+        for wd in widths:
+            grp.append(dev(np.ascontiguousarray(f[:, off:off + wd])))
+            off += wd
+        parts.append(grp)
+    for a, b in zip(ref, h1.forward(parts)):
+        assert torch.equal(a, b)
