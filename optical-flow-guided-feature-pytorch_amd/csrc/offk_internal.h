@@ -76,6 +76,9 @@ struct PtParams {
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
   const float* zeros;
+#ifdef OFFK_PT_TIMING
+  unsigned long long* dbg;   // cycle-counter sums (tools only)
+#endif
 };
 int pt_tgroups(int L);
 hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);

@@ -17,6 +17,9 @@
 // X is NCHW: per (frame, channel) the 32 pixels are one 128-byte run; 4 k-rows x 4 pixels per thread, register
 // transpose into the [row][k] LDS image as in K1.  L > 7: temporal groups of 7 frames overlapping by one.
 // Training keeps the unfused pair (the backward needs G for the ReLU mask).
+#include <cstdio>
+#include <cstdlib>
+
 #include "offk_common.h"
 #include "offk_internal.h"
 
@@ -35,15 +38,17 @@ __device__ __forceinline__ int pt_down_row(int f, int L, int P, int slice_mode) 
 
 int pt_tgroups(int L) { return L <= PT_FT ? 1 : (L - 2) / (PT_FT - 1) + 1; }
 
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
+// PC = 1 (bf16x3 only): 512 threads, waves 0-3 multiply, waves 4-7 load two K-tiles ahead, split and store into a
+// two-stage LDS ring (one block per CU); the 256-thread form holds one tile of prefetch beside 144 accumulator
+// registers and waits a memory latency per K-tile.
+template <int PREC, int PC>
+__global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p) {
+  static_assert(PC == 0 || PREC == 1, "producer / consumer form is bf16x3 only");
   constexpr int A_PLANE = PT_BM * B3_ROW, B_PLANE = PT_BN * B3_ROW;
-  constexpr int LDS_BYTES = PREC == 0 ? (PT_BM + PT_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  constexpr int STAGE = PREC == 0 ? (PT_BM + PT_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
+  extern __shared__ __attribute__((aligned(16))) char lds[];     // STAGE bytes, two stages with PC
   float* As = reinterpret_cast<float*>(lds);                    // fp32: [224][LDS_K] then [160][LDS_K]
   float* Bs = As + PT_BM * LDS_K;
-  char* Ahi = lds;                                              // bf16x3: A_hi | A_lo | B_hi | B_lo
-  char* Bhi = lds + 2 * A_PLANE;
 
   PtSite S;
 #define OFFK_PT_PICK(i)                                                                                \
@@ -65,7 +70,8 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
   const int t0 = tg * (PT_FT - 1);
   const int nf = min(PT_FT, L - t0);          // frames of this block (>= 2)
   const bool last_group = tg == p.tgroups - 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x & 255;          // index within the four loading waves
 
   // ---- loader: thread = (k quad kq, pixel quad pq, frame select fs): frames fs and fs + 4 --------------------
   const int kq = tid & 7, pq = (tid >> 3) & 7, fs = tid >> 6;
@@ -83,9 +89,10 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
       }
     }
   };
-  float4 rg[8 + 5];   // A: frame fs (4 k-rows), frame fs+4 (4 k-rows); B: 5 weight rows
+  constexpr int NRG = 8 + 5;          // A: frame fs (4 k-rows), frame fs+4 (4 k-rows); B: 5 weight rows
+  float4 rg[PC ? 2 * NRG : NRG];      // PC: two sets (one array: separate ones go to scratch)
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](const int set, int k0) {
     const float* xb; int cpart, kl;
     locate(k0, xb, cpart, kl);
 #pragma unroll
@@ -96,22 +103,24 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f4u v = *reinterpret_cast<const f4u*>(ok ? base + (size_t)i * HW : p.zeros);
-        rg[4 * half + i] = make_float4(v.x, v.y, v.z, v.w);
+        rg[set + 4 * half + i] = make_float4(v.x, v.y, v.z, v.w);
       }
     }
 #pragma unroll
-    for (int r = 0; r < 5; ++r) rg[8 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
+    for (int r = 0; r < 5; ++r) rg[set + 8 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
   };
   auto shifted = [&](float4 v) {
     if (sh == 0) return v;
     return sh == 1 ? make_float4(v.y, v.z, v.w, 0.f) : (sh == 2 ? make_float4(v.z, v.w, 0.f, 0.f) : make_float4(v.w, 0.f, 0.f, 0.f));
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const int set, int stage) {
+    char* Ahi = lds + stage * STAGE;                              // bf16x3: A_hi | A_lo | B_hi | B_lo
+    char* Bhi = Ahi + 2 * A_PLANE;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int j = fs + 4 * half;
       if (j < PT_FT) {
-        const float4 a0 = shifted(rg[4 * half]), a1 = shifted(rg[4 * half + 1]), a2 = shifted(rg[4 * half + 2]), a3 = shifted(rg[4 * half + 3]);
+        const float4 a0 = shifted(rg[set + 4 * half]), a1 = shifted(rg[set + 4 * half + 1]), a2 = shifted(rg[set + 4 * half + 2]), a3 = shifted(rg[set + 4 * half + 3]);
         const int row = j * 32 + 4 * pq;
         if (PREC == 1) {
           b3_store(Ahi, A_PLANE, row, kq, make_float4(a0.x, a1.x, a2.x, a3.x));
@@ -131,17 +140,38 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
       if (p.presplit) {
 #pragma unroll
         for (int r = 0; r < 5; ++r)
-          *reinterpret_cast<float4*>(Bhi + ((tid & 7) >> 2) * B_PLANE + ((tid >> 3) + 32 * r) * B3_ROW + ((tid & 3) << 4)) = rg[8 + r];
+          *reinterpret_cast<float4*>(Bhi + ((tid & 7) >> 2) * B_PLANE + ((tid >> 3) + 32 * r) * B3_ROW + ((tid & 3) << 4)) = rg[set + 8 + r];
       } else {
 #pragma unroll
-        for (int r = 0; r < 5; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[8 + r]);
+        for (int r = 0; r < 5; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[set + 8 + r]);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 5; ++r)
-        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[8 + r];
+        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[set + 8 + r];
     }
   };
+
+  const int nkt = C / BK;
+  if (PC && wave >= 4) {
+    // ---- producers (as in conv_igemm.hip): tile t is stored one step before it is multiplied, loaded two before that
+    load_tile(0, 0);
+    store_tile(0, 0);
+    if (1 < nkt) load_tile(0, BK);
+    if (2 < nkt) load_tile(NRG, 2 * BK);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+      store_tile(0, 1);
+      if (kt + 3 < nkt) load_tile(0, (kt + 3) * BK);
+      __syncthreads();
+      if (kt + 2 < nkt) store_tile(NRG, 0);
+      if (kt + 4 < nkt) load_tile(NRG, (kt + 4) * BK);
+      __syncthreads();
+    }
+    if (kt < nkt) __syncthreads();
+    return;
+  }
 
   f32x16 acc[PT_FT + 2];   // 0..6: gen tile of frame j; 7, 8: down tiles of frames wave and wave + 4
 #pragma unroll
@@ -151,12 +181,25 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
 
   const int r32 = lane & 31, h = lane >> 5;
   const bool d1 = wave + 4 < PT_FT;          // waves 0-2 own a second down tile
-  const int nkt = C / BK;
-  load_tile(0);
+  if (PC) __syncthreads();
+  else load_tile(0, 0);
+#ifdef OFFK_PT_TIMING
+  unsigned long long t_st = 0, t_s1 = 0, t_ld = 0, t_mm = 0, t_s2 = 0, c0 = __builtin_readcyclecounter(), c1;
+#define OFFK_TICK(var) c1 = __builtin_readcyclecounter(); var += c1 - c0; c0 = c1;
+#else
+#define OFFK_TICK(var)
+#endif
   for (int kt = 0; kt < nkt; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+    if (!PC) {
+      store_tile(0, 0);
+      OFFK_TICK(t_st)
+      __syncthreads();
+      OFFK_TICK(t_s1)
+      if (kt + 1 < nkt) load_tile(0, (kt + 1) * BK);
+      OFFK_TICK(t_ld)
+    }
+    const char* Ahi = lds + (PC ? (kt & 1) * STAGE : 0);
+    const char* Bhi = Ahi + 2 * A_PLANE;
     if (PREC == 1) {
 #pragma unroll 1
       for (int s2 = 0; s2 < BK / 16; ++s2) {
@@ -217,8 +260,18 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
         }
       }
     }
+    OFFK_TICK(t_mm)
     __syncthreads();
+    OFFK_TICK(t_s2)
   }
+#ifdef OFFK_PT_TIMING
+  if (p.dbg && threadIdx.x == 0) {
+    atomicAdd(p.dbg + 0, t_st); atomicAdd(p.dbg + 1, t_s1); atomicAdd(p.dbg + 2, t_ld); atomicAdd(p.dbg + 3, t_mm);
+    atomicAdd(p.dbg + 4, t_s2); atomicAdd(p.dbg + 5, (unsigned long long)nkt); atomicAdd(p.dbg + 6, 1ull);
+  }
+  const unsigned long long e0 = __builtin_readcyclecounter();
+#endif
+#undef OFFK_TICK
 
   // ---- epilogue: G = relu(acc + bias) in registers, T = G[j+1] - G[j] -> M; D -> HBM -------------------------
   const float bg = S.bias[wave * 32 + r32], bd = S.bias[kGenCh + r32];
@@ -265,12 +318,45 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
       }
     }
   }
+#ifdef OFFK_PT_TIMING
+  if (p.dbg && threadIdx.x == 0) atomicAdd(p.dbg + 7, __builtin_readcyclecounter() - e0);
+#endif
 }
 
-hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st) {
+hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
+  PtParams p = p_in;
   if (p.total_blocks <= 0) return hipSuccess;
-  if (p.precision == 0) hipLaunchKernelGGL(pw_tdiff_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(pw_tdiff_kernel<1>, dim3(p.total_blocks), dim3(256), 0, st, p);
+#ifdef OFFK_PT_TIMING
+  {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64); (void)hipMemset(dbg, 0, 64); }
+    p.dbg = dbg;
+    if (getenv("OFFK_PT_TIMING_DUMP")) {
+      unsigned long long hb[8];
+      (void)hipMemcpy(hb, dbg, 64, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[pt timing] store %llu sync1 %llu load-issue %llu mma %llu sync2 %llu | ktiles %llu blocks %llu epilogue %llu\n",
+              hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
+      (void)hipMemset(dbg, 0, 64);
+    }
+  }
+#endif
+  constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4, kStageB3 = 2 * (size_t)(PT_BM + PT_BN) * B3_ROW;
+  // OFFK_FUSED_PC=1: the 512-thread producer / consumer form (measured slower: 0.945 vs 0.828 ms, one block per CU)
+  static const bool pc = [] { const char* e = getenv("OFFK_FUSED_PC"); return e && *e == '1'; }();
+  if (p.precision == 0) {
+    hipLaunchKernelGGL((pw_tdiff_kernel<0, 0>), dim3(p.total_blocks), dim3(256), kStage32, st, p);
+  } else if (!pc) {
+    hipLaunchKernelGGL((pw_tdiff_kernel<1, 0>), dim3(p.total_blocks), dim3(256), kStageB3, st, p);
+  } else {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kStageB3));
+      if (e != hipSuccess) return e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((pw_tdiff_kernel<1, 1>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
+  }
   return hipGetLastError();
 }
 
