@@ -212,23 +212,23 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
         for (int j = 0; j < PT_FT; ++j) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + j * 32 * B3_ROW + off);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + j * 32 * B3_ROW + off);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[j], 0, 0, 0);   // weights first: rows of the
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[j], 0, 0, 0);   // accumulator tile = channels,
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[j], 0, 0, 0);   // lanes = pixels (16-B stores)
         }
         {   // down tile of frame `wave` (its rows are read again: a runtime row offset, not a runtime register index)
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + wave * 32 * B3_ROW + off);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + wave * 32 * B3_ROW + off);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, dh, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dl, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dh, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, al, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, ah, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, ah, acc[PT_FT], 0, 0, 0);
         }
         if (d1) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + (wave + 4) * 32 * B3_ROW + off);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + (wave + 4) * 32 * B3_ROW + off);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, dh, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dl, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dh, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, al, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, ah, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, ah, acc[PT_FT + 1], 0, 0, 0);
         }
       }
     } else {
@@ -239,24 +239,24 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 #pragma unroll
         for (int j = 0; j < PT_FT; ++j) {
           const float4 a = *reinterpret_cast<const float4*>(As + (j * 32 + r32) * LDS_K + 8 * g + 4 * h);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw.x, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw.y, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw.z, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw.w, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.x, a.x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.y, a.y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.z, a.z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw.w, a.w, acc[j], 0, 0, 0);
         }
         {
           const float4 a = *reinterpret_cast<const float4*>(As + (wave * 32 + r32) * LDS_K + 8 * g + 4 * h);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dw.x, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dw.y, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dw.z, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dw.w, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.x, a.x, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.y, a.y, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.z, a.z, acc[PT_FT], 0, 0, 0);
+          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.w, a.w, acc[PT_FT], 0, 0, 0);
         }
         if (d1) {
           const float4 a = *reinterpret_cast<const float4*>(As + ((wave + 4) * 32 + r32) * LDS_K + 8 * g + 4 * h);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dw.x, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dw.y, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dw.z, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dw.w, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.x, a.x, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.y, a.y, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.z, a.z, acc[PT_FT + 1], 0, 0, 0);
+          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dw.w, a.w, acc[PT_FT + 1], 0, 0, 0);
         }
       }
     }
@@ -274,47 +274,55 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 #undef OFFK_TICK
 
   // ---- epilogue: G = relu(acc + bias) in registers, T = G[j+1] - G[j] -> M; D -> HBM -------------------------
-  const float bg = S.bias[wave * 32 + r32], bd = S.bias[kGenCh + r32];
+  // accumulator tile: register (reg) <-> channel acc_row(reg, h) of the wave's 32-channel slab, lane r32 <-> pixel:
+  // registers 4g .. 4g+3 of a lane are four consecutive channels, one 16-byte store
+  float4 bg4[4], bd4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bg4[g] = *reinterpret_cast<const float4*>(S.bias + wave * 32 + 8 * g + 4 * h);
+    bd4[g] = *reinterpret_cast<const float4*>(S.bias + kGenCh + 8 * g + 4 * h);
+  }
 #pragma unroll
   for (int j = 0; j < PT_FT; ++j)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float v = fmaxf(acc[j][reg] + bg, 0.f);
-      asm volatile("" : "+v"(v));
-      acc[j][reg] = v;
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(fmaxf(acc[j][4 * g] + bg4[g].x, 0.f), fmaxf(acc[j][4 * g + 1] + bg4[g].y, 0.f),
+                             fmaxf(acc[j][4 * g + 2] + bg4[g].z, 0.f), fmaxf(acc[j][4 * g + 3] + bg4[g].w, 0.f));
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+      acc[j][4 * g] = v.x; acc[j][4 * g + 1] = v.y; acc[j][4 * g + 2] = v.z; acc[j][4 * g + 3] = v.w;
     }
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    float d0v = acc[PT_FT][reg] + bd, d1v = acc[PT_FT + 1][reg] + bd;
-    asm volatile("" : "+v"(d0v));
-    asm volatile("" : "+v"(d1v));
-    acc[PT_FT][reg] = d0v; acc[PT_FT + 1][reg] = d1v;
-  }
+  for (int t = PT_FT; t < PT_FT + 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(acc[t][4 * g] + bd4[g].x, acc[t][4 * g + 1] + bd4[g].y, acc[t][4 * g + 2] + bd4[g].z, acc[t][4 * g + 3] + bd4[g].w);
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+      acc[t][4 * g] = v.x; acc[t][4 * g + 1] = v.y; acc[t][4 * g + 2] = v.z; acc[t][4 * g + 3] = v.w;
+    }
   const size_t pair0 = (size_t)b * (L - 1) + t0;
+  const bool pix_ok = q0 + r32 < HW;
 #pragma unroll
   for (int j = 0; j + 1 < PT_FT; ++j) {
-    if (j + 1 < nf) {
-      float* mrow = S.M + ((pair0 + j) * HW + q0) * S.m_cs + S.m_coff + kDownCh + wave * 32 + r32;
+    if (j + 1 < nf && pix_ok) {
+      float* mrow = S.M + ((pair0 + j) * HW + q0 + r32) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * h;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int px = acc_row(reg, h);
-        if (q0 + px < HW) mrow[(size_t)px * S.m_cs] = acc[j + 1][reg] - acc[j][reg];
-      }
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(mrow + 8 * g) = make_float4(acc[j + 1][4 * g] - acc[j][4 * g], acc[j + 1][4 * g + 1] - acc[j][4 * g + 1],
+                                                                acc[j + 1][4 * g + 2] - acc[j][4 * g + 2], acc[j + 1][4 * g + 3] - acc[j][4 * g + 3]);
     }
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int j = wave + 4 * half;
     // the frame shared with the next temporal group belongs to that group
-    if (j < nf && (last_group || j < PT_FT - 1)) {
+    if (j < nf && (last_group || j < PT_FT - 1) && pix_ok) {
       const int dr = pt_down_row(b * L + t0 + j, L, p.P, p.slice_mode);
       if (dr >= 0) {
-        float* drow = S.D + ((size_t)dr * HW + q0) * kDownCh + r32;
+        float* drow = S.D + ((size_t)dr * HW + q0 + r32) * kDownCh + 4 * h;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int px = acc_row(reg, h);
-          if (q0 + px < HW) drow[(size_t)px * kDownCh] = acc[PT_FT + half][reg];
-        }
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(drow + 8 * g) = make_float4(acc[PT_FT + half][4 * g], acc[PT_FT + half][4 * g + 1],
+                                                                  acc[PT_FT + half][4 * g + 2], acc[PT_FT + half][4 * g + 3]);
       }
     }
   }
