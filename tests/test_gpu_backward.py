@@ -285,7 +285,7 @@ def test_off_units_module_autograd(rt, variant):
     (5, 3, spec.VARIANT_RGB, "fp32", spec.SLICE_PER_CLIP, False),     # P % 4 != 0: partial 196-pixel groups in the patch conv
 ])
 def test_odd_shapes_forward_and_backward(rt, B, L, variant, prec, slice_mode, cons):
-    """Shapes off the benchmark grid (tools/fuzz_shapes.py draws more of them): whole forward and units backward."""
+    """Shapes off the benchmark grid (tests/tools/fuzz_shapes.py draws more of them): whole forward and units backward."""
     P = B * (L - 1)
     feats = synth.make_features(B, L, 9)
     wnp = synth.make_weights(variant, seed=0xBEEF + B + L)

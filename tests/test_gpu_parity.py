@@ -21,7 +21,7 @@ from oracle import off_oracle as orc
 pytestmark = pytest.mark.gpu
 RTOL_NORTH_STAR = 1e-3
 RTOL = 2e-4
-PRECISIONS = ["fp32", "bf16x3"]   # bf16x3: split-fp32 on the bf16 matrix cores, measured ~1-3e-5 (tools/precision_report.py)
+PRECISIONS = ["fp32", "bf16x3"]   # bf16x3: split-fp32 on the bf16 matrix cores, measured ~1-3e-5 (tests/tools/precision_report.py)
 
 
 def rel_err(a, b):

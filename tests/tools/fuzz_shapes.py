@@ -1,7 +1,7 @@
 """Shape fuzz on the GPU: forward (both variants, both precisions, both slice modes) and units backward against the oracle
-for random (B, L).  Test-infrastructure use of the oracle only.   python tools/fuzz_shapes.py [n_cases] [seed]"""
+for random (B, L).  Test-infrastructure use of the oracle only.   python tests/tools/fuzz_shapes.py [n_cases] [seed]"""
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

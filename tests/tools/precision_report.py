@@ -1,9 +1,9 @@
 """Measured error of the two arithmetic modes against the oracle and the fp64-accumulating C
-oracle on the golden configurations (GPU only).  python tools/precision_report.py"""
+oracle on the golden configurations (GPU only).  python tests/tools/precision_report.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
