@@ -179,6 +179,7 @@ int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_i
  * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), 6 / 7 = the LDS-patch kernel (bf16x3, k x k
  * convs whose 196-pixel output groups come from a 28x28 / four 14x14 / one 14x14 / four 7x7 input patch: 7x7s2@28,
  * 5x5s2@14, 3x3s1@14, 3x3s1@7; 128 / 64 output channels per block; splitk then splits the channel chunks),
+ * 10 = its half-chunk form (16-channel patches, 64 channels per block, 7x7s2@28 and 5x5s2@14: two blocks per CU),
  * < 0 = automatic; splitk >= 1
  * K-slices whose fp32 partial slabs [splitk][M][Co] go to `partial` (summed in slice order by
  * a second launch, so results are bit-reproducible); splitk < 1 = automatic; precision = enum

@@ -56,7 +56,7 @@ const int kTunedP384[kNumConvs][2] = {
     {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
-    {1, 6}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},   // fusion @28
+    {10, 4}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},  // fusion @28 (10 = half-chunk patch kernel)
     {0, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {7, 1},                           // fusion @14
     {7, 4}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // tile_cfg 7 = the LDS-patch kernel (64 channels per block): wins the two 3x3 convs whose patch is small enough

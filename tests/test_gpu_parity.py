@@ -125,6 +125,8 @@ PATCH_CASES = [  # (k, stride, H, Ci, Co, n_img, cfg, splitk): the four shapes o
     (7, 2, 28, 320, 64, 3, 7, 1), (7, 2, 28, 64, 128, 2, 6, 2), (5, 2, 14, 1056, 128, 6, 6, 3), (5, 2, 14, 96, 64, 9, 7, 1),
     (3, 1, 14, 64, 64, 3, 7, 2), (3, 1, 14, 128, 256, 2, 6, 1), (3, 1, 7, 832, 256, 7, 6, 4), (3, 1, 7, 128, 128, 5, 7, 1),
     (3, 1, 7, 256, 256, 8, 6, 3),
+    # tile_cfg 10: the half-chunk (16-channel) form for the 784-pixel patches
+    (7, 2, 28, 320, 64, 3, 10, 1), (7, 2, 28, 64, 128, 2, 10, 3), (5, 2, 14, 1056, 128, 6, 10, 4), (5, 2, 14, 96, 64, 9, 10, 1),
 ]
 
 

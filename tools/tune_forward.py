@@ -15,9 +15,7 @@ import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
-    "motion_conv_trans_28": [(1, 6), (9, 6), (9, 4), (9, 8), (9, 5)],
-    "motion_conv_trans_14": [(0, 6), (8, 6), (8, 4)],
-    "motion_conv_trans": [(7, 4), (8, 3), (5, 3)],
+    "motion_conv_trans_28": [(1, 6), (10, 4), (10, 2), (10, 5), (10, 10), (10, 20)],
 }
 
 
