@@ -50,3 +50,20 @@ def test_no_cpu_path():
     feats = [torch.zeros(s) for s in spec.feature_shapes(1, 3)]
     with pytest.raises(_lib.OffkError):
         m.RGB_OFF_forward(feats)
+
+
+@pytest.mark.parametrize("tag", ["rgb", "flow"])
+def test_off_units_trainable_mirror_keys(tag, golden_dir):
+    """OFFUnits (training side): its parameters are exactly the reference's unit tensors that
+    train_off.py:39-45 leaves trainable, under the reference's keys; the Sobel weight of the Flow variant is frozen
+    (util.py:72); no CPU path."""
+    want = {k: s for k, s in ref_off_keys(tag, golden_dir).items()
+            if k.startswith(spec.UNIT_PARAM_PREFIXES) or k == spec.SOBEL_KEY}
+    m = off_module.OFFUnits(2, 3, tag)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    assert trainable == {k for k in want if k != spec.SOBEL_KEY}
+    assert m.param_keys == [k for k in spec.weight_shapes(m.variant) if k.startswith(spec.UNIT_PARAM_PREFIXES)]
+    with pytest.raises(_lib.OffkError):
+        m([torch.zeros(s) for s in spec.feature_shapes(2, 3)])
