@@ -453,3 +453,18 @@ def test_fused_units_path_bit_identical(rt, prec, B, L, monkeypatch):
         parts.append(grp)
     for a, b in zip(ref, h1.forward(parts)):
         assert torch.equal(a, b)
+
+
+def test_test_time_shape_plans_agree_across_precisions(rt):
+    """The reference's test-time shape (10 crops x 25 segments, test_rgb_off.py:24-25 -> P = 240) runs on its own tuned
+    plan table (patch-kernel tiles included).  The exact-fp32 mode (different kernels, different plans) is the check:
+    both modes are pinned to the oracle at other sizes, here they must agree to bf16x3 accuracy."""
+    B, L = 10, 25
+    feats = [dev(f) for f in synth.make_features(B, L, 6)]
+    h32, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="fp32")
+    hb3, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
+    a = h32.forward(feats)
+    b = hb3.forward(feats)
+    for x, y in zip(a, b):
+        assert rel_err(y, x) < RTOL
+    assert torch.equal(b[0], hb3.forward(feats)[0])
