@@ -15,16 +15,13 @@ import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
-    "motion_conv_trans_28": [(3, 4), (1, 4), (1, 6), (10, 2), (10, 4), (3, 8)],
-    "motion_conv_trans_14": [(0, 8), (0, 4), (4, 8), (0, 12), (4, 4)],
-    "motion_conv_trans": [(5, 8), (7, 4), (7, 2), (0, 6), (0, 8), (5, 3)],
-    "motion_conv3_trans_14b": [(4, 1), (7, 1), (4, 2), (1, 1)],
-    "motion_conv2_trans": [(4, 2), (0, 3), (7, 1), (7, 2), (4, 3)],
-    "motion_conv2_trans_14a": [(3, 1), (4, 1), (7, 1)],
-    "motion_conv2_trans_14b": [(3, 1), (4, 1), (7, 1)],
-    "motion_conv2_trans_28a": [(3, 1), (1, 1), (7, 1)],
-    "motion_conv2_trans_28b": [(3, 1), (1, 1), (7, 1)],
-    "motion_conv2_trans_28c": [(3, 1), (1, 1), (7, 1)],
+    "motion_conv_trans_28": [(3, 3), (1, 3), (1, 6), (3, 6), (2, 3)],
+    "motion_conv_trans_14": [(4, 12), (0, 6), (4, 6), (0, 12), (1, 6)],
+    "motion_conv_trans": [(0, 6), (4, 6), (5, 3), (0, 3), (4, 3)],
+    "motion_conv3_trans_14b": [(4, 1), (0, 1), (1, 1), (3, 1)],
+    "motion_conv2_trans": [(4, 3), (0, 3), (3, 1), (4, 2)],
+    "motion_conv2_trans_14a": [(0, 3), (3, 1), (4, 1)],
+    "motion_conv2_trans_14b": [(0, 3), (3, 1), (4, 1)],
 }
 
 
