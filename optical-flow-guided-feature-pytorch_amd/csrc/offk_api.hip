@@ -58,7 +58,7 @@ const int kTunedP384[kNumConvs][2] = {
 const int kTunedP384B3[kNumConvs][2] = {
     {10, 4}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},  // fusion @28 (10 = half-chunk patch kernel)
     {0, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {7, 1},                           // fusion @14
-    {7, 4}, {4, 1}, {0, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+    {7, 4}, {4, 1}, {7, 1}, {3, 1}, {3, 1}};                                                   // fusion @7
 // tile_cfg 7 = the LDS-patch kernel (64 channels per block): wins the two 3x3 convs whose patch is small enough
 // for two blocks per CU (3x3 128->512 and 3x3 832->256 at 7x7)
 // (re-tuned inside the whole forward with tools/tune_forward.py after the bf16x3 kernels were bounded to 128
@@ -117,7 +117,7 @@ struct offk_handle {
   float* merged_w[3] = {};
   float* merged_wb3[3] = {};
   float* merged_b[3] = {};
-  int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};
+  int merged_cfg[3] = {3, 3, 0}, merged_sk[3] = {1, 1, 1};   // merged_7 (512 -> 1024): the 128x128 tile, in-situ sweep
   bool merged_dirty = true;
   // the 28- and 14-heads only depend on sum_28c / sum_14b: they run on a side stream beside the later
   // fusion stages and are joined back into the caller's stream before offk_forward returns

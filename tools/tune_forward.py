@@ -15,13 +15,23 @@ import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
-    "motion_conv_trans_28": [(3, 3), (1, 3), (1, 6), (3, 6), (2, 3)],
-    "motion_conv_trans_14": [(4, 12), (0, 6), (4, 6), (0, 12), (1, 6)],
-    "motion_conv_trans": [(0, 6), (4, 6), (5, 3), (0, 3), (4, 3)],
-    "motion_conv3_trans_14b": [(4, 1), (0, 1), (1, 1), (3, 1)],
-    "motion_conv2_trans": [(4, 3), (0, 3), (3, 1), (4, 2)],
-    "motion_conv2_trans_14a": [(0, 3), (3, 1), (4, 1)],
-    "motion_conv2_trans_14b": [(0, 3), (3, 1), (4, 1)],
+    "motion_conv1_trans_28a": [(3, 1), (1, 1)],
+    "motion_conv1_trans_28b": [(3, 1), (1, 1)],
+    "motion_conv1_trans_28c": [(3, 1), (1, 1)],
+    "motion_conv3_trans_28b": [(3, 1), (1, 1), (4, 1), (0, 1)],
+    "motion_conv3_trans_28c": [(3, 1), (1, 1), (4, 1), (0, 1)],
+    "merged_28a": [(3, 1), (1, 1), (4, 1), (0, 1)],
+    "motion_conv1_trans_14a": [(3, 1), (4, 1), (1, 1)],
+    "merged_14a": [(3, 1), (1, 1), (4, 1), (0, 1), (5, 1)],
+    "motion_conv1_trans_14b": [(3, 1), (4, 1), (1, 1)],
+    "motion_conv1_trans": [(4, 1), (3, 1), (1, 1), (0, 1)],
+    "merged_7": [(3, 1), (1, 1), (4, 1), (0, 1), (5, 1)],
+    "motion_conv2_trans_14a": [(4, 1), (7, 1), (3, 1)],
+    "motion_conv2_trans_14b": [(4, 1), (7, 1), (3, 1)],
+    "motion_conv2_trans": [(0, 3), (7, 2), (7, 1), (4, 3)],
+    "motion_conv_trans": [(7, 4), (7, 2), (7, 3), (5, 3)],
+    "motion_conv_trans_14": [(0, 6), (0, 12), (0, 4), (0, 8)],
+    "motion_conv_trans_28": [(10, 4), (10, 5), (10, 3), (1, 6)],
 }
 
 
