@@ -524,8 +524,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WrParams p) {
   const int role = blockIdx.x - wblocks;          // 0: the two biases, 1..10: depthwise tap rows / bias
   if (role == 0) {
     if (tid < kUnitCh) {
-      float s = 0.f;
-      for (int k = 0; k < S.nchunks; ++k) s += S.bpart[(size_t)k * kUnitCh + tid];
+      // four interleaved accumulators (independent load chains), combined in a fixed order
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int k = 0;
+      for (; k + 3 < S.nchunks; k += 4) {
+        a0 += S.bpart[(size_t)k * kUnitCh + tid];
+        a1 += S.bpart[(size_t)(k + 1) * kUnitCh + tid];
+        a2 += S.bpart[(size_t)(k + 2) * kUnitCh + tid];
+        a3 += S.bpart[(size_t)(k + 3) * kUnitCh + tid];
+      }
+      for (; k < S.nchunks; ++k) a0 += S.bpart[(size_t)k * kUnitCh + tid];
+      const float s = ((a0 + a1) + a2) + a3;
       float* dst = tid < kGenCh ? S.gen_b + tid : S.down_b + (tid - kGenCh);
       *dst = (p.accumulate ? *dst : 0.f) + s;
     }
@@ -535,9 +544,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WrParams p) {
   // 32 channels x 8 interleaved slices of the S-block partials, slices then summed in order
   __shared__ float red[8][kDownCh];
   const int j = role - 1, c = tid & 31, sl = tid >> 5;
-  float s = 0.f;
-  for (int k = sl; k < S.nsblocks; k += 8) s += S.dw_part[((size_t)k * 10 + j) * kDownCh + c];
-  red[sl][c] = s;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // independent load chains, fixed combine order
+  int k = sl;
+  for (; k + 24 < S.nsblocks; k += 32) {
+    a0 += S.dw_part[((size_t)k * 10 + j) * kDownCh + c];
+    a1 += S.dw_part[((size_t)(k + 8) * 10 + j) * kDownCh + c];
+    a2 += S.dw_part[((size_t)(k + 16) * 10 + j) * kDownCh + c];
+    a3 += S.dw_part[((size_t)(k + 24) * 10 + j) * kDownCh + c];
+  }
+  for (; k < S.nsblocks; k += 8) a0 += S.dw_part[((size_t)k * 10 + j) * kDownCh + c];
+  red[sl][c] = ((a0 + a1) + a2) + a3;
   __syncthreads();
   if (tid < kDownCh) {
     float t = 0.f;
