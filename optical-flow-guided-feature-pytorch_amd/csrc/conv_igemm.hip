@@ -829,11 +829,9 @@ static hipError_t launch_patch16(ConvArgs a, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(((NP + 1) * 32 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 32);
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_patch16_kernel<KH, S, W>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   a.gm = (a.M + 195) / 196;
   a.gn = a.Co / BN;
@@ -852,11 +850,9 @@ static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(((NP + 1) * 64 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 64);
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_patch_kernel<KH, S, W, NT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   a.gm = (a.M + 195) / 196;
   a.gn = a.Co / BN;
@@ -886,12 +882,9 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr size_t lds = PREC == 0 ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64;
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN, PREC>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;

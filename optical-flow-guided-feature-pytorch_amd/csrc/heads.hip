@@ -11,7 +11,24 @@
 #include "offk_common.h"
 #include "offk_internal.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace offk {
+
+hipError_t lds_attr_once(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kernel, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({kernel, dev});
+  return e;
+}
 
 constexpr int HEAD_MAX_C = 1024;
 

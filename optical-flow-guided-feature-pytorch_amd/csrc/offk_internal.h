@@ -6,6 +6,10 @@
 
 namespace offk {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): the attribute is per device, a process may drive
+// several (two_stream.py, tests); heads.hip implements it
+hipError_t lds_attr_once(const void* kernel, int bytes);
+
 constexpr int OFFK_CONV_RELU_IN_ = 1, OFFK_CONV_RELU_PRE_ = 2, OFFK_CONV_RELU_POST_ = 4;
 constexpr int kNumSites = 9;
 constexpr int kGenCh = 128, kDownCh = 32, kUnitCh = 160;

@@ -356,12 +356,9 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   } else if (!pc) {
     hipLaunchKernelGGL((pw_tdiff_kernel<1, 0>), dim3(p.total_blocks), dim3(256), kStageB3, st, p);
   } else {
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kStageB3));
+    {
+      hipError_t e = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1>), (int)(2 * kStageB3));
       if (e != hipSuccess) return e;
-      attr_done = true;
     }
     hipLaunchKernelGGL((pw_tdiff_kernel<1, 1>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
   }

@@ -226,7 +226,7 @@ hipError_t units_bwd_launch(const UbParams& p, hipStream_t st) {
   }
   const size_t lds = (2 * tile_px + 9 + 40) * kDownCh * sizeof(float);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(units_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(units_bwd_kernel), (int)lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(units_bwd_kernel, dim3(p.total_s + p.total_t), dim3(UB_THREADS), lds, st, p);
