@@ -468,3 +468,16 @@ def test_test_time_shape_plans_agree_across_precisions(rt):
     for x, y in zip(a, b):
         assert rel_err(y, x) < RTOL
     assert torch.equal(b[0], hb3.forward(feats)[0])
+
+
+def test_forward_without_the_28_head(rt):
+    """out28 = NULL (the reference never returns the 28x28 head, RGB_OFF.py:860): the other two logits are unchanged and
+    no side-stream work is left dangling."""
+    B, L = 2, 3
+    h, _ = make_handle(rt, B, L, spec.VARIANT_FLOW, precision="bf16x3")
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    a7, a14, a28 = h.forward(feats)
+    b7, b14, b28 = h.forward(feats, want28=False)
+    torch.cuda.synchronize()
+    assert b28 is None and a28 is not None
+    assert torch.equal(a7, b7) and torch.equal(a14, b14)
