@@ -171,6 +171,20 @@ class OFFUnits(nn.Module):
         mod, attr = key.rsplit(".", 1)
         return getattr(getattr(self, mod), attr)
 
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Takes a reference-format checkpoint: the unit keys are used, every other key (backbone, fusion stages,
+        heads) is ignored; a DataParallel 'module.' prefix is accepted (test_flow_off.py:52-58)."""
+        own = set(self.state_dict().keys())
+        sd = {}
+        for k, v in state_dict.items():
+            kk = k[7:] if k.startswith("module.") else k
+            if kk in own:
+                sd[kk] = v
+        missing = sorted(own - set(sd))
+        if strict and missing:
+            raise KeyError("missing OFF unit weights: %s" % ", ".join(missing[:5]))
+        return super().load_state_dict(sd, strict=False, **kw)
+
     def _handle(self, device, params):
         if self._rt is None or self._rt.device != torch.device(device):
             self._rt = runtime.OffForward(self.batch, self.length, self.variant, self.slice_mode, False,

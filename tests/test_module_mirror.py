@@ -67,3 +67,10 @@ def test_off_units_trainable_mirror_keys(tag, golden_dir):
     assert m.param_keys == [k for k in spec.weight_shapes(m.variant) if k.startswith(spec.UNIT_PARAM_PREFIXES)]
     with pytest.raises(_lib.OffkError):
         m([torch.zeros(s) for s in spec.feature_shapes(2, 3)])
+    # a whole reference-format checkpoint (with the DataParallel prefix) loads: foreign keys are ignored
+    full = {"module." + k: torch.full(s, 0.25) for k, s in ref_off_keys(tag, golden_dir).items()}
+    full["module.conv1_7x7_s2.weight"] = torch.zeros(64, 3, 7, 7)
+    m.load_state_dict(full)
+    assert float(m.motion_conv_gen_5b.weight.mean()) == 0.25
+    with pytest.raises(KeyError):
+        m.load_state_dict({k: v for k, v in full.items() if "motion_spatial_down_3c" not in k})
