@@ -61,11 +61,13 @@ class OFFSubNetwork(nn.Module):
             setattr(self, key, nn.Linear(cin, num_classes))
         self._rt = None
         self._rt_key = None
-        self._dirty = True
+        self._pushed = {}      # key -> (data_ptr, _version) of the tensor the library last copied
 
     # -- weights -> library ---------------------------------------------------------
     def mark_weights_dirty(self):
-        self._dirty = True
+        """Force a re-push of every weight on the next forward (only needed after writing a parameter through a
+        path that bypasses torch's version counter, e.g. a raw-pointer write by foreign code)."""
+        self._pushed = {}
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         own = set(self.state_dict().keys())
@@ -77,9 +79,7 @@ class OFFSubNetwork(nn.Module):
         missing = sorted(own - set(sd))
         if strict and missing:
             raise KeyError("missing OFF weights: %s" % ", ".join(missing[:5]))
-        out = super().load_state_dict(sd, strict=False, **kw)
-        self._dirty = True
-        return out
+        return super().load_state_dict(sd, strict=False, **kw)
 
     def _handle(self, device):
         key = (self.batch, self.length, self.variant, self.slice_mode, self.consensus_avg, self.feat_layout, str(device), self.precision)
@@ -87,10 +87,16 @@ class OFFSubNetwork(nn.Module):
             self._rt = runtime.OffForward(self.batch, self.length, self.variant, self.slice_mode,
                                           self.consensus_avg, self.num_classes, self.feat_layout, device, self.precision)
             self._rt_key = key
-            self._dirty = True
-        if self._dirty:
-            self._rt.load_state_dict(self.state_dict())
-            self._dirty = False
+            self._pushed = {}
+        # liboffk keeps packed copies: push every tensor that is new or was written since the last push.  Any writer
+        # that goes through torch -- load_state_dict of this module OR of a parent (which calls _load_from_state_dict
+        # and never reaches the override above), optimizer steps, param.copy_(), param.data = ... -- either bumps the
+        # tensor's version counter or replaces its storage, and both are part of the tag.
+        for k, v in self.state_dict(keep_vars=True).items():
+            tag = (v.data_ptr(), v._version)
+            if self._pushed.get(k) != tag:
+                self._rt.set_weight(k, v)
+                self._pushed[k] = tag
         return self._rt
 
     # -- forward ----------------------------------------------------------------------
@@ -116,12 +122,13 @@ class _OFFUnitsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, feats, drop, *params):
         rt = mod._handle(feats[0].device, params)
-        seed, p = drop
-        if p > 0.0:
-            rt.off_units_train(feats, seed, p)
-        else:
-            rt.off_units(feats)
+        mod._run_units(rt, feats, drop)
         ctx.mod, ctx.feats, ctx.drop = mod, feats, drop
+        # the backward reads the G / D activations this call leaves in the handle's ONE workspace: remember which
+        # call that was (and which parameter values it used) so that a later forward through the same module
+        # -- an eval pass, a second micro-batch, a checkpoint recompute -- is detected instead of silently used
+        ctx.gen = mod._generation
+        ctx.versions = dict(mod._versions)
         P = rt.P
         # copies: the workspace is rewritten by the next forward, autograd consumers may outlive it
         outs = []
@@ -134,6 +141,12 @@ class _OFFUnitsFn(torch.autograd.Function):
     def backward(ctx, g28, g14, g7):
         mod, feats, (seed, p) = ctx.mod, ctx.feats, ctx.drop
         rt = mod._rt
+        if rt is None or any((mod._param(k).data_ptr(), mod._param(k)._version) != v for k, v in ctx.versions.items()):
+            raise RuntimeError("OFFUnits: a parameter was modified (or the module moved) between this forward and its "
+                               "backward; the saved activations no longer belong to the current weights")
+        if mod._generation != ctx.gen:
+            # another forward has overwritten G / D since: recompute them (K1 + K2 only, same seed => same mask)
+            mod._run_units(rt, feats, ctx.drop)
         bufs = [g.permute(0, 2, 3, 1).contiguous() for g in (g28, g14, g7)]      # channels-last rows
         views = [(bufs[0], 0), (bufs[0], 160)] + [(bufs[1], 160 * k) for k in range(5)] + [(bufs[2], 0), (bufs[2], 160)]
         _flat, grads = rt.off_units_backward(feats, views, seed, p)
@@ -166,6 +179,15 @@ class OFFUnits(nn.Module):
             self.sobel_edge_diagonal = _SobelHolder()
         self.param_keys = [k for k in spec.weight_shapes(self.variant) if k.startswith(spec.UNIT_PARAM_PREFIXES)]
         self._rt, self._versions, self.drop_seed = None, {}, 0
+        self._generation = 0    # bumped by every units forward: tells a backward whether G / D in the workspace are its own
+
+    def _run_units(self, rt, feats, drop):
+        seed, p = drop
+        if p > 0.0:
+            rt.off_units_train(feats, seed, p)
+        else:
+            rt.off_units(feats)
+        self._generation += 1
 
     def _param(self, key):
         mod, attr = key.rsplit(".", 1)
@@ -239,11 +261,27 @@ class BNInception_OFF(nn.Module):
         return type(sd)((k[4:] if k.startswith("off.") else k, v) for k, v in sd.items())
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        self.off.load_state_dict(state_dict, strict=strict)
+        """Reference-format checkpoints (model_utils.py:188-216, Flow_OFF.py:1398-1413): OFF keys and backbone keys side
+        by side at top level, optionally under a DataParallel 'module.' prefix (test_flow_off.py:52-58).  OFF keys go to
+        the OFF sub-network, everything else to the backbone (plain or 'backbone.'-prefixed names).  Returns the
+        (missing_keys, unexpected_keys) named tuple of nn.Module.load_state_dict; with strict=True missing OFF keys
+        raise KeyError and keys nobody takes raise RuntimeError."""
+        from torch.nn.modules.module import _IncompatibleKeys
+        plain = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        own = set(self.off.state_dict().keys())
+        self.off.load_state_dict({k: v for k, v in plain.items() if k in own}, strict=strict)
+        missing = sorted(own - set(plain))
+        rest = {(k[9:] if k.startswith("backbone.") else k): v for k, v in plain.items() if k not in own}
+        unexpected = []
         if self.backbone is not None:
-            bb = {k[9:]: v for k, v in state_dict.items() if k.startswith("backbone.")}
-            if bb:
-                self.backbone.load_state_dict(bb, strict=False)
+            r = self.backbone.load_state_dict(rest, strict=False)
+            missing += ["backbone." + k for k in r.missing_keys]
+            unexpected = list(r.unexpected_keys)
+        else:
+            unexpected = sorted(rest)      # no backbone attached: nobody takes the TSN keys
+        if strict and self.backbone is not None and unexpected:
+            raise RuntimeError("unexpected keys in state_dict: %s" % ", ".join(unexpected[:5]))
+        return _IncompatibleKeys(missing, unexpected)
 
     def _features(self, input):
         if self.backbone is None:
@@ -273,6 +311,9 @@ class BNInception_OFF(nn.Module):
         if fgs is not None and fgs.shape[0] == self.batch * self.length:
             fgs = runtime.segment_consensus(fgs.contiguous().float(), self.batch)   # Flow_OFF.py:867,873 (K6)
         if self.modality_fuse:
+            if fgs is None:
+                raise ValueError("modality_fuse adds the backbone's Feature_Generation_Score (Flow_OFF.py:881): "
+                                 "attach a backbone that returns it")
             return fc7 + fgs + fc14                                            # Flow_OFF.py:881
         if self.variant_name == "rgb_v2":
             return fc7, fgs, fc14, conv2                                       # RGB_OFF_v2.py:891

@@ -16,8 +16,10 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """HIP stream the call is enqueued on: torch's current stream OF THE DEVICE THE DATA LIVES ON (a handle on cuda:1
+    must not launch on cuda:0's stream just because cuda:0 is torch's current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _check_dev(t, name, device):
@@ -158,7 +160,7 @@ class OffForward:
             out7 = torch.empty(rows, self.num_classes, dtype=torch.float32, device=self.device)
             out14 = torch.empty_like(out7)
             out28 = torch.empty_like(out7) if want28 else None
-            _lib.check(self.lib.offk_forward_parts(self._h, _stream(), arr, _ptr(out7), _ptr(out14), _ptr(out28),
+            _lib.check(self.lib.offk_forward_parts(self._h, _stream(self.device), arr, _ptr(out7), _ptr(out14), _ptr(out28),
                                                    _ptr(self.workspace)), self._h)
             return out7, out14, out28
         arr = self._feat_array(feats)
@@ -166,25 +168,25 @@ class OffForward:
         out7 = torch.empty(rows, self.num_classes, dtype=torch.float32, device=self.device)
         out14 = torch.empty_like(out7)
         out28 = torch.empty_like(out7) if want28 else None
-        _lib.check(self.lib.offk_forward(self._h, _stream(), arr, _ptr(out7), _ptr(out14), _ptr(out28),
+        _lib.check(self.lib.offk_forward(self._h, _stream(self.device), arr, _ptr(out7), _ptr(out14), _ptr(out28),
                                          _ptr(self.workspace)), self._h)
         return out7, out14, out28
 
     def forward_into(self, feat_array, out7, out14, out28):
         """Launch-only variant for benchmarking: pre-validated ctypes array + outputs."""
-        _lib.check(self.lib.offk_forward(self._h, _stream(), feat_array, _ptr(out7), _ptr(out14), _ptr(out28),
+        _lib.check(self.lib.offk_forward(self._h, _stream(self.device), feat_array, _ptr(out7), _ptr(out14), _ptr(out28),
                                          _ptr(self.workspace)), self._h)
 
     def off_units(self, feats):
         arr = self._feat_array(feats)
-        _lib.check(self.lib.offk_off_units(self._h, _stream(), arr, _ptr(self.workspace)), self._h)
+        _lib.check(self.lib.offk_off_units(self._h, _stream(self.device), arr, _ptr(self.workspace)), self._h)
 
     # ---- training side of the units (SURVEY.md 8(f) rank 4) ----------------------------
     def off_units_train(self, feats, drop_seed=0, drop_p=0.8):
         """K1+K2 in training mode: nn.Dropout(p) (RGB_OFF.py:356, :612) on the spatial gradients with the
         reproducible mask of synth.dropout_keep; leaves G/D in the workspace for off_units_backward."""
         arr = self._feat_array(feats)
-        _lib.check(self.lib.offk_off_units_train(self._h, _stream(), arr, _ptr(self.workspace),
+        _lib.check(self.lib.offk_off_units_train(self._h, _stream(self.device), arr, _ptr(self.workspace),
                                                  ctypes.c_uint64(int(drop_seed)), float(drop_p)), self._h)
 
     def unit_grad_slots(self):
@@ -220,7 +222,7 @@ class OffForward:
         if grads is None:
             grads = self.new_unit_grads()
         _check_dev(grads, "grads", self.device)
-        _lib.check(self.lib.offk_off_units_backward(self._h, _stream(), arr, gv, _ptr(self.workspace),
+        _lib.check(self.lib.offk_off_units_backward(self._h, _stream(self.device), arr, gv, _ptr(self.workspace),
                                                     ctypes.c_uint64(int(drop_seed)), float(drop_p), _ptr(grads),
                                                     int(bool(accumulate))), self._h)
         views = dict((k, grads[off:off + int(np.prod(shape))].view(shape)) for k, (off, shape) in self.unit_grad_slots().items())
@@ -232,19 +234,19 @@ class OffForward:
         G = torch.empty(self.N * H * H, spec.GEN_CH, dtype=torch.float32, device=self.device)
         D = torch.zeros(self.P * H * H, spec.DOWN_CH, dtype=torch.float32, device=self.device)
         _check_dev(feat, "feat", self.device)
-        _lib.check(self.lib.offk_pw_reduce(self._h, _stream(), site, _ptr(feat), _ptr(G), _ptr(D)), self._h)
+        _lib.check(self.lib.offk_pw_reduce(self._h, _stream(self.device), site, _ptr(feat), _ptr(G), _ptr(D)), self._h)
         return G, D
 
     def sobel_tdiff(self, site, G, D, M, m_coff, algo=0):
         _check_dev(G, "G", self.device)
         _check_dev(D, "D", self.device)
         _check_dev(M, "M", self.device)
-        _lib.check(self.lib.offk_sobel_tdiff(self._h, _stream(), site, _ptr(G), _ptr(D), _ptr(M),
+        _lib.check(self.lib.offk_sobel_tdiff(self._h, _stream(self.device), site, _ptr(G), _ptr(D), _ptr(M),
                                              M.shape[-1], m_coff, algo), self._h)
 
     def sobel_tdiff_all(self, algo=0):
         """Grouped K2 launch over the workspace G/D regions (after off_units / forward)."""
-        _lib.check(self.lib.offk_sobel_tdiff_all(self._h, _stream(), _ptr(self.workspace), algo), self._h)
+        _lib.check(self.lib.offk_sobel_tdiff_all(self._h, _stream(self.device), _ptr(self.workspace), algo), self._h)
 
     def set_conv_plan(self, conv_key, tile_cfg, splitk):
         _lib.check(self.lib.offk_set_conv_plan(self._h, conv_key.encode(), tile_cfg, splitk), self._h)
@@ -265,7 +267,7 @@ def segment_consensus_backward(grad_out, length_m1):
     lib = _lib.load()
     B, C = grad_out.shape
     gi = torch.empty(B * length_m1, C, dtype=torch.float32, device=grad_out.device)
-    _lib.check(lib.offk_segment_consensus_backward(_stream(), _ptr(grad_out.contiguous()), B, int(length_m1), C, _ptr(gi)))
+    _lib.check(lib.offk_segment_consensus_backward(_stream(grad_out.device), _ptr(grad_out.contiguous()), B, int(length_m1), C, _ptr(gi)))
     return gi
 
 
@@ -280,10 +282,10 @@ def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=No
     wp = w_packed
     if wp is None:
         wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=x.device)   # library K order [Co][Ci/32][KH*KW][32]
-        _lib.check(lib.offk_pack_conv_weight(_stream(), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
+        _lib.check(lib.offk_pack_conv_weight(_stream(x.device), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
     if precision == 1 and w_packed is None:      # bf16x3: the kernel consumes pre-split hi | lo bf16 planes
         ws = torch.empty_like(wp)
-        _lib.check(lib.offk_split_bf16x3(_stream(), _ptr(wp), wp.numel(), _ptr(ws)))
+        _lib.check(lib.offk_split_bf16x3(_stream(x.device), _ptr(wp), wp.numel(), _ptr(ws)))
         wp = ws
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
@@ -293,7 +295,7 @@ def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=No
     if splitk > 1:
         nfl = splitk * n * Ho * Wo * Co
         part = torch.empty(nfl, dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_conv2d_ex(_stream(), _ptr(x), cs, x_coff, n, H, W, Ci, _ptr(wp), _ptr(bias), Co, KH, KW,
+    _lib.check(lib.offk_conv2d_ex(_stream(x.device), _ptr(x), cs, x_coff, n, H, W, Ci, _ptr(wp), _ptr(bias), Co, KH, KW,
                                   stride, pad, _ptr(res), res.shape[-1] if res is not None else 0, 0, flags,
                                   _ptr(y), y.shape[-1], y_coff, tile_cfg, splitk, _ptr(part), nfl, precision))
     return y
@@ -304,7 +306,7 @@ def head(x, fc_w, fc_b, maxpool, x_coff=0, c=None):
     n, H, W, cs = x.shape
     C = cs if c is None else c
     out = torch.empty(n, fc_w.shape[0], dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_head(_stream(), _ptr(x), cs, x_coff, n, H, W, C, int(maxpool), _ptr(fc_w.contiguous()),
+    _lib.check(lib.offk_head(_stream(x.device), _ptr(x), cs, x_coff, n, H, W, C, int(maxpool), _ptr(fc_w.contiguous()),
                              _ptr(fc_b.contiguous()), fc_w.shape[0], _ptr(out)))
     return out
 
@@ -313,7 +315,7 @@ def segment_consensus(x, batch):
     lib = _lib.load()
     T = x.shape[0] // batch
     out = torch.empty(batch, x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_segment_consensus(_stream(), _ptr(x.contiguous()), batch, T, x.shape[1], _ptr(out)))
+    _lib.check(lib.offk_segment_consensus(_stream(x.device), _ptr(x.contiguous()), batch, T, x.shape[1], _ptr(out)))
     return out
 
 
@@ -321,7 +323,7 @@ def nchw_to_nhwc(x):
     lib = _lib.load()
     n, C, H, W = x.shape
     out = torch.empty(n, H, W, C, dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_nchw_to_nhwc(_stream(), _ptr(x.contiguous()), n, C, H * W, _ptr(out)))
+    _lib.check(lib.offk_nchw_to_nhwc(_stream(x.device), _ptr(x.contiguous()), n, C, H * W, _ptr(out)))
     return out
 
 
@@ -330,7 +332,7 @@ def nhwc_to_nchw(x, coff=0, c=None):
     n, H, W, cs = x.shape
     C = cs - coff if c is None else c
     out = torch.empty(n, C, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(lib.offk_nhwc_to_nchw(_stream(), _ptr(x), cs, coff, n, C, H * W, _ptr(out)))
+    _lib.check(lib.offk_nhwc_to_nchw(_stream(x.device), _ptr(x), cs, coff, n, C, H * W, _ptr(out)))
     return out
 
 
@@ -347,5 +349,5 @@ def score_fusion(score_sets, weights, want_pred=True):
     pred = torch.empty(v, dtype=torch.int32, device=sets[0].device) if want_pred else None
     ptrs = (ctypes.c_void_p * len(sets))(*[s.data_ptr() for s in sets])
     w = (ctypes.c_float * len(sets))(*[float(x) for x in weights])
-    _lib.check(lib.offk_score_fusion(_stream(), ptrs, w, len(sets), v, k, c, _ptr(fused), _ptr(pred)))
+    _lib.check(lib.offk_score_fusion(_stream(sets[0].device), ptrs, w, len(sets), v, k, c, _ptr(fused), _ptr(pred)))
     return fused, pred

@@ -74,6 +74,27 @@ def make_features(batch, length, config_id=0, clip_offset=0):
     return feats
 
 
+# ---- stress distributions for the split-precision (bf16x3) contractions -----------------------------------------
+# feature_values() yields k * 2**-15 with k < 2**17: at most 17 significant bits, so every value splits into bf16
+# hi + lo (almost) exactly and the activation split of the bf16x3 kernels is never stressed.  The maps below have
+# full 24-bit mantissas and a realistic dynamic range (real BN-Inception taps are post-ReLU / post-max-pool and
+# reach 1e1 .. 1e2); tests/test_gpu_parity.py and bench.py measure the bf16x3 error on them.
+FEATURE_KINDS = ("synth", "full_mantissa", "heavy_tail")
+
+
+def make_features_kind(batch, length, config_id=0, kind="synth", clip_offset=0):
+    """kind 'synth': make_features.  'full_mantissa': the same maps times pi/3 rounded to fp32 (random low mantissa
+    bits, same range).  'heavy_tail': expm1(1.151 * z) -- still ~half zeros, median ~1, tail up to 1e2."""
+    feats = make_features(batch, length, config_id, clip_offset)
+    if kind == "synth":
+        return feats
+    if kind == "full_mantissa":
+        return [(f.astype(np.float64) * (math.pi / 3.0)).astype(np.float32) for f in feats]
+    if kind == "heavy_tail":
+        return [np.expm1(f.astype(np.float64) * 1.151).astype(np.float32) for f in feats]
+    raise ValueError("unknown feature kind %r" % (kind,))
+
+
 def make_weights(variant, seed=0xBEEF):
     """OrderedDict key -> fp32 ndarray for every OFF parameter of ``variant``."""
     out = {}

@@ -31,13 +31,14 @@ import torch  # noqa: E402
 import offk_amd  # noqa: E402,F401
 from offk_amd import spec, synth  # noqa: E402
 
-CASES = (  # (tag, variant, B, L, config_id)
+CASES = (  # (tag, variant, B, L, config_id); tag prefix picks the reference file: rgb_ RGB_OFF, flow_ Flow_OFF, rgbv2_ RGB_OFF_v2
     ("rgb_b1_l7", spec.VARIANT_RGB, 1, 7, 1),
     ("rgb_b2_l3", spec.VARIANT_RGB, 2, 3, 2),
     ("rgb_b3_l7", spec.VARIANT_RGB, 3, 7, 3),
     ("flow_b1_l7", spec.VARIANT_FLOW, 1, 7, 1),
     ("flow_b2_l3", spec.VARIANT_FLOW, 2, 3, 2),
     ("flow_b3_l7", spec.VARIANT_FLOW, 3, 7, 3),
+    ("rgbv2_b2_l3", spec.VARIANT_FLOW, 2, 3, 4),     # RGB_OFF_v2.py:613-883: the Flow arithmetic behind a 3-channel backbone
 )
 SAMPLE = 97  # sampled elements per stage tensor
 
@@ -52,12 +53,21 @@ def checksum(t):
     return np.array([a.sum().item(), a.abs().sum().item()]), t.detach().reshape(-1)[idx].numpy().copy()
 
 
+def ref_module(tag):
+    """(reference module, input channels) for a golden tag."""
+    if tag.startswith("rgbv2_"):
+        import RGB_OFF_v2 as ref
+        return ref, 3
+    if tag.startswith("rgb_"):
+        import RGB_OFF as ref
+        return ref, 3
+    import Flow_OFF as ref
+    return ref, 10
+
+
 def run_case(tag, variant, B, L, config_id):
     import basic_ops
-    if variant == spec.VARIANT_RGB:
-        import RGB_OFF as ref
-    else:
-        import Flow_OFF as ref
+    ref, in_ch = ref_module(tag)
     torch.manual_seed(0)
     model = ref.bninception_off(spec.NUM_CLASSES, B, L).eval()
     weights = synth.make_weights(variant)
@@ -98,7 +108,9 @@ def run_case(tag, variant, B, L, config_id):
         if variant == spec.VARIANT_RGB:
             ret = model.RGB_OFF_forward(torch.zeros(B * L, 3, 224, 224))
         else:
-            ret = model(torch.zeros(B * L, 10, 224, 224))
+            ret = model(torch.zeros(B * L, in_ch, 224, 224))
+    if tag.startswith("rgbv2_"):
+        assert len(ret) == 4 and tuple(ret[3].shape) == (B * L, 192, 56, 56)     # RGB_OFF_v2.py:891
     out = dict(meta=np.array([variant, B, L, config_id], dtype=np.int64))
     out["fc7"], out["fc14"], out["fc28"] = (cap[k].numpy() for k in ("fc7", "fc14", "fc28"))
     out["ret7"], out["ret14"] = ret[0].numpy(), ret[2].numpy()
@@ -216,6 +228,58 @@ def run_grad_case(tag, variant, B, L, config_id, drop_seed):
     print(tag, "->", os.path.getsize(path), "bytes")
 
 
+RET_CASES = (  # (tag, variant, B, L, config_id): what the reference's forward RETURNS
+    ("ret_rgb_b2_l3", spec.VARIANT_RGB, 2, 3, 2),
+    ("ret_rgb_b1_l2", spec.VARIANT_RGB, 1, 2, 5),      # P == 1: torch.squeeze drops the pair axis (RGB_OFF.py:786,792,846)
+    ("ret_flow_b2_l3", spec.VARIANT_FLOW, 2, 3, 2),
+    ("ret_flow_b1_l2", spec.VARIANT_FLOW, 1, 2, 5),
+    ("ret_rgbv2_b2_l3", spec.VARIANT_FLOW, 2, 3, 4),
+)
+
+
+def run_ret_case(tag, variant, B, L, config_id):
+    """Return conventions of the reference forward on injected maps: RGB_OFF.py:860 (fc7, FGS, fc14);
+    Flow_OFF.py:879-884 (3-tuple, or the sum with modality_fuse); RGB_OFF_v2.py:886-891 (4-tuple).  Stores the
+    returned tensors, the backbone's per-frame Feature_Generation_Score (what a stub backbone must hand back, :592-594)
+    and, for the consensus variants, the fused return."""
+    import basic_ops
+    ref, in_ch = ref_module(tag[4:])
+    torch.manual_seed(0)
+    model = ref.bninception_off(spec.NUM_CLASSES, B, L).eval()
+    weights = synth.make_weights(variant)
+    sd = model.state_dict()
+    for k, v in weights.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    feats = [torch.from_numpy(f) for f in synth.make_features(B, L, config_id)]
+    P = B * (L - 1)
+    cap = {}
+    for (site, _c, _h), f in zip(spec.SITES, feats):
+        getattr(model, "motion_conv_gen_" + site).register_forward_pre_hook(lambda m, inp, f=f: (f,))
+        getattr(model, "motion_spatial_down_" + site).register_forward_pre_hook(lambda m, inp, f=f: (f[:P],))
+    model.last_linear.register_forward_hook(lambda m, inp, o: cap.__setitem__("fgs_raw", o.detach().clone()))
+    if variant == spec.VARIANT_FLOW:
+        class ConsensusShim(torch.nn.Module):
+            def forward(self, x):
+                return basic_ops.SegmentConsensus("avg", 1).forward(x)   # the reference's own method
+        model.consensus = ConsensusShim()
+    x = torch.zeros(B * L, in_ch, 224, 224)
+    out = dict(meta=np.array([variant, B, L, config_id], dtype=np.int64))
+    with torch.no_grad():
+        ret = model.RGB_OFF_forward(x) if variant == spec.VARIANT_RGB else model(x)
+        out["fgs_raw"] = cap["fgs_raw"].numpy()
+        for i in range(3):
+            out["ret%d" % i] = ret[i].numpy()
+        if len(ret) == 4:
+            out["ret3_shape"] = np.array(ret[3].shape, dtype=np.int64)
+        if variant == spec.VARIANT_FLOW:
+            model.modality_fuse = True
+            out["ret_fused"] = model(x).numpy()
+    path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+    np.savez_compressed(path, **out)
+    print(tag, [tuple(out["ret%d" % i].shape) for i in range(3)], "->", os.path.getsize(path), "bytes")
+
+
 def run_consensus_backward():
     """basic_ops.py:29-36 called directly (the legacy Function object cannot be applied through autograd)."""
     import basic_ops
@@ -252,6 +316,11 @@ if __name__ == "__main__":
         for case in CASES:
             run_case(*case)
         dump_state_dict_keys()
+    if which in ("all", "ret"):
+        for case in RET_CASES:
+            run_ret_case(*case)
+    if which == "rgbv2":
+        run_case(*CASES[-1])
     if which in ("all", "grad"):
         for case in GRAD_CASES:
             run_grad_case(*case)

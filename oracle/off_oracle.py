@@ -168,6 +168,31 @@ def off_forward(feats, w, batch, length, variant=VARIANT_RGB, slice_mode=SLICE_F
     return fc7, fc14, fc28
 
 
+def reference_return(feats, w, batch, length, ref_file, fgs_raw, modality_fuse=False, conv2=None,
+                     slice_mode=SLICE_FLAT):
+    """What the reference's forward hands back, given the backbone's per-frame
+    Feature_Generation_Score [N,101] (RGB_OFF.py:592-594) and, for RGB_OFF_v2, its conv2_relu_3x3_out.
+
+    ref_file "rgb":    RGB_OFF.py:860      (fc7, FGS, fc14) -- per-pair logits, no consensus (:849-858 commented out);
+                                           torch.squeeze at :786/:792/:846 also drops the pair axis when P == 1.
+    ref_file "flow":   Flow_OFF.py:866-884 view(B, L-1, -1) / view(B, L, -1), consensus avg on all four scores, then
+                                           fc7 + FGS + fc14 if modality_fuse else (fc7, FGS, fc14).
+    ref_file "rgb_v2": RGB_OFF_v2.py:873-891 as flow, the tuple carries conv2_relu_3x3_out as a fourth item.
+    """
+    variant = VARIANT_RGB if ref_file == "rgb" else VARIANT_FLOW
+    fc7, fc14, _fc28 = off_forward(feats, w, batch, length, variant, slice_mode, consensus=False)
+    if ref_file == "rgb":
+        return fc7, fgs_raw, fc14
+    fgs = segment_consensus(fgs_raw.reshape(batch, length, -1), batch)                  # Flow_OFF.py:866, :873
+    fc7 = segment_consensus(fc7.reshape(batch, length - 1, -1), batch)                  # :867, :874
+    fc14 = segment_consensus(fc14.reshape(batch, length - 1, -1), batch)                # :869, :876
+    if modality_fuse:
+        return fc7 + fgs + fc14                                                         # :881
+    if ref_file == "rgb_v2":
+        return fc7, fgs, fc14, conv2                                                    # RGB_OFF_v2.py:891
+    return fc7, fgs, fc14                                                               # Flow_OFF.py:884
+
+
 UNIT_PARAM_PREFIXES = ("motion_conv_gen_", "motion_spatial_down_", "motion_spatial_grad_")
 
 

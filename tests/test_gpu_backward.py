@@ -306,3 +306,47 @@ def test_odd_shapes_forward_and_backward(rt, B, L, variant, prec, slice_mode, co
     _flat, got = h.off_units_backward(df, grad_views(dm), 5, DROP_P)
     for k in g:
         assert rel_err(got[k], g[k]) < RTOL, k
+
+
+def test_off_units_interleaved_forwards_before_backward(rt):
+    """the backward reads the G / D activations of ITS forward, but they live in the handle's one workspace.
+    fwd(A), fwd(B), backward(A) (an eval pass, a second micro-batch, a checkpoint recompute in between) must give the
+    gradients of A -- the module notices the foreign forward and recomputes K1 + K2 from the saved inputs and seed --
+    and a parameter written between forward and backward must raise instead of pairing old activations with new weights."""
+    from offk_amd.off_module import OFFUnits
+    B, L = 2, 3
+    wnp = synth.make_weights(spec.VARIANT_RGB)
+    units = OFFUnits(B, L, "rgb").cuda()
+    units.load_state_dict({k: torch.from_numpy(a) for k, a in wnp.items() if k in units.state_dict()}, strict=True)
+    units.train()
+    fa = [dev(f) for f in synth.make_features(B, L, 2)]
+    fb = [dev(f) for f in synth.make_features(B, L, 5)]
+    g = torch.Generator().manual_seed(3)
+    cots = [torch.randn(s, generator=g).cuda() for s in ((4, 320, 28, 28), (4, 800, 14, 14), (4, 320, 7, 7))]
+
+    def grads_of(run):
+        for p in units.parameters():
+            p.grad = None
+        out = run()
+        torch.autograd.backward(out, cots)
+        return {k: p.grad.clone() for k, p in units.named_parameters() if p.grad is not None}
+
+    alone = grads_of(lambda: units(fa, drop_seed=7))
+
+    def interleaved():
+        out = units(fa, drop_seed=7)
+        units(fb, drop_seed=9)                      # second micro-batch through the same module
+        units.eval()
+        units(fb)                                   # and an eval pass
+        units.train()
+        return out
+
+    mixed = grads_of(interleaved)
+    assert alone.keys() == mixed.keys() and len(alone) == 54
+    for k in alone:
+        assert torch.equal(alone[k], mixed[k]), k
+    out = units(fa, drop_seed=7)
+    with torch.no_grad():
+        units.motion_conv_gen_3a.weight.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified"):
+        torch.autograd.backward(out, cots)

@@ -230,7 +230,7 @@ def test_sobel_tdiff_vs_oracle(rt, site, variant, algo):
     assert torch.all(Mv[:, :160] == -3.0) and torch.all(Mv[:, 320:] == -3.0)
 
 
-GOLDEN = ["rgb_b1_l7", "rgb_b2_l3", "rgb_b3_l7", "flow_b1_l7", "flow_b2_l3", "flow_b3_l7"]
+GOLDEN = ["rgb_b1_l7", "rgb_b2_l3", "rgb_b3_l7", "flow_b1_l7", "flow_b2_l3", "flow_b3_l7", "rgbv2_b2_l3"]
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
@@ -257,11 +257,17 @@ def test_forward_vs_golden_and_oracle(rt, tag, golden_dir, prec):
     if "full_motion_5a" in g.files:
         got = h.region("fusion_7", 832).view(P, 7, 7, 832).permute(0, 3, 1, 2)[:, :160]
         assert rel_err(got, g["full_motion_5a"]) < RTOL
-    # logits are bias-dominated under default init: also pin the row-to-row signal
-    d = (out7 - out7.mean(0, keepdim=True)).cpu().double()
-    dr = torch.from_numpy(g["fc7"]).double()
-    dr = dr - dr.mean(0, keepdim=True)
-    assert ((d - dr).abs().max() / dr.abs().max()).item() < 5e-3
+    # logits are bias-dominated under default init: also pin the row-to-row signal, at the
+    # north_star tolerance (the signal is ~2.6 % of the logit magnitude, so this is ~40x stricter than the check above)
+    for out, key in ((out7, "fc7"), (out14, "fc14"), (out28, "fc28")):
+        if B * (L - 1) < 2:
+            continue
+        d = (out - out.mean(0, keepdim=True)).cpu().double()
+        dr = torch.from_numpy(g[key]).double()
+        dr = dr - dr.mean(0, keepdim=True)
+        sig_err = ((d - dr).abs().max() / dr.abs().max()).item()
+        print("%s %s %s: row-to-row signal error %.2e" % (tag, prec, key, sig_err))
+        assert sig_err < RTOL_NORTH_STAR, (key, sig_err)
 
 
 @pytest.mark.parametrize("tag", ["flow_b2_l3", "flow_b3_l7"])
@@ -396,6 +402,12 @@ def test_forward_from_inception_branch_parts(rt, prec):
     got = h.forward(parts)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+    # ... and the oracle's on the concatenated maps (RGB_OFF.py:395..590 cat, then :596-847)
+    with torch.no_grad():
+        want = orc.off_forward([torch.from_numpy(f) for f in feats], orc.to_torch_weights(synth.make_weights(spec.VARIANT_RGB)),
+                               B, L, spec.VARIANT_RGB, orc.SLICE_FLAT)
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < RTOL
     from offk_amd import _lib
     bad = list(parts)
     bad[0] = [dev(np.ascontiguousarray(feats[0][:, :48])), dev(np.ascontiguousarray(feats[0][:, 48:]))]
@@ -455,19 +467,25 @@ def test_fused_units_path_bit_identical(rt, prec, B, L, monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_test_time_shape_plans_agree_across_precisions(rt):
-    """The reference's test-time shape (10 crops x 25 segments, test_rgb_off.py:24-25 -> P = 240) runs on its own tuned
-    plan table (patch-kernel tiles included).  The exact-fp32 mode (different kernels, different plans) is the check:
-    both modes are pinned to the oracle at other sizes, here they must agree to bf16x3 accuracy."""
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("variant", [spec.VARIANT_RGB, spec.VARIANT_FLOW])
+def test_test_time_shape_vs_oracle(rt, variant, prec):
+    """The reference's eval shape: 10 crops x 25 segments per video, model built with batch = 10 (test_rgb_off.py:24-25,
+    :184; test_flow_off.py:29-30, :414) -> N = 250 frames, P = 240 pairs.  It runs on its own tuned plan table
+    (offk_api.hip kTunedP240*, LDS-patch tiles included), so it is checked against the oracle itself, both variants,
+    both arithmetic modes."""
     B, L = 10, 25
-    feats = [dev(f) for f in synth.make_features(B, L, 6)]
-    h32, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="fp32")
-    hb3, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
-    a = h32.forward(feats)
-    b = hb3.forward(feats)
-    for x, y in zip(a, b):
-        assert rel_err(y, x) < RTOL
-    assert torch.equal(b[0], hb3.forward(feats)[0])
+    feats_np = synth.make_features(B, L, 6)
+    h, w = make_handle(rt, B, L, variant, precision=prec)
+    got = h.forward([dev(f) for f in feats_np])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, variant, orc.SLICE_FLAT)
+    rows = B if variant == spec.VARIANT_FLOW else B * (L - 1)
+    for a, b in zip(got, want):
+        assert a.shape == (rows, 101)
+        assert rel_err(a, b) < RTOL
+    assert torch.equal(got[0], h.forward([dev(f) for f in feats_np])[0])
 
 
 def test_forward_without_the_28_head(rt):
@@ -481,3 +499,217 @@ def test_forward_without_the_28_head(rt):
     torch.cuda.synchronize()
     assert b28 is None and a28 is not None
     assert torch.equal(a7, b7) and torch.equal(a14, b14)
+
+
+# ---- round 2: inputs that stress the split-precision contractions (VERDICT r01 weak #1b) -------------------------
+
+STRESS_KINDS = ["full_mantissa", "heavy_tail"]
+
+
+@pytest.mark.parametrize("kind", STRESS_KINDS)
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_pw_reduce_on_full_range_inputs(rt, prec, kind):
+    """K1 on maps with 24-bit mantissas / values up to 1e2 (synth.make_features_kind): the bf16x3 activation split is
+    exercised for real.  Checked against an fp64 contraction, all nine sites."""
+    B, L = 2, 3
+    h, w = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    feats = synth.make_features_kind(B, L, 4, kind)
+    worst = 0.0
+    for site, (name, C, H) in enumerate(spec.SITES):
+        x = torch.from_numpy(feats[site])
+        G, D = h.pw_reduce(site, dev(x))
+        g_ref = torch.relu(F.conv2d(x.double(), w["motion_conv_gen_%s.weight" % name].double(), w["motion_conv_gen_%s.bias" % name].double()))
+        d_ref = F.conv2d(x[:B * (L - 1)].double(), w["motion_spatial_down_%s.weight" % name].double(),
+                         w["motion_spatial_down_%s.bias" % name].double())
+        eg = rel_err(G.view(B * L, H, H, 128).permute(0, 3, 1, 2), g_ref)
+        ed = rel_err(D.view(B * (L - 1), H, H, 32).permute(0, 3, 1, 2), d_ref)
+        worst = max(worst, eg, ed)
+    print("K1 %s on %s maps: worst error / max|out| over nine sites = %.2e" % (prec, kind, worst))
+    assert worst < RTOL
+
+
+@pytest.mark.parametrize("kind", STRESS_KINDS)
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_forward_on_full_range_inputs(rt, prec, kind):
+    """Whole forward (RGB variant, B = 3, L = 7, quirk Q1 active) on the stress maps against the oracle."""
+    B, L = 3, 7
+    feats_np = synth.make_features_kind(B, L, 3, kind)
+    h, w = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    got = h.forward([dev(f) for f in feats_np])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, spec.VARIANT_RGB, orc.SLICE_FLAT,
+                                   return_stages=True)
+    errs = [rel_err(a, b) for a, b in zip(got, want)]
+    P = B * (L - 1)
+    for name, ch, H in (("fusion_28", 320, 28), ("fusion_14", 1056, 14), ("fusion_7", 832, 7), ("sum_7", 1024, 7)):
+        errs.append(rel_err(h.region(name, ch).view(P, H, H, ch).permute(0, 3, 1, 2), st[name]))
+    d = (got[0] - got[0].mean(0, keepdim=True)).cpu().double()
+    dr = want[0].double() - want[0].double().mean(0, keepdim=True)
+    sig = ((d - dr).abs().max() / dr.abs().max()).item()
+    print("forward %s on %s maps: logits %.2e %.2e %.2e, stages %.2e %.2e %.2e %.2e, fc7 row-to-row signal %.2e"
+          % ((prec, kind) + tuple(errs) + (sig,)))
+    assert max(errs) < RTOL and sig < RTOL_NORTH_STAR
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_pw_reduce_cancellation_case(rt, prec):
+    """Weights orthogonal to the activations: every channel of a pixel carries the same value a(pixel) and every weight
+    row has zero sum, so the exact result is the bias and everything else is rounding.  The error of a contraction is
+    bounded by eps * sum_k |w_k x_k| (fp32 MFMA: eps ~ 2**-24 per term; bf16x3: 2**-16.5, lo*lo dropped), NOT by eps *
+    |result|: assert that backward-error bound and report the error relative to max|out| for DESIGN.md section 4."""
+    B, L, site = 2, 3, 5
+    name, C, H = spec.SITES[site]
+    wnp = synth.make_weights(spec.VARIANT_RGB)
+    for key in ("motion_conv_gen_%s.weight" % name, "motion_spatial_down_%s.weight" % name):
+        wk = wnp[key].astype(np.float64)
+        wnp[key] = (wk - wk.mean(axis=1, keepdims=True)).astype(np.float32)
+    h, w = make_handle(rt, B, L, spec.VARIANT_RGB, weights=wnp, precision=prec)
+    a = synth.make_features_kind(B, L, 4, "heavy_tail")[site][:, :1] + np.float32(0.5)          # [N,1,H,H], > 0
+    x = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(a, (B * L, C, H, H))))
+    G, D = h.pw_reduce(site, dev(x))
+    wd, bd = w["motion_spatial_down_%s.weight" % name].double(), w["motion_spatial_down_%s.bias" % name].double()
+    d_ref = F.conv2d(x[:B * (L - 1)].double(), wd, bd)
+    mag = F.conv2d(x[:B * (L - 1)].double().abs(), wd.abs())             # sum_k |w_k x_k|
+    Dn = D.view(B * (L - 1), H, H, 32).permute(0, 3, 1, 2).double().cpu()
+    err = (Dn - d_ref).abs()
+    backward = (err / mag).max().item()
+    forward = (err.max() / d_ref.abs().max()).item()
+    print("K1 %s cancellation case: max error / sum|w x| = %.2e, max error / max|out| = %.2e (out ~ bias, sum|w x| up to %.1f)"
+          % (prec, backward, forward, mag.max().item()))
+    assert backward < (2e-6 if prec == "fp32" else 4e-5)
+    if prec == "fp32":
+        assert forward < RTOL
+
+
+# ---- round 2: the drop-in class itself on the GPU (SURVEY.md 8a row A11; VERDICT r01 missing #1) -------------------
+
+class _StubBackbone(torch.nn.Module):
+    """Stands for the TSN backbone (out of scope, RGB_OFF.py:362-594): hands back the nine tap maps, the per-frame
+    Feature_Generation_Score the golden captured from the reference's own backbone and, for RGB_OFF_v2, conv2."""
+
+    def __init__(self, feats, fgs, conv2=None):
+        super().__init__()
+        self.feats, self.fgs, self.conv2 = feats, fgs, conv2
+
+    def forward(self, frames):
+        assert frames.shape[0] == self.fgs.shape[0]
+        return (self.feats, self.fgs) if self.conv2 is None else (self.feats, self.fgs, self.conv2)
+
+
+RET_GOLDEN = ["ret_rgb_b2_l3", "ret_rgb_b1_l2", "ret_flow_b2_l3", "ret_flow_b1_l2", "ret_rgbv2_b2_l3"]
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("tag", RET_GOLDEN)
+def test_bninception_off_mirror_returns_what_the_reference_returns(rt, tag, prec, golden_dir):
+    """off_module.BNInception_OFF -- the class a user of RGB_OFF.py / Flow_OFF.py / RGB_OFF_v2.py would switch to --
+    against the tensors the reference's own forward returned (oracle/gen_golden.py run_ret_case): tuple order
+    (7x7, backbone, 14x14; RGB_OFF.py:860), the P == 1 squeeze (:786), consensus (Flow_OFF.py:866-876), the
+    modality_fuse sum (:881) and the RGB_OFF_v2 4-tuple (RGB_OFF_v2.py:891)."""
+    from offk_amd import off_module
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    variant, B, L, cfg = (int(v) for v in g["meta"])
+    ref_file = tag.split("_")[1].replace("rgbv2", "rgb_v2")
+    feats = [dev(f) for f in synth.make_features(B, L, cfg)]
+    fgs = dev(g["fgs_raw"])
+    in_ch = 10 if ref_file == "flow" else 3
+    conv2 = torch.full((B * L, 192, 2, 2), 3.0, device="cuda") if ref_file == "rgb_v2" else None
+    m = off_module.bninception_off(101, B, L, variant=ref_file, backbone=_StubBackbone(feats, fgs, conv2), precision=prec)
+    sd = {"module." + k: torch.from_numpy(v) for k, v in synth.make_weights(variant).items()}
+    m.load_state_dict(sd, strict=False)
+    assert (m.batch, m.length, m.modality_fuse) == (B, L, False)
+    frames = torch.zeros(B * L, in_ch, 8, 8, device="cuda")
+    ret = m.RGB_OFF_forward(frames) if ref_file == "rgb" else m(frames)
+    assert len(ret) == (4 if ref_file == "rgb_v2" else 3)
+    for i in range(3):
+        assert tuple(ret[i].shape) == g["ret%d" % i].shape, (i, tuple(ret[i].shape))
+        assert rel_err(ret[i], g["ret%d" % i]) < RTOL, i
+    if ref_file == "rgb":
+        assert torch.equal(ret[1], fgs)                  # Feature_Generation_Score passes through untouched (:860)
+        for a, b in zip(m(frames), ret):                 # forward() of the rgb mirror is RGB_OFF_forward
+            assert torch.equal(a, b)
+    else:
+        if ref_file == "rgb_v2":
+            assert ret[3] is conv2
+        m.modality_fuse = True
+        fused = m(frames)
+        assert tuple(fused.shape) == g["ret_fused"].shape and rel_err(fused, g["ret_fused"]) < RTOL
+    # no backbone: the nine maps are the input, FGS is None, fusing without it is an error
+    m2 = off_module.bninception_off(101, B, L, variant=ref_file, precision=prec)
+    m2.load_state_dict(sd, strict=False)
+    r2 = m2(feats) if ref_file != "rgb" else m2.RGB_OFF_forward(feats)
+    assert r2[1] is None and torch.equal(r2[0], ret[0]) and torch.equal(r2[2], ret[2])
+    if ref_file != "rgb":
+        m2.modality_fuse = True
+        with pytest.raises(ValueError, match="Feature_Generation_Score"):
+            m2(feats)
+
+
+def test_mirror_picks_up_parameter_updates_on_the_gpu(rt):
+    """a weight written after the first forward (optimizer step, copy_, a parent's load_state_dict) must
+    reach liboffk's packed copies before the next forward."""
+    from offk_amd import off_module
+    B, L = 2, 3
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    net = off_module.OFFSubNetwork(101, B, L, "rgb").cuda()
+    w0 = synth.make_weights(spec.VARIANT_RGB)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    a = [t.clone() for t in net(feats)]
+    with torch.no_grad():
+        net.motion_conv_trans_28.weight.mul_(1.5)
+        net.fc_action_motion_14.bias.add_(1.0)
+    b = net(feats)
+    w1 = dict(w0)
+    w1["motion_conv_trans_28.weight"] = w0["motion_conv_trans_28.weight"] * np.float32(1.5)
+    w1["fc_action_motion_14.bias"] = w0["fc_action_motion_14.bias"] + np.float32(1.0)
+    with torch.no_grad():
+        want = orc.off_forward([f.cpu() for f in feats], orc.to_torch_weights(w1), B, L, 0, orc.SLICE_FLAT)
+    for x, y in zip(b, want):
+        assert rel_err(x, y) < RTOL
+    assert not torch.equal(a[0], b[0])
+    wrapper = torch.nn.Sequential(net)                    # a parent module loading a checkpoint
+    wrapper.load_state_dict({"0." + k: torch.from_numpy(v) for k, v in w0.items()})
+    for x, y in zip(net(feats), a):
+        assert torch.equal(x, y)
+
+
+# ---- round 2: BASELINE configs 3 and 5 at full per-GPU size (VERDICT r01 missing #4) ---------------------------------
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_flow_full_size_b64_vs_oracle(rt, prec):
+    """BASELINE config 3: Flow_OFF (fixed diagonal Sobel, util.py:52-77; consensus inside, Flow_OFF.py:867-876), B = 64."""
+    B, L = 64, 7
+    feats = synth.make_features(B, L, 3)
+    h, w = make_handle(rt, B, L, spec.VARIANT_FLOW, precision=prec)
+    got = h.forward([dev(f) for f in feats])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = orc.off_forward([torch.from_numpy(f) for f in feats], w, B, L, spec.VARIANT_FLOW, orc.SLICE_FLAT)
+    for a, b in zip(got, want):
+        assert a.shape == (B, 101) and rel_err(a, b) < RTOL
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_two_stream_b64_vs_oracle(rt, prec):
+    """BASELINE config 5 on one GPU at the per-GPU batch: RGB-OFF + Flow-OFF on the same 64 clips, two HIP streams,
+    K7 late fusion with the notebook weights (score_fusion.ipynb lines 300-301) incl. both TSN scores."""
+    from offk_amd import scores, two_stream
+    B, L = 64, 7
+    wr, wf = synth.make_weights(spec.VARIANT_RGB), synth.make_weights(spec.VARIANT_FLOW, seed=0xF10)
+    fr, ff = synth.make_features(B, L, 2), synth.make_features(B, L, 3)
+    tsn_r = torch.from_numpy(synth.uniform_values(0x7501, B * 101, 4.0).reshape(B, 101))
+    tsn_f = torch.from_numpy(synth.uniform_values(0x7502, B * 101, 4.0).reshape(B, 101))
+    ts = two_stream.TwoStreamOFF(B, L, precision=prec)
+    ts.load_state_dicts(wr, wf)
+    fused, pred = ts.forward([dev(f) for f in fr], [dev(f) for f in ff], rgb_tsn=dev(tsn_r), flow_tsn=dev(tsn_f))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        r = orc.off_forward([torch.from_numpy(f) for f in fr], orc.to_torch_weights(wr), B, L, spec.VARIANT_RGB, consensus=True)
+        f = orc.off_forward([torch.from_numpy(x) for x in ff], orc.to_torch_weights(wf), B, L, spec.VARIANT_FLOW, consensus=True)
+    w = scores.FUSION_BEST
+    ref = w[0] * r[0] + w[1] * tsn_r + w[2] * r[1] + w[3] * f[0] + w[4] * tsn_f + w[5] * f[1]
+    assert rel_err(fused, ref) < RTOL
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()       # ties within the tolerance may flip
+    assert torch.equal(pred.cpu().long()[clear], ref.argmax(dim=1)[clear])

@@ -18,7 +18,8 @@ from offk_amd import spec, synth
 from oracle import off_oracle as orc
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(
-    os.path.join(os.path.dirname(__file__), "golden", "*_b?_l?.npz")) if not os.path.basename(p).startswith("grad_"))
+    os.path.join(os.path.dirname(__file__), "golden", "*_b?_l?.npz")) if not os.path.basename(p).startswith(("grad_", "ret_")))
+RET_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ret_*.npz")))
 
 
 def sample_idx(n, k=97):
@@ -32,7 +33,33 @@ def close(a, b, rtol=2e-6):
 
 
 def test_golden_present():
-    assert len(CASES) == 6
+    assert len(CASES) == 7         # RGB_OFF x3, Flow_OFF x3, RGB_OFF_v2 x1
+    assert len(RET_CASES) == 5
+
+
+@pytest.mark.parametrize("tag", RET_CASES)
+def test_oracle_return_conventions_match_reference(tag, golden_dir):
+    """what RGB_OFF_forward / Flow_OFF.forward / RGB_OFF_v2.forward return (tuple order, shapes
+    incl. the P == 1 squeeze, consensus, modality_fuse sum), captured from the reference import."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    variant, B, L, cfg = (int(v) for v in g["meta"])
+    ref_file = tag.split("_")[1].replace("rgbv2", "rgb_v2")
+    feats = [torch.from_numpy(f) for f in synth.make_features(B, L, cfg)]
+    w = orc.to_torch_weights(synth.make_weights(variant))
+    fgs = torch.from_numpy(g["fgs_raw"])
+    with torch.no_grad():
+        ret = orc.reference_return(feats, w, B, L, ref_file, fgs, conv2="conv2")
+        assert len(ret) == (4 if ref_file == "rgb_v2" else 3)
+        for i in range(3):
+            assert tuple(ret[i].shape) == g["ret%d" % i].shape, (i, ret[i].shape)
+            assert close(ret[i].numpy(), g["ret%d" % i]), i
+        if ref_file == "rgb_v2":
+            assert ret[3] == "conv2" and tuple(g["ret3_shape"]) == (B * L, 192, 56, 56)
+        if ref_file != "rgb":
+            fused = orc.reference_return(feats, w, B, L, ref_file, fgs, modality_fuse=True)
+            assert close(fused.numpy(), g["ret_fused"]) and fused.shape == (B, 101)
+    if tag.endswith("b1_l2") and ref_file == "rgb":
+        assert g["ret0"].shape == (101,)       # RGB_OFF.py:786: squeeze dropped the pair axis
 
 
 @pytest.mark.parametrize("tag", CASES)
