@@ -32,6 +32,42 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _llvm_objdump():
+    for c in ("/opt/rocm/lib/llvm/bin/llvm-objdump", "llvm-objdump"):
+        if not os.path.isabs(c) or os.path.exists(c):
+            return c
+    return None
+
+
+def check_isa(obj):
+    """The DESIGN.md co-residency finding: compiler-generated packed-fp32 VALU instructions with an op_sel operand
+    swizzle (`v_pk_fma_f32 ... op_sel:[0,1,0]`, what the SLP vectoriser makes of neighbouring scalar FMAs that share a
+    broadcast operand) returned wrong low halves on MI355X while the kernel shared CUs with an MFMA kernel of another
+    stream.  The mechanism is not established, so the hazard is kept out of the library by construction: disassemble
+    the gfx950 code object of every translation unit and refuse to build if one contains such an instruction (fix:
+    add the file to EXTRA_FLAGS with -fno-slp-vectorize, or break the pairing in the source)."""
+    objdump = _llvm_objdump()
+    if objdump is None:
+        raise RuntimeError("llvm-objdump not found: cannot run the op_sel ISA check")
+    r = subprocess.run([objdump, "--offloading", obj], capture_output=True, text=True, cwd=os.path.dirname(obj))
+    bad = []
+    found = False
+    for f in sorted(os.listdir(os.path.dirname(obj))):
+        if f.startswith(os.path.basename(obj) + ".") and "amdgcn" in f:
+            found = True
+            path = os.path.join(os.path.dirname(obj), f)
+            d = subprocess.run([objdump, "-d", path], capture_output=True, text=True)
+            bad += [ln.strip() for ln in d.stdout.splitlines() if "v_pk_" in ln and "_f32" in ln and "op_sel" in ln]
+            os.remove(path)
+        elif f.startswith(os.path.basename(obj) + ".") and "host" in f:
+            os.remove(os.path.join(os.path.dirname(obj), f))
+    if not found and os.path.basename(obj) != "offk_api.o":       # offk_api.hip has no device code
+        raise RuntimeError("ISA check: no gfx950 code object found in %s (%s)" % (obj, r.stderr.strip()))
+    if bad:
+        raise RuntimeError("ISA check failed for %s: %d packed-fp32 instruction(s) with op_sel (see check_isa), first: %s"
+                           % (obj, len(bad), bad[0]))
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return False
@@ -58,6 +94,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr)
+        check_isa(o)
         return o
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
