@@ -152,8 +152,10 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
  * diagonal Sobel (RGB_OFF.py:611; Flow_OFF.py:622 + util.py:52-77) and the concats
  * (RGB_OFF.py:616,656,760,832): writes [spatial 32 | temporal 128] into channels
  * [m_coff, m_coff+160) of M, a channels-last buffer with m_cstride channels per pixel.
- * algo: 0 = register rotation over t (default), 1 = t across lanes + wavefront shuffle;
- * 2 / 3 = diagnostics for bandwidth attribution (temporal half only / spatial half only). */
+ * algo: temporal difference by 0 = register rotation over t (default), 1 = t across lanes + wavefront shuffle,
+ * 4 = flat shifted stream (T_row[r] = G_row[r + HW] - G_row[r] within a clip; every frame read twice, second time from cache);
+ * 2 / 3 / 5 = diagnostics for bandwidth attribution (temporal half only with rotation / spatial half only / temporal
+ * half only, flat form). */
 int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, const float* D,
                      float* M, int m_cstride, int m_coff, int algo);
 

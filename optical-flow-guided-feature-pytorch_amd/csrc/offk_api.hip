@@ -108,6 +108,7 @@ struct offk_handle {
   float* dw_w[kNumSites] = {};   // [9][32]
   float* dw_b[kNumSites] = {};   // [32] or null
   float* sobel_w = nullptr;      // shared [9][32] (diag variant)
+  bool sobel_taps4 = false;      // the loaded Sobel weight is zero outside the four taps of util.py:61 -> K2's four-tap path
   float* conv_w[kNumConvs] = {};
   float* conv_wb3[kNumConvs] = {};   // bf16x3 mode: bf16 hi plane | lo plane of conv_w (same byte size)
   float* conv_b[kNumConvs] = {};
@@ -317,12 +318,15 @@ void fill_pw_site(const offk_handle* h, int site, const offk_feat_parts& fp, flo
 }
 void fill_st_site(const offk_handle* h, int site, const float* G, const float* D, float* M, int m_cs, int m_coff, StSite* o) {
   o->G = G; o->D = D;
+  // one unit = [S 32 | T 128] of a channels-last row (RGB_OFF.py:616); the kernel takes the two halves as separate views
+  o->Ms = M; o->s_cs = m_cs; o->s_coff = m_coff; o->Mt = M; o->t_cs = m_cs; o->t_coff = m_coff + kDownCh;
   o->dw = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? h->sobel_w : h->dw_w[site];
   o->db = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? nullptr : h->dw_b[site];
-  o->M = M; o->H = kSites[site].H; o->m_cs = m_cs; o->m_coff = m_coff;
+  o->H = kSites[site].H;
   st_plan(o->H, &o->strips, &o->rows);
+  st_recips(o->H, &o->wrecip, &o->twrecip);
   o->tchunks = st_tchunks(o->H);
-  o->s_begin = 0; o->t_begin = 0; o->tgroup = 1;
+  o->s_begin = 0; o->t_begin = 0;
 }
 
 struct DropCfg { unsigned thresh = 0; float scale = 1.f; unsigned long long seed = 0; };
@@ -341,8 +345,7 @@ int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo, cons
   sp.drop_thresh = drop.thresh; sp.drop_scale = drop.scale;
   sp.zeros = h->zero_page;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
-  const char* tg = getenv("OFFK_K2_TGROUP");
-  const bool tgrouped = tg ? (*tg != '0') : false;  // tuning knob: T-blocks walk all sites of a fusion buffer (measured slower: profiles/r01/k2_ab.txt)
+  sp.taps4 = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL && h->sobel_taps4;
   int sblk = 0, tblk = 0;
   for (int s = 0; s < kNumSites; ++s) {
     fill_st_site(h, s, region(h, ws, (std::string("G_") + kSites[s].name).c_str()),
@@ -351,17 +354,9 @@ int run_sobel_tdiff_all(offk_handle* h, hipStream_t st, void* ws, int algo, cons
     sp.s[s].s_begin = sblk;
     sp.s[s].drop_base = drop_stream_base(drop.seed, s);
     sblk += h->P * sp.s[s].strips;
-    const bool group_head = s == 0 || kSiteFusion[s] != kSiteFusion[s - 1];
-    if (!tgrouped || group_head) {
-      int n = 1;
-      if (tgrouped) while (s + n < kNumSites && kSiteFusion[s + n] == kSiteFusion[s]) ++n;
-      sp.s[s].t_begin = tblk;
-      sp.s[s].tgroup = n;
-      tblk += h->cfg.batch * sp.s[s].tchunks;
-    } else {
-      sp.s[s].t_begin = 0x7fffffff;   // covered by its group head's T-blocks
-      sp.s[s].tgroup = 0;
-    }
+    if (algo >= 4) sp.s[s].tchunks = st_tchunks_flat(kSites[s].H, h->cfg.length);
+    sp.s[s].t_begin = tblk;
+    tblk += h->cfg.batch * sp.s[s].tchunks;
   }
   sp.total_s = sblk; sp.total_t = tblk;
   HIP_TRY(h, sobel_tdiff_launch(sp, algo, st));
@@ -680,7 +675,21 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
     case SK_DOWN_B: rc = copy(h->pw_b[i] + kGenCh); break;
     case SK_DW_W: rc = staged([&](const float* t) { return repack_dw_launch(t, h->dw_w[i], nullptr); }); break;
     case SK_DW_B: rc = copy(h->dw_b[i]); break;
-    case SK_SOBEL: rc = staged([&](const float* t) { return repack_dw_launch(t, h->sobel_w, nullptr); }); break;
+    case SK_SOBEL: {
+      rc = staged([&](const float* t) { return repack_dw_launch(t, h->sobel_w, nullptr); });
+      // frozen parameter (util.py:72), but it travels in checkpoints: take the four-tap path only for weights that
+      // really are zero at the corners and the centre
+      std::vector<float> host(n);
+      if (rc == OFFK_OK && hipMemcpy(host.data(), data, bytes, hipMemcpyDefault) == hipSuccess) {
+        bool four = true;
+        for (int c = 0; c < kDownCh && four; ++c)
+          for (int tap : {0, 2, 4, 6, 8}) four = four && host[(size_t)c * 9 + tap] == 0.f;
+        h->sobel_taps4 = four;
+      } else {
+        h->sobel_taps4 = false;
+      }
+      break;
+    }
     case SK_CONV_W:
       if (kConvs[i].K == 1) rc = copy(h->conv_w[i]);
       else rc = staged([&](const float* t) { return pack_conv_weight_launch(t, kConvs[i].Co, kConvs[i].Ci, kConvs[i].K, kConvs[i].K, h->conv_w[i], nullptr); });
@@ -767,15 +776,17 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
 int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, const float* D, float* M, int m_cstride,
                      int m_coff, int algo) {
   if (!h || site < 0 || site >= kNumSites || !G || !D || !M) return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: bad argument");
-  if (m_cstride % 4 || m_coff % 4 || m_coff < 0 || m_coff + kUnitCh > m_cstride || algo < 0 || algo > 3)
-    return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: need 16-byte aligned channel slice of 160 channels inside m_cstride, algo in 0..3");
+  if (m_cstride % 4 || m_coff % 4 || m_coff < 0 || m_coff + kUnitCh > m_cstride || algo < 0 || algo > 5)
+    return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff: need 16-byte aligned channel slice of 160 channels inside m_cstride, algo in 0..5");
   TRY(site_weights_ready(h, site, false, true));
   DeviceGuard guard(h->cfg.device);
   StParams sp;
   memset(&sp, 0, sizeof(sp));
   sp.nsites = 1; sp.B = h->cfg.batch; sp.L = h->cfg.length;
   sp.zeros = h->zero_page; sp.drop_scale = 1.f;
+  sp.taps4 = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL && h->sobel_taps4;
   fill_st_site(h, site, G, D, M, m_cstride, m_coff, &sp.s[0]);
+  if (algo >= 4) sp.s[0].tchunks = st_tchunks_flat(kSites[site].H, h->cfg.length);
   sp.total_s = h->P * sp.s[0].strips;
   sp.total_t = h->cfg.batch * sp.s[0].tchunks;
   HIP_TRY(h, sobel_tdiff_launch(sp, algo, static_cast<hipStream_t>(stream)));
@@ -783,7 +794,7 @@ int offk_sobel_tdiff(offk_handle* h, void* stream, int site, const float* G, con
 }
 
 int offk_sobel_tdiff_all(offk_handle* h, void* stream, void* workspace, int algo) {
-  if (!h || !workspace || algo < 0 || algo > 3) return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff_all: bad argument");
+  if (!h || !workspace || algo < 0 || algo > 5) return fail(h, OFFK_ERR_INVALID, "offk_sobel_tdiff_all: bad argument");
   for (int s = 0; s < kNumSites; ++s) {
     int rc = site_weights_ready(h, s, false, true);
     if (rc != OFFK_OK) return rc;
@@ -1009,7 +1020,7 @@ int offk_off_units_backward(offk_handle* h, void* stream, const float* const fea
   memset(&wp, 0, sizeof(wp));
   wp.nsites = kNumSites; wp.L = h->cfg.length; wp.P = h->P; wp.slice_mode = h->cfg.slice_mode; wp.kt_per_blk = h->wg_kpb;
   wp.precision = h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0;
-  { const char* e = getenv("OFFK_WG_DBG"); wp.dbg = e ? atoi(e) : 0; }
+  wp.dbg = 0;   // ablation bits of the tools build only
   wp.zeros = h->zero_page;
   WrParams rp;
   memset(&rp, 0, sizeof(rp));

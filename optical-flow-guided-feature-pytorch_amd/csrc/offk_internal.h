@@ -93,13 +93,14 @@ struct StSite {
   const float* D;     // [P*HW][32]
   const float* dw;    // [9][32] tap-major depthwise weights
   const float* db;    // [32] bias or nullptr
-  float* M;           // fusion buffer, channels-last
-  int H, m_cs, m_coff;
+  float* Ms;          // spatial gradient out: channels [s_coff, s_coff + 32) of rows of s_cs floats
+  float* Mt;          // temporal difference out: channels [t_coff, t_coff + 128) of rows of t_cs floats
+  int H, s_cs, s_coff, t_cs, t_coff;
+  int wrecip, twrecip;  // ceil(65536 / W), ceil(65536 / (W + 2)): n / W == (n * wrecip) >> 16 for the n the S-blocks divide (st_plan checks)
   int strips, rows;   // S-blocks: strips per plane, rows per strip
   int tchunks;        // T-blocks per clip
   int s_begin;        // first S-block (spatial role) of this site within the S index space
   int t_begin;        // first T-block (temporal role) of this site within the T index space
-  int tgroup;         // sites (this one and the next tgroup-1 table entries) one T-block walks: they share M
   unsigned long long drop_base;   // training: mixed base of this site's dropout stream (drop_stream_base)
 };
 struct StParams {
@@ -107,12 +108,17 @@ struct StParams {
   int nsites;
   int total_s, total_t;   // S-blocks = sum P*strips, T-blocks = sum B*tchunks
   int B, L, tpix;         // tpix = pixels per T-block
+  int flat_rows;          // (pair, pixel) rows per T-block of the flat form
   unsigned drop_thresh;   // training: 16-bit keep threshold of nn.Dropout(p) on the spatial branch, 0 = eval (identity)
   float drop_scale;       // 1 / (1 - p)
+  int taps4;              // every site's depthwise weights are zero outside (0,1) (1,0) (1,2) (2,1) and there is no bias:
+                          // the diagonal Sobel of util.py:61 -- four taps instead of nine
   const float* zeros;     // >= 16 bytes of zeros in device memory: what a halo / masked-out load reads
 };
 void st_plan(int H, int* strips, int* rows);
+void st_recips(int H, int* wrecip, int* twrecip);
 int st_tchunks(int H);
+int st_tchunks_flat(int H, int L);   // T-blocks per clip of the flat form (algo 4 / 5)
 hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st);
 
 // ---- training side of the OFF units (units_bwd.hip) ----------------------------------

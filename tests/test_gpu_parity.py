@@ -206,7 +206,7 @@ def test_pw_reduce_vs_oracle(rt, site, slice_mode, prec):
     assert rel_err(D.view(B * (L - 1), H, H, 32).permute(0, 3, 1, 2), d_ref) < RTOL
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 4])      # temporal difference by register rotation / wavefront shuffle / flat shifted stream
 @pytest.mark.parametrize("variant", [spec.VARIANT_RGB, spec.VARIANT_FLOW])
 @pytest.mark.parametrize("site", [0, 2, 7])
 def test_sobel_tdiff_vs_oracle(rt, site, variant, algo):

@@ -36,7 +36,8 @@ def main():
     print("grouped K2 launch (all nine sites), B=%d L=%d" % (B, L))
     print("algo  what                         us       GB/s (algorithmic bytes of the part)")
     for algo, what, nbytes in ((0, "rotation + spatial (shipped)", full), (1, "shuffle + spatial", full),
-                               (2, "temporal only (rotation)", tb), (3, "spatial only", sb)):
+                               (2, "temporal only (rotation)", tb), (3, "spatial only", sb),
+                               (4, "flat + spatial", full), (5, "temporal only (flat)", tb)):
         for _ in range(3):
             h.sobel_tdiff_all(algo)
         torch.cuda.synchronize()

@@ -11,7 +11,7 @@ for si, H in ((0, 28), (2, 14)):
     G = torch.relu(torch.randn(N*H*H, 128, device="cuda")); D = torch.randn(P*H*H, 32, device="cuda")
     for cs in (160, 320, 1056):
         M = torch.empty(P*H*H, cs, device="cuda")
-        for algo in (2, 3, 0):
+        for algo in (2, 5, 3, 0, 4):
             for _ in range(3): h.sobel_tdiff(si, G, D, M, 0, algo)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

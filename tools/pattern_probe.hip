@@ -42,8 +42,8 @@ int main() {
   f4 *a, *b; float* sink;
   CK(hipMalloc(&a, big)); CK(hipMalloc(&b, dense)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(a, 0, big)); CK(hipMemset(b, 0, dense));
-  const int pieces[] = {128, 512, 640, 1024};
-  const int strides[] = {0 /* dense */, 640, 1280, 3328, 4224};
+  const int pieces[] = {128, 512};
+  const int strides[] = {0 /* dense */, 256, 512, 1024, 2048, 4096, 640, 1280, 3328, 4224};
   printf("piece stride  moved_MB   write_us GB/s | read_us GB/s | dense->piece us GB/s(total) | piece->dense us GB/s(total)\n");
   for (int piece : pieces)
     for (int stride : strides) {
