@@ -175,7 +175,37 @@ def units_training(B, L, variant, weights, feats, dev, precision, iters=10):
     hw = sum(H * H for _n, _c, H in spec.SITES)
     k2b = B * hw * 4 * ((160 + 32 + 32) * (L - 1) + 256 * L)
     k1b = sum(B * L * C * H * H * 4 for _n, C, H in spec.SITES) + B * hw * 4 * (128 * L + 32 * (L - 1))
+    # a whole training step of the host-side module (off_module.OFFUnits): train-mode forward, backward into .grad, SGD
+    # update, next forward sees the new weights -- the parameters are bound in place (offk_bind_weight), so the
+    # "weight refresh" is the part of the step that no longer exists; measured here as the host time of OFFUnits._handle
+    from offk_amd.off_module import OFFUnits
+    units = OFFUnits(B, L, "rgb" if variant == spec.VARIANT_RGB else "flow", precision=precision).to(dev)
+    units.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items() if k in units.state_dict()})
+    units.train()
+    opt = torch.optim.SGD([p_ for p_ in units.parameters() if p_.requires_grad], lr=1e-3)
+    cots = [torch.randn(P, c, H, H, device=dev, generator=gen) for H, c in ((28, 320), (14, 800), (7, 320))]
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        outs = units(feats, drop_seed=21)
+        torch.autograd.backward(outs, cots)
+        opt.step()
+
+    step_ms = timed(train_step)
+    params = [units._param(k) for k in units.param_keys]
+    units._handle(dev, params)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        units._handle(dev, params)
+    refresh_us = (time.perf_counter() - t0) / 20 * 1e6
     return {"precision": precision, "train_forward_ms": fwd, "backward_ms": bwd,
+            "module_train_step_ms": step_ms,
+            "module_train_step_note": "off_module.OFFUnits: forward (dropout 0.8) + backward + torch SGD step, wall clock; the "
+                                      "three output copies and the permutes of the autograd boundary are inside",
+            "weight_refresh_host_us_per_step": refresh_us,
+            "weight_refresh_note": "unit parameters are bound in place (offk_bind_weight): after an optimizer step there is "
+                                   "no copy, no packing kernel and no synchronisation; this is the host time of the per-step "
+                                   "pointer check (54 tensors)",
             "clips_per_s_forward_plus_backward": B / (fwd + bwd) * 1e3,
             "backward_algorithmic_bytes": k2b + k1b, "backward_hbm_floor_ms_at_8TBs": (k2b + k1b) / 8e12 * 1e3,
             "note": "units only (K1+K2 train mode; K2b + weight-gradient GEMM + reductions); fusion stages / heads train on the caller's autograd"}

@@ -20,6 +20,10 @@
  *    side heads onto a stream the handle owns (event fork / event join, both inside the call):
  *    seen from the caller everything is ordered on `stream`, and the call can be stream-captured.
  *    OFFK_SIDE_STREAM=0 in the environment at offk_create disables the fork.
+ *  - offk_forward runs the units as ONE kernel that fuses the 1x1 reduces with the temporal difference (the gen output G
+ *    never goes to HBM) plus the spatial half of K2; OFFK_FUSED_UNITS=0 in the environment at offk_create selects the
+ *    two-kernel form (K1 then K2), which offk_off_units / offk_off_units_train always use (the backward needs G).  Both
+ *    give the same bits.
  *  - a handle is not thread-safe; distinct handles are independent.
  *  - fp32 everywhere.  Boundary tensors are NCHW contiguous exactly as the reference
  *    backbone produces them; INTERNAL activations (workspace, stage entry points) are
@@ -35,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 3
+#define OFFK_ABI_VERSION 4
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -99,8 +103,19 @@ int offk_destroy(offk_handle* h);
  * keys (model_utils.py:188-216, Flow_OFF.py:1398-1413).  `key` is the reference
  * state_dict key (an optional "module." prefix is ignored, test_flow_off.py:52-58);
  * `data` may be a host or a device pointer; shape is checked against the reference's.
- * The library keeps its own packed device copy. */
+ * The library keeps its own packed device copy.  Blocking, load-time call: it first waits for all work on the device
+ * (so no kernel still reads the copy being replaced and a device-side `data` is complete whatever stream produced it). */
 int offk_set_weight(offk_handle* h, const char* key, const float* data, const int64_t* shape, int ndim);
+/* Training-side alternative for the parameters that change every optimizer step (train_off.py:39-45 leaves exactly the
+ * OFF units' tensors trainable: motion_conv_gen_<s>, motion_spatial_down_<s>, motion_spatial_grad_<s>, weight and bias):
+ * bind the caller's own parameter storage instead of copying it.  `device_data` is the tensor in the reference layout of
+ * the key ([128,C,1,1], [128], [32,C,1,1], [32], [32,1,3,3], [32]; contiguous, 16-byte aligned, on the handle's device);
+ * every later launch reads it in place, so an in-place optimizer update needs NO call at all -- it only has to be ordered
+ * before the next launch, which it is when both are enqueued on the same stream.  The caller keeps the storage alive and
+ * re-binds if the tensor is re-allocated.  A later offk_set_weight of the same key replaces the binding by a copy.  In
+ * bf16x3 mode bound weights are split on the fly by the kernel (the pre-split copy is not used).  Not blocking, no
+ * allocation, no kernel launch. */
+int offk_bind_weight(offk_handle* h, const char* key, const float* device_data);
 /* Number of weights still unset (0 = ready); if buf != NULL the first missing key is copied there. */
 int offk_missing_weights(const offk_handle* h, char* buf, size_t buflen);
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "offk_create": (_I, [_c.POINTER(OffkConfig), _c.POINTER(_P)]),
     "offk_destroy": (_I, [_P]),
     "offk_set_weight": (_I, [_P, _c.c_char_p, _F, _c.POINTER(_c.c_int64), _I]),
+    "offk_bind_weight": (_I, [_P, _c.c_char_p, _F]),
     "offk_missing_weights": (_I, [_P, _c.c_char_p, _c.c_size_t]),
     "offk_workspace_bytes": (_c.c_size_t, [_P]),
     "offk_forward": (_I, [_P, _P, _c.POINTER(_F), _F, _F, _F, _P]),
@@ -95,7 +96,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 3:
+    if lib.offk_abi_version() != 4:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

@@ -41,6 +41,9 @@ struct ConvArgs {
 #ifdef OFFK_CONV_TIMING
   unsigned long long* dbg;   // [8] timing sums of the bf16x3 producer / consumer waves (tools only)
 #endif
+#ifdef OFFK_TUNING_KNOBS
+  int ablate;                // tools only (OFFK_CONV_ABLATE): 1 no activation loads, 2 no weight loads, 4 no LDS stores, 8 no MFMAs
+#endif
 };
 
 // PREC 0: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
@@ -124,12 +127,19 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
       int hi = hi0[r] + kh, wi = wi0[r] + kw;
       bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       mask |= ok ? (1u << r) : 0u;
+#ifdef OFFK_TUNING_KNOBS
+      if (p.ablate & 1) continue;
+#endif
       rg[r] = *reinterpret_cast<const float4*>(ok ? xbase + (size_t)(pix0[r] + hi * p.W + wi) * p.x_cs + c0 : xbase);
     }
     okm = mask;
 #pragma unroll
-    for (int r = 0; r < NRB; ++r)
+    for (int r = 0; r < NRB; ++r) {
+#ifdef OFFK_TUNING_KNOBS
+      if (p.ablate & 2) continue;
+#endif
       rg[NRA * VA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
+    }
   };
   // bf16x3 LDS image per stage: A_hi [BM] | A_lo [BM] | B_hi [BN] | B_lo [BN], rows of 64 B (32 bf16), the
   // 16-B chunk c of row r stored at chunk c ^ ((r >> 2) & 3): conflict-free for the 16-B stores (8
@@ -144,6 +154,9 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
     return relu_in ? relu4(t) : t;
   };
   auto store_tile = [&](const float4 (&rg)[NRG], unsigned okm, int stage) {
+#ifdef OFFK_TUNING_KNOBS
+    if (p.ablate & 4) return;
+#endif
     if (PREC == 0) {
       float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
@@ -212,6 +225,9 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int st = (kt - kt_begin) & 1;
       if (kt + 1 < kt_end) load_tile(rg0, okm0, kt + 1);
+#ifdef OFFK_TUNING_KNOBS
+      if (!(p.ablate & 8))
+#endif
       acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
                     Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
       if (kt + 1 < kt_end) store_tile(rg0, okm0, st ^ 1);
@@ -365,17 +381,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
 // Waves 0-3 multiply (wave = one 32-column tile x all seven row tiles for 128 channels; column tile x alternate row
 // tiles for 64), waves 4-7 stream the weight tiles two steps ahead and hold the next chunk's patch in registers.
 // ---------------------------------------------------------------------------------------------------
-template <int KH, int S, int W, int NT>
+// PREC 1 = bf16x3 (hi / lo bf16 planes, rows of 64 B).  PREC 0 = exact fp32 (v_mfma_f32_32x32x2_f32): ONE plane of fp32
+// rows of 128 B -- the same LDS bytes -- whose 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7): a
+// ds_read_b128 lane group (16 consecutive rows, same chunk) then covers all 16 slots of the 256-byte bank row.  The fp32
+// form exists because the generic fp32 kernel re-fetches every input value once per tap from L2: its load / LDS-store
+// pipeline alone took as long as the MFMAs (tools/conv_ablate.py: 0.93 ms of staging beside 0.96 ms of MFMAs on the 7x7),
+// so the matrix pipe sat at 68-70 %; with the patch in LDS the fp32 consumers are purely MFMA-bound.
+template <int KH, int S, int W, int NT, int PREC>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
   constexpr int KW = KH, TAPS = KH * KW, PAD = KH / 2, H = W, HW = H * W;
   constexpr int WO = (W + 2 * PAD - KW) / S + 1, HOWO = WO * WO, IMG = 196 / HOWO, NP = IMG * HW;
   static_assert(196 % HOWO == 0 && (S == 1 || (W % 2) == 0), "196-pixel output groups only");
-  constexpr int BN = 32 * NT, RT = NT == 4 ? 7 : 4, B3R = 64;
-  constexpr int PATCH_PLANE = ((NP + 1) * B3R + 127) / 128 * 128, B_PLANE = BN * B3R, B_STAGE = 2 * B_PLANE;
+  constexpr int BN = 32 * NT, RT = NT == 4 ? 7 : 4, B3R = PREC == 0 ? 128 : 64;
+  constexpr int PATCH_PLANE = ((NP + 1) * B3R + 127) / 128 * 128, B_PLANE = BN * B3R, B_STAGE = PREC == 0 ? B_PLANE : 2 * B_PLANE;
   constexpr int NJ = (NP + 31) / 32;   // patch pixels per producer thread
   extern __shared__ __attribute__((aligned(16))) char lds_c[];
-  char* const patch = lds_c;                        // hi plane, then lo plane
-  char* const bst = lds_c + 2 * PATCH_PLANE;         // two stages of (B_hi | B_lo)
+  char* const patch = lds_c;                        // bf16x3: hi plane, then lo plane; fp32: one plane
+  char* const bst = lds_c + (PREC == 0 ? 1 : 2) * PATCH_PLANE;   // two stages of (B_hi | B_lo) / of B
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tid = threadIdx.x & 255;
@@ -423,11 +445,15 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
           const int img = pp / HW, rem = pp - img * HW, y = rem / W, x = rem - y * W;
           const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
           const int slot = img * HW + y * W + xp;
-          uint2 hh, ll;
-          split4(t, hh, ll);
-          char* q = patch + slot * B3R + ((((c8 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c8 & 1) << 3));
-          *reinterpret_cast<uint2*>(q) = hh;
-          *reinterpret_cast<uint2*>(q + PATCH_PLANE) = ll;
+          if constexpr (PREC == 0) {
+            *reinterpret_cast<float4*>(patch + slot * B3R + ((c8 ^ ((slot >> 1) & 7)) << 4)) = t;
+          } else {
+            uint2 hh, ll;
+            split4(t, hh, ll);
+            char* q = patch + slot * B3R + ((((c8 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c8 & 1) << 3));
+            *reinterpret_cast<uint2*>(q) = hh;
+            *reinterpret_cast<uint2*>(q + PATCH_PLANE) = ll;
+          }
         }
       }
     };
@@ -441,12 +467,19 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
         const int row = (tid >> 3) + 32 * r;
-        *reinterpret_cast<float4*>(bst + stage * B_STAGE + (c8 >> 2) * B_PLANE + row * B3R + (((c8 & 3) ^ ((row >> 2) & 3)) << 4)) = rgP[set + r];
+        if constexpr (PREC == 0)
+          *reinterpret_cast<float4*>(bst + stage * B_STAGE + row * B3R + ((c8 ^ ((row >> 1) & 7)) << 4)) = rgP[set + r];
+        else
+          *reinterpret_cast<float4*>(bst + stage * B_STAGE + (c8 >> 2) * B_PLANE + row * B3R + (((c8 & 3) ^ ((row >> 2) & 3)) << 4)) = rgP[set + r];
       }
     };
     if (tid < 8) {   // the zero pixel
-      *reinterpret_cast<uint2*>(patch + NP * B3R + tid * 8) = make_uint2(0u, 0u);
-      *reinterpret_cast<uint2*>(patch + PATCH_PLANE + NP * B3R + tid * 8) = make_uint2(0u, 0u);
+      if constexpr (PREC == 0) {
+        *reinterpret_cast<float4*>(patch + NP * B3R + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        *reinterpret_cast<uint2*>(patch + NP * B3R + tid * 8) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(patch + PATCH_PLANE + NP * B3R + tid * 8) = make_uint2(0u, 0u);
+      }
     }
     load_patch(c_begin);
     load_b(B0, 0);
@@ -501,7 +534,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const int bbase = (ct * 32 + r32) * B3R + ((h ^ ((r32 >> 2) & 3)) << 4);
+  const int brow = ct * 32 + r32;
+  const int bbase = PREC == 0 ? brow * B3R + ((h ^ ((brow >> 1) & 7)) << 4) : brow * B3R + ((h ^ ((r32 >> 2) & 3)) << 4);
   __syncthreads();
   int tap = 0;
   for (int g = 0; g < G; ++g) {
@@ -513,8 +547,25 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
       const bool inb = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
       const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
       const int slot = inb ? ib(i) + y * W + xp : NP;
-      aoff(i) = slot * B3R + ((h ^ ((slot >> 2) & 3)) << 4);
+      aoff(i) = PREC == 0 ? slot * B3R + ((h ^ ((slot >> 1) & 7)) << 4) : slot * B3R + ((h ^ ((slot >> 2) & 3)) << 4);
     }
+    if constexpr (PREC == 0) {
+      // fp32: chunk (2 q + h) ^ swz == ((h ^ swz) ^ 2 q): a lane reads four consecutive k of its row per visit
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bh_p + ((bbase ^ (q << 5)) - bbase));
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          if (NT == 4 || (wave >> 1) + 2 * i < 7) {
+            const float4 a = *reinterpret_cast<const float4*>(patch + (aoff(i) ^ (q << 5)));
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int boff = (bbase ^ (s2 << 5)) - bbase;
@@ -844,12 +895,14 @@ static hipError_t launch_patch16(ConvArgs a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int KH, int S, int W, int NT>
+template <int KH, int S, int W, int NT, int PREC>
 static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
   constexpr int PAD = KH / 2, WO = (W + 2 * PAD - KH) / S + 1, IMG = 196 / (WO * WO), NP = IMG * W * W, BN = 32 * NT;
-  constexpr size_t lds = 2 * (size_t)(((NP + 1) * 64 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 64);
+  // bf16x3: hi + lo planes of 64-byte rows; fp32: one plane of 128-byte rows -- the same bytes
+  constexpr size_t lds = PREC == 0 ? (size_t)(NP + 1) * 128 + 2 * (size_t)(BN * 128)
+                                   : 2 * (size_t)(((NP + 1) * 64 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 64);
   if (a.Co % BN) return hipErrorInvalidConfiguration;
-  auto kern = conv_patch_kernel<KH, S, W, NT>;
+  auto kern = conv_patch_kernel<KH, S, W, NT, PREC>;
   {
     hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds);
     if (e != hipSuccess) return e;
@@ -865,9 +918,12 @@ static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
   return hipGetLastError();
 }
 // shapes the patch kernel covers: (k, stride, W) = (7, 2, 28), (5, 2, 14), (3, 1, 14), (3, 1, 7), pad = k / 2, square maps
-static hipError_t launch_patch_shape(const ConvArgs& a, int KH, int S, int W, int nt, hipStream_t st) {
-#define OFFK_PATCH_CASE(k, s, w)                                                        \
-  if (KH == k && S == s && W == w) return nt == 4 ? launch_patch<k, s, w, 4>(a, st) : launch_patch<k, s, w, 2>(a, st);
+static hipError_t launch_patch_shape(const ConvArgs& a, int KH, int S, int W, int nt, int prec, hipStream_t st) {
+#define OFFK_PATCH_CASE(k, s, w)                                                                                     \
+  if (KH == k && S == s && W == w) {                                                                                 \
+    if (prec == 0) return nt == 4 ? launch_patch<k, s, w, 4, 0>(a, st) : launch_patch<k, s, w, 2, 0>(a, st);        \
+    return nt == 4 ? launch_patch<k, s, w, 4, 1>(a, st) : launch_patch<k, s, w, 2, 1>(a, st);                       \
+  }
   OFFK_PATCH_CASE(7, 2, 28)
   OFFK_PATCH_CASE(5, 2, 14)
   OFFK_PATCH_CASE(3, 1, 14)
@@ -968,6 +1024,9 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.co_limit = narrow ? d.co_limit : d.Co;
   if (sk > 1 && (!d.partial || d.partial_floats < (size_t)sk * (size_t)M * d.Co)) sk = 1;   // no slab space: unsplit
   a.splitk = sk; a.partial = d.partial; a.gm = a.gn = 0;
+#ifdef OFFK_TUNING_KNOBS
+  { const char* e = getenv("OFFK_CONV_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+#endif
 #ifdef OFFK_CONV_TIMING
   {
     static unsigned long long* dbg = nullptr;
@@ -996,14 +1055,14 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
     if (e == hipErrorInvalidConfiguration) *why = "conv2d: the half-chunk patch kernel covers 7x7s2@28 and 5x5s2@14 with Co % 64 == 0";
     return e;
   }
-  if (cfg == 6 || cfg == 7) {   // patch kernel: bf16x3, square map, pad = k / 2, one of its four shapes
-    if (d.precision != 1 || narrow || d.KH != d.KW || d.H != d.W || d.pad != d.KH / 2) {
-      *why = "conv2d: the patch kernel (tile_cfg 6 / 7) needs bf16x3, a square map and pad = k / 2";
+  if (cfg == 6 || cfg == 7) {   // patch kernel: square map, pad = k / 2, one of its four shapes (both precisions)
+    if (narrow || d.KH != d.KW || d.H != d.W || d.pad != d.KH / 2) {
+      *why = "conv2d: the patch kernel (tile_cfg 6 / 7) needs a square map and pad = k / 2";
       return hipErrorInvalidValue;
     }
     if (sk > d.Ci / 32) sk = d.Ci / 32;   // it splits over channel chunks
     a.splitk = sk;
-    e = launch_patch_shape(a, d.KH, d.stride, d.H, cfg == 6 ? 4 : 2, st);
+    e = launch_patch_shape(a, d.KH, d.stride, d.H, cfg == 6 ? 4 : 2, d.precision, st);
     if (e == hipErrorInvalidConfiguration) *why = "conv2d: the patch kernel covers 7x7s2@28, 5x5s2@14, 3x3s1@14, 3x3s1@7 with Co % 128 (cfg 6) / % 64 (cfg 7)";
     return e;
   }

@@ -107,6 +107,13 @@ struct offk_handle {
   float* pw_b[kNumSites] = {};   // [160]
   float* dw_w[kNumSites] = {};   // [9][32]
   float* dw_b[kNumSites] = {};   // [32] or null
+  // unit parameters bound in place (offk_bind_weight): the caller's own tensors, reference layouts, read at launch time
+  const float* bnd_gen_w[kNumSites] = {};   // [128][C]
+  const float* bnd_gen_b[kNumSites] = {};   // [128]
+  const float* bnd_down_w[kNumSites] = {};  // [32][C]
+  const float* bnd_down_b[kNumSites] = {};  // [32]
+  const float* bnd_dw_w[kNumSites] = {};    // [32][1][3][3]
+  const float* bnd_dw_b[kNumSites] = {};    // [32]
   float* sobel_w = nullptr;      // shared [9][32] (diag variant)
   bool sobel_taps4 = false;      // the loaded Sobel weight is zero outside the four taps of util.py:61 -> K2's four-tap path
   float* conv_w[kNumConvs] = {};
@@ -127,7 +134,7 @@ struct offk_handle {
 
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
-  bool fused_units = false;      // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS at offk_create)
+  bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
   std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
@@ -309,10 +316,28 @@ int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
   return OFFK_OK;
 }
 
+// bf16x3: K1 reads the library's pre-split weight copies unless a contraction weight is bound in place -- then every site
+// takes fp32 weights (its bound tensors, or the library's fp32 copy) and the kernel splits them on the way into LDS
+bool pw_presplit_now(const offk_handle* h) {
+  if (h->cfg.precision != OFFK_PRECISION_BF16X3 || !h->pw_presplit) return false;
+  for (int s = 0; s < kNumSites; ++s)
+    if (h->bnd_gen_w[s] || h->bnd_down_w[s]) return false;
+  return true;
+}
+void pw_weight_ptrs(const offk_handle* h, int site, bool presplit, const float** w, const float** w_down, const float** b,
+                    const float** b_down) {
+  const float* own = presplit ? h->pw_wb3[site] : h->pw_w[site];
+  *w = h->bnd_gen_w[site] ? h->bnd_gen_w[site] : own;
+  *w_down = h->bnd_down_w[site] ? h->bnd_down_w[site] : own + (size_t)kGenCh * kSites[site].C;
+  *b = h->bnd_gen_b[site] ? h->bnd_gen_b[site] : h->pw_b[site];
+  *b_down = h->bnd_down_b[site] ? h->bnd_down_b[site] : h->pw_b[site] + kGenCh;
+}
+
 void fill_pw_site(const offk_handle* h, int site, const offk_feat_parts& fp, float* G, float* D, PwSite* o) {
   for (int q = 0; q < 4; ++q) { o->xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o->cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
   o->nparts = fp.n_parts;
-  o->w = (h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit) ? h->pw_wb3[site] : h->pw_w[site]; o->bias = h->pw_b[site]; o->G = G; o->D = D;
+  pw_weight_ptrs(h, site, pw_presplit_now(h), &o->w, &o->w_down, &o->bias, &o->bias_down);
+  o->G = G; o->D = D;
   o->C = kSites[site].C; o->HW = kSites[site].H * kSites[site].H; o->M = h->N * o->HW;
   o->blk_begin = 0;
 }
@@ -320,8 +345,10 @@ void fill_st_site(const offk_handle* h, int site, const float* G, const float* D
   o->G = G; o->D = D;
   // one unit = [S 32 | T 128] of a channels-last row (RGB_OFF.py:616); the kernel takes the two halves as separate views
   o->Ms = M; o->s_cs = m_cs; o->s_coff = m_coff; o->Mt = M; o->t_cs = m_cs; o->t_coff = m_coff + kDownCh;
-  o->dw = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? h->sobel_w : h->dw_w[site];
-  o->db = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL ? nullptr : h->dw_b[site];
+  const bool sobel = h->cfg.variant == OFFK_VARIANT_DIAG_SOBEL;
+  o->dw = sobel ? h->sobel_w : (h->bnd_dw_w[site] ? h->bnd_dw_w[site] : h->dw_w[site]);
+  o->dw_ref = !sobel && h->bnd_dw_w[site] != nullptr;
+  o->db = sobel ? nullptr : (h->bnd_dw_b[site] ? h->bnd_dw_b[site] : h->dw_b[site]);
   o->H = kSites[site].H;
   st_plan(o->H, &o->strips, &o->rows);
   st_recips(o->H, &o->wrecip, &o->twrecip);
@@ -402,7 +429,8 @@ int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[],
   pp.nsites = kNumSites; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
   pp.precision = h->cfg.precision;
-  pp.presplit = h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit;
+  pp.presplit = pw_presplit_now(h);
+  pp.zeros = h->zero_page;
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
     int s = kPwOrder[i];
@@ -429,7 +457,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   pt.nsites = kNumSites; pt.B = h->cfg.batch; pt.L = h->cfg.length; pt.P = h->P; pt.slice_mode = h->cfg.slice_mode;
   pt.tgroups = pt_tgroups(h->cfg.length);
   pt.precision = h->cfg.precision;
-  pt.presplit = h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit;
+  pt.presplit = pw_presplit_now(h);
   pt.zeros = h->zero_page;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   int blk = 0;
@@ -439,8 +467,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
     const offk_feat_parts& fp = feats[s];
     for (int q = 0; q < 4; ++q) { o.xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o.cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
     o.nparts = fp.n_parts;
-    o.w = pt.presplit ? h->pw_wb3[s] : h->pw_w[s];
-    o.bias = h->pw_b[s];
+    pw_weight_ptrs(h, s, pt.presplit, &o.w, &o.w_down, &o.bias, &o.bias_down);
     o.D = region(h, ws, (std::string("D_") + kSites[s].name).c_str());
     o.M = region(h, ws, fus[kSiteFusion[s]]);
     o.m_cs = kFusionC[kSiteFusion[s]]; o.m_coff = kSiteCoff[s];
@@ -610,7 +637,8 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     offk_destroy(h);
     return OFFK_ERR_HIP;
   }
-  { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = e && *e == '1'; }
+  // inference: K1 fused with the temporal difference (pw_tdiff.hip) unless OFFK_FUSED_UNITS=0 at offk_create
+  { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&
@@ -651,6 +679,10 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
   for (int i = 0; ok && i < ndim; ++i) { ok = shape[i] == s.shape[i]; n *= (size_t)s.shape[i]; }
   if (!ok) return fail(h, OFFK_ERR_INVALID, "offk_set_weight: shape mismatch for " + k);
   DeviceGuard guard(h->cfg.device);
+  // A load-time call, blocking by contract: wait for everything enqueued on the device first -- a kernel that still reads
+  // the copy being replaced, or (device source) the kernel that is still producing `data` on some non-blocking stream.
+  // Parameters that change every step are not pushed through here: offk_bind_weight.
+  HIP_TRY(h, hipDeviceSynchronize());
   const size_t bytes = n * sizeof(float);
   auto copy = [&](float* dst) -> int {
     HIP_TRY(h, hipMemcpy(dst, data, bytes, hipMemcpyDefault));
@@ -703,10 +735,50 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
     case SK_FC_W: rc = copy(h->fc_w[i]); break;
     case SK_FC_B: rc = copy(h->fc_b[i]); break;
   }
-  if (rc == OFFK_OK) s.set = true;
+  if (rc == OFFK_OK) {
+    s.set = true;
+    switch (s.kind) {       // an explicit copy replaces an earlier in-place binding of the same key
+      case SK_GEN_W: h->bnd_gen_w[i] = nullptr; break;
+      case SK_GEN_B: h->bnd_gen_b[i] = nullptr; break;
+      case SK_DOWN_W: h->bnd_down_w[i] = nullptr; break;
+      case SK_DOWN_B: h->bnd_down_b[i] = nullptr; break;
+      case SK_DW_W: h->bnd_dw_w[i] = nullptr; break;
+      case SK_DW_B: h->bnd_dw_b[i] = nullptr; break;
+      default: break;
+    }
+  }
   if (s.kind == SK_CONV_W || s.kind == SK_CONV_B) h->merged_dirty = true;
   if (s.kind == SK_GEN_W || s.kind == SK_DOWN_W) h->pw_dirty = true;
   return rc;
+}
+
+int offk_bind_weight(offk_handle* h, const char* key, const float* device_data) {
+  if (!h || !key || !device_data) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: null argument");
+  std::string k(key);
+  if (k.compare(0, 7, "module.") == 0) k = k.substr(7);
+  auto it = h->index.find(k);
+  if (it == h->index.end()) return fail(h, OFFK_ERR_UNKNOWN_KEY, "offk_bind_weight: not an OFF sub-network key for this variant: " + k);
+  Slot& s = h->slots[it->second];
+  if ((reinterpret_cast<uintptr_t>(device_data) & 15) != 0) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: pointer must be 16-byte aligned: " + k);
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, device_data) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != h->cfg.device) {
+    (void)hipGetLastError();
+    return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: needs a device pointer on the handle's device: " + k);
+  }
+  const int i = s.idx;
+  switch (s.kind) {
+    case SK_GEN_W: h->bnd_gen_w[i] = device_data; break;
+    case SK_GEN_B: h->bnd_gen_b[i] = device_data; break;
+    case SK_DOWN_W: h->bnd_down_w[i] = device_data; break;
+    case SK_DOWN_B: h->bnd_down_b[i] = device_data; break;
+    case SK_DW_W: h->bnd_dw_w[i] = device_data; break;
+    case SK_DW_B: h->bnd_dw_b[i] = device_data; break;
+    default:
+      return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: only the OFF units' parameters (motion_conv_gen_*, motion_spatial_down_*, "
+                                       "motion_spatial_grad_*) can be bound in place: " + k);
+  }
+  s.set = true;
+  return OFFK_OK;
 }
 
 int offk_missing_weights(const offk_handle* h, char* buf, size_t buflen) {
@@ -765,7 +837,8 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
   pp.nsites = 1; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
   pp.precision = h->cfg.precision;
-  pp.presplit = h->cfg.precision == OFFK_PRECISION_BF16X3 && h->pw_presplit;
+  pp.presplit = pw_presplit_now(h);
+  pp.zeros = h->zero_page;
   TRY(finalize_pw(h, static_cast<hipStream_t>(stream)));
   fill_pw_site(h, site, whole_map(site, feat), G, D, &pp.s[0]);
   pp.total_blocks = pw_blocks_for(pp.s[0].M);
@@ -999,7 +1072,8 @@ int offk_off_units_backward(offk_handle* h, void* stream, const float* const fea
   for (int s = 0; s < kNumSites; ++s) {
     UbSite& u = up.s[s];
     u.G = reg("G_", s); u.D = reg("D_", s);
-    u.dw = learned_dw ? h->dw_w[s] : h->sobel_w;
+    u.dw = learned_dw ? (h->bnd_dw_w[s] ? h->bnd_dw_w[s] : h->dw_w[s]) : h->sobel_w;
+    u.dw_ref = learned_dw && h->bnd_dw_w[s] != nullptr;
     u.gm = gm[s].data; u.gm_cs = gm[s].cstride; u.gm_coff = gm[s].coff;
     u.dG = reg("dG_", s); u.dD = reg("dD_", s);
     u.dw_part = learned_dw ? reg("dwp_", s) : nullptr;

@@ -99,6 +99,18 @@ __device__ __forceinline__ void b3_store(char* hi_plane, int plane_bytes, int ro
   *reinterpret_cast<uint2*>(p + plane_bytes) = l;
 }
 
+// XCD-aware tile order inside one group of n blocks that start at any block id: blocks are dealt round-robin over the
+// 8 XCDs (private 4 MiB L2 each), so blocks j, j+8, j+16 ... of the group share an XCD; they get a CONTIGUOUS range
+// of logical tiles (bijective for every n).  Neighbouring tiles share partial 128-byte lines (rows of HW floats are
+// only 16-byte aligned) and weight rows: on one XCD the second touch is an L2 hit instead of a second fetch.
+__device__ __forceinline__ int xcd_contiguous(int j, int n) {
+#ifdef OFFK_NO_XCD_REMAP
+  return j;
+#endif
+  const int c = j & 7, idx = j >> 3, q = n >> 3, r = n & 7;
+  return (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + idx;
+}
+
 // row (M index) of accumulator register `reg` for a lane in half `h` (lane>>5)
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 

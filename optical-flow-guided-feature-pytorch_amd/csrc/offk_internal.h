@@ -42,9 +42,11 @@ struct PwSite {
   const float* xp[4];
   int cp[4];
   int nparts;
-  const float* w;     // stacked [160][C]: rows 0-127 motion_conv_gen, 128-159 motion_spatial_down (fp32), or the
-                      // same matrix pre-split for bf16x3: [160][C/32][hi 32 | lo 32] bf16
-  const float* bias;  // [160]
+  const float* w;     // motion_conv_gen rows [128][C] (fp32), or the same rows pre-split for bf16x3: [128][C/32][hi 32 | lo 32] bf16
+  const float* w_down;   // motion_spatial_down rows [32][C], same format as w (the library's packed copy keeps them adjacent;
+                         // weights bound with offk_bind_weight live wherever the caller's parameters do)
+  const float* bias;  // [128]
+  const float* bias_down;   // [32]
   float* G;           // [N*HW][128]
   float* D;           // [P*HW][32]
   int C, HW, M;       // M = N*HW rows
@@ -56,6 +58,10 @@ struct PwParams {
   int L, P, slice_mode, nhwc;
   int precision;       // 0 = exact fp32 MFMA, 1 = bf16x3
   int presplit;        // bf16x3: w is already in the split format
+  const float* zeros;  // >= 16 bytes of zeros in device memory: what a masked-out load reads
+#ifdef OFFK_TUNING_KNOBS
+  int ablate;          // tools only (OFFK_PW_ABLATE): 1 no feature-map loads, 2 no weight loads, 4 no LDS stores, 8 no MFMAs
+#endif
 };
 int pw_blocks_for(int M);
 hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st);
@@ -65,8 +71,10 @@ struct PtSite {
   const float* xp[4];   // feature map parts, NCHW (as PwSite)
   int cp[4];
   int nparts;
-  const float* w;       // stacked [160][C] fp32, or pre-split for bf16x3 (as PwSite)
-  const float* bias;    // [160]
+  const float* w;       // gen rows [128][C] fp32, or pre-split for bf16x3 (as PwSite)
+  const float* w_down;  // down rows [32][C]
+  const float* bias;    // [128]
+  const float* bias_down;   // [32]
   float* D;             // [P*HW][32]
   float* M;             // fusion buffer: T goes to channels [m_coff + 32, m_coff + 160)
   int m_cs, m_coff;
@@ -91,8 +99,10 @@ hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);
 struct StSite {
   const float* G;     // [N*HW][128]
   const float* D;     // [P*HW][32]
-  const float* dw;    // [9][32] tap-major depthwise weights
+  const float* dw;    // depthwise weights: [9][32] tap-major (the library's packed copy) or, dw_ref != 0, the reference's own
+                      // [32][1][3][3] layout (a parameter bound with offk_bind_weight)
   const float* db;    // [32] bias or nullptr
+  int dw_ref;
   float* Ms;          // spatial gradient out: channels [s_coff, s_coff + 32) of rows of s_cs floats
   float* Mt;          // temporal difference out: channels [t_coff, t_coff + 128) of rows of t_cs floats
   int H, s_cs, s_coff, t_cs, t_coff;
@@ -126,7 +136,8 @@ unsigned long long drop_stream_base(unsigned long long seed, int site);
 struct UbSite {
   const float* G;     // saved post-ReLU gen output [N*HW][128]
   const float* D;     // saved down output [P*HW][32]
-  const float* dw;    // [9][32] tap-major depthwise weights (or the Sobel taps)
+  const float* dw;    // [9][32] tap-major depthwise weights (or the Sobel taps); dw_ref != 0: the reference's [32][1][3][3]
+  int dw_ref;
   const float* gm;    // gradient w.r.t. motion_<site>: channels-last rows [P*HW][gm_cs], the unit's 160 channels at gm_coff
   int gm_cs, gm_coff;
   float* dG;          // out: gradient w.r.t. the gen conv output (pre-ReLU) [N*HW][128]

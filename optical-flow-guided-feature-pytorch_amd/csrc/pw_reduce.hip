@@ -14,6 +14,8 @@
 // 4 k-rows x 4 pixels per thread with 16-B loads and transposes in registers into the
 // [row][k] LDS image the MFMA core wants.  Outputs are channels-last:
 //   G [N*HW][128] (post-ReLU), D [P*HW][32] (row = output pair index).
+#include <cstdlib>
+
 #include "offk_common.h"
 #include "offk_internal.h"
 
@@ -88,9 +90,12 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   // the by-value kernarg array with a runtime index (or copying a whole entry) goes
   // through scratch memory
   PwSite S;
+  int nblk_site;
 #define OFFK_PW_PICK(i)                                                                              \
   S.w = p.s[i].w; S.bias = p.s[i].bias; S.G = p.s[i].G; S.D = p.s[i].D;                              \
+  S.w_down = p.s[i].w_down; S.bias_down = p.s[i].bias_down;                                          \
   S.C = p.s[i].C; S.HW = p.s[i].HW; S.M = p.s[i].M; S.blk_begin = p.s[i].blk_begin;                  \
+  nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;         \
   S.nparts = p.s[i].nparts;                                                                          \
   S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];    \
   S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PW_PICK(i) }
 #undef OFFK_PW_PICK
   const int C = S.C, HW = S.HW, M = S.M;
-  const int m0 = ((int)blockIdx.x - S.blk_begin) * PW_BM;
+  const int m0 = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site) * PW_BM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // is any row of this block a source frame of the spatial branch?
@@ -148,12 +153,20 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   };
 
   float4 rg[4 + PW_TN];   // prefetch registers: 4 x A, then 5 x B (one array: two arrays end up in scratch)
+  // weight rows (tid>>3) + 32 r: r = 0..3 gen rows, r = 4 the down rows (their own pointer: bound parameters need not be adjacent)
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
+  const float* wdbase = S.w_down + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   auto load_tile = [&](int k0) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xb; int cpart, kl;
     locate(k0, xb, cpart, kl);
+#ifdef OFFK_TUNING_KNOBS
+    if (p.ablate & 1) {
+    } else
+#endif
     if (mode == 0) {
+      // (the branch-free form -- masked rows reading a zero page through a selected pointer -- measured 5 % SLOWER here,
+      // same box A/B in round 2: row_ok is false only in the last tile of a site and the branch is cheap)
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       const float* base = xb + ((size_t)fr * cpart + kl + koff) * HW + pix;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -161,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
         if (row_ok) rg[j] = *reinterpret_cast<const float4*>(base + (size_t)j * HW);
       }
     } else if (mode == 1) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       const float* base = xb + ((size_t)fr * cpart + kl + koff) * HW + pix;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -170,17 +184,25 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
       }
     } else {
       const float* base = xb + (size_t)(m0 + (tid >> 3)) * cpart + kl + koff;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         rg[r] = z;
         if (m0 + (tid >> 3) + 32 * r < M) rg[r] = *reinterpret_cast<const float4*>(base + (size_t)32 * r * cpart);
       }
     }
+#ifdef OFFK_TUNING_KNOBS
+    if (p.ablate & 2) return;
+#endif
 #pragma unroll
-    for (int r = 0; r < PW_TN; ++r)
+    for (int r = 0; r < PW_TN - 1; ++r)
       rg[4 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
+    rg[4 + PW_TN - 1] = *reinterpret_cast<const float4*>(wdbase + k0);
   };
   auto store_tile = [&]() {
+#ifdef OFFK_TUNING_KNOBS
+    if (p.ablate & 4) return;
+#endif
     if (PREC == 1) {
       if (mode == 0) {
         const int row = 4 * (tid >> 3), kq = tid & 7;
@@ -238,6 +260,10 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+#ifdef OFFK_TUNING_KNOBS
+    if (p.ablate & 8) {
+    } else
+#endif
     if (PREC == 0) {
       if (down_active) pw_mma<5>(acc, As + wave * 32 * LDS_K, Bs, lane);
       else pw_mma<4>(acc, As + wave * 32 * LDS_K, Bs, lane);
@@ -252,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   const int r32 = lane & 31, h = lane >> 5;
   float bv[PW_TN];
 #pragma unroll
-  for (int t = 0; t < PW_TN; ++t) bv[t] = S.bias[t * 32 + r32];
+  for (int t = 0; t < PW_TN - 1; ++t) bv[t] = S.bias[t * 32 + r32];
+  bv[PW_TN - 1] = S.bias_down[r32];
   // bias / ReLU in straight-line code first: a loaded value (the bias) used inside the `if (row in range)` blocks
   // makes every block start with an s_waitcnt that also throttles the stores of the blocks before it
 #pragma unroll
@@ -283,7 +310,11 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   }
 }
 
-hipError_t pw_reduce_launch(const PwParams& p, hipStream_t st) {
+hipError_t pw_reduce_launch(const PwParams& p_in, hipStream_t st) {
+  PwParams p = p_in;
+#ifdef OFFK_TUNING_KNOBS
+  { const char* e = getenv("OFFK_PW_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+#endif
   if (p.total_blocks <= 0) return hipSuccess;
   if (p.precision == 0) hipLaunchKernelGGL(pw_reduce_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(pw_reduce_kernel<1>, dim3(p.total_blocks), dim3(256), 0, st, p);

@@ -51,10 +51,13 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   float* Bs = As + PT_BM * LDS_K;
 
   PtSite S;
+  int nblk_site;
 #define OFFK_PT_PICK(i)                                                                                \
   S.w = p.s[i].w; S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;           \
+  S.w_down = p.s[i].w_down; S.bias_down = p.s[i].bias_down;                                              \
   S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
   S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
+  nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;          \
   S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
   S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
   OFFK_PT_PICK(0)
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PT_PICK(i) }
 #undef OFFK_PT_PICK
   const int C = S.C, HW = S.HW, L = p.L;
-  int local = (int)blockIdx.x - S.blk_begin;
+  int local = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site);   // neighbouring pixel chunks of a clip on one XCD
   const int tg = local % p.tgroups; local /= p.tgroups;
   const int chunk = local % S.chunks, b = local / S.chunks;
   const int q0 = chunk * 32;
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   constexpr int NRG = 8 + 5;          // A: frame fs (4 k-rows), frame fs+4 (4 k-rows); B: 5 weight rows
   float4 rg[PC ? 2 * NRG : NRG];      // PC: two sets (one array: separate ones go to scratch)
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
+  const float* wdbase = S.w_down + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   auto load_tile = [&](const int set, int k0) {
     const float* xb; int cpart, kl;
     locate(k0, xb, cpart, kl);
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
       }
     }
 #pragma unroll
-    for (int r = 0; r < 5; ++r) rg[set + 8 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
+    for (int r = 0; r < 4; ++r) rg[set + 8 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
+    rg[set + 12] = *reinterpret_cast<const float4*>(wdbase + k0);
   };
   auto shifted = [&](float4 v) {
     if (sh == 0) return v;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     bg4[g] = *reinterpret_cast<const float4*>(S.bias + wave * 32 + 8 * g + 4 * h);
-    bd4[g] = *reinterpret_cast<const float4*>(S.bias + kGenCh + 8 * g + 4 * h);
+    bd4[g] = *reinterpret_cast<const float4*>(S.bias_down + 8 * g + 4 * h);
   }
 #pragma unroll
   for (int j = 0; j < PT_FT; ++j)

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(ST_THREADS, 7) void sobel_tdiff_kernel(StParams p) 
   StSite S;
 #define OFFK_ST_PICK(i)                                                                                         \
   S.G = p.s[i].G; S.D = p.s[i].D; S.dw = p.s[i].dw; S.db = p.s[i].db; S.Ms = p.s[i].Ms; S.Mt = p.s[i].Mt;       \
+  S.dw_ref = p.s[i].dw_ref;                                                                                     \
   S.H = p.s[i].H; S.s_cs = p.s[i].s_cs; S.s_coff = p.s[i].s_coff; S.t_cs = p.s[i].t_cs; S.t_coff = p.s[i].t_coff; \
   S.strips = p.s[i].strips; S.rows = p.s[i].rows; S.s_begin = p.s[i].s_begin; S.t_begin = p.s[i].t_begin;       \
   S.tchunks = p.s[i].tchunks; S.drop_base = p.s[i].drop_base; S.wrecip = p.s[i].wrecip; S.twrecip = p.s[i].twrecip;
@@ -215,7 +216,12 @@ __global__ __launch_bounds__(ST_THREADS, 7) void sobel_tdiff_kernel(StParams p) 
   // (tap weights first) is issued before the first wait: halo / out-of-tile pieces read the handle's zero page
   // through a selected pointer -- with `if (inside) v = load` the compiler waited for the first loads before
   // issuing the rest and fetched the weights only after the tile had arrived (three latencies per block)
-  const float4 wreg = *reinterpret_cast<const float4*>(tid < 72 ? S.dw + 4 * tid : ((S.db && tid < 80) ? S.db + 4 * (tid - 72) : p.zeros));
+  // threads 0..71: one (tap, channel quad) of the depthwise weights; 72..79: the bias quads.  Library copy: [9][32]
+  // tap-major.  A parameter bound in place (offk_bind_weight) keeps the reference layout [32][1][3][3]: channel stride 9.
+  const bool has_w = tid < 72, has_b = S.db && tid >= 72 && tid < 80;
+  const float* wq = has_w ? (S.dw_ref ? S.dw + 36 * (tid & 7) + (tid >> 3) : S.dw + 4 * tid) : (has_b ? S.db + 4 * (tid - 72) : p.zeros);
+  const int ws_ = has_w ? (S.dw_ref ? 9 : 1) : (has_b ? 1 : 0);
+  const float4 wreg = make_float4(wq[0], wq[ws_], wq[2 * ws_], wq[3 * ws_]);
   float4 st[ST_STAGE_MAX];
 #pragma unroll
   for (int j = 0; j < ST_STAGE_MAX; ++j) {

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(UB_THREADS, 2) void units_bwd_kernel(UbParams p) { 
   UbSite S;
 #define OFFK_UB_PICK(i)                                                                                        \
   S.G = p.s[i].G; S.D = p.s[i].D; S.dw = p.s[i].dw; S.gm = p.s[i].gm; S.gm_cs = p.s[i].gm_cs;                    \
+  S.dw_ref = p.s[i].dw_ref;                                                                                      \
   S.gm_coff = p.s[i].gm_coff; S.dG = p.s[i].dG; S.dD = p.s[i].dD; S.dw_part = p.s[i].dw_part;                    \
   S.drop_base = p.s[i].drop_base; S.H = p.s[i].H; S.strips = p.s[i].strips; S.rows = p.s[i].rows;                \
   S.tchunks = p.s[i].tchunks; S.s_begin = p.s[i].s_begin; S.t_begin = p.s[i].t_begin;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(UB_THREADS, 2) void units_bwd_kernel(UbParams p) { 
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int i = tid + UB_THREADS * r;
-    wreg[r] = *(i < 9 * kDownCh ? S.dw + i : p.zeros);
+    wreg[r] = *(i < 9 * kDownCh ? S.dw + (S.dw_ref ? (i & 31) * 9 + (i >> 5) : i) : p.zeros);   // dw_ref: bound [32][1][3][3] parameter
   }
   float4 sgd[2 * UB_STAGE_MAX];   // dS pieces, then D pieces (one array: two arrays end up in scratch)
   float4* const sg = sgd;

@@ -128,7 +128,7 @@ class _OFFUnitsFn(torch.autograd.Function):
         # call that was (and which parameter values it used) so that a later forward through the same module
         # -- an eval pass, a second micro-batch, a checkpoint recompute -- is detected instead of silently used
         ctx.gen = mod._generation
-        ctx.versions = dict(mod._versions)
+        ctx.versions = dict((k, (prm.data_ptr(), prm._version)) for k, prm in zip(mod.param_keys, params))
         P = rt.P
         # copies: the workspace is rewritten by the next forward, autograd consumers may outlive it
         outs = []
@@ -178,7 +178,7 @@ class OFFUnits(nn.Module):
         if self.variant == spec.VARIANT_FLOW:
             self.sobel_edge_diagonal = _SobelHolder()
         self.param_keys = [k for k in spec.weight_shapes(self.variant) if k.startswith(spec.UNIT_PARAM_PREFIXES)]
-        self._rt, self._versions, self.drop_seed = None, {}, 0
+        self._rt, self._bound, self.drop_seed = None, {}, 0
         self._generation = 0    # bumped by every units forward: tells a backward whether G / D in the workspace are its own
 
     def _run_units(self, rt, feats, drop):
@@ -211,14 +211,18 @@ class OFFUnits(nn.Module):
         if self._rt is None or self._rt.device != torch.device(device):
             self._rt = runtime.OffForward(self.batch, self.length, self.variant, self.slice_mode, False,
                                           device=device, precision=self.precision, training=True)
-            self._versions = {}
+            self._bound = {}
             if self.variant == spec.VARIANT_FLOW:
                 self._rt.set_weight(spec.SOBEL_KEY, self.sobel_edge_diagonal.conv.weight)
-        for key, prm in zip(self.param_keys, params):   # push what an optimizer step (or a load) changed
-            tag = (prm.data_ptr(), prm._version)
-            if self._versions.get(key) != tag:
-                self._rt.set_weight(key, prm)
-                self._versions[key] = tag
+        # The trainable tensors are BOUND, not copied (offk_bind_weight): liboffk reads the parameters' own storage at
+        # launch time, so an optimizer step costs the library nothing -- no 54 blocking copies per step, no staging, no
+        # re-packing -- and is ordered like any other kernel on the stream.  Only a re-allocated parameter is re-bound.
+        for key, prm in zip(self.param_keys, params):
+            if not prm.is_contiguous():
+                raise ValueError("OFFUnits parameter %s must be contiguous" % key)
+            if self._bound.get(key) != prm.data_ptr():
+                self._rt.bind_weight(key, prm)
+                self._bound[key] = prm.data_ptr()
         return self._rt
 
     def forward(self, feats, drop_seed=None):

@@ -79,6 +79,12 @@ class OffForward:
         _lib.check(self.lib.offk_set_weight(self._h, key.encode(), ptr, arr, len(shape)), self._h)
         del keep
 
+    def bind_weight(self, key, tensor):
+        """offk_bind_weight: the library reads ``tensor`` (a contiguous fp32 parameter on this device, reference layout)
+        in place from now on -- no copy now, none after an optimizer step.  The caller keeps it alive."""
+        _check_dev(tensor, key, self.device)
+        _lib.check(self.lib.offk_bind_weight(self._h, key.encode(), ctypes.c_void_p(tensor.data_ptr())), self._h)
+
     def load_state_dict(self, state_dict, strict=True):
         """Accepts a reference-format state_dict (extra backbone keys are ignored;
         a 'module.' prefix is accepted, test_flow_off.py:52-58)."""

@@ -350,3 +350,65 @@ def test_off_units_interleaved_forwards_before_backward(rt):
         units.motion_conv_gen_3a.weight.mul_(2.0)
     with pytest.raises(RuntimeError, match="modified"):
         torch.autograd.backward(out, cots)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_off_units_bound_weights_follow_updates_on_a_side_stream(rt, prec):
+    """the trainable tensors are bound in place (offk_bind_weight), so an optimizer step needs no
+    library call at all.  Parameters updated by kernels on a NON-DEFAULT (non-blocking) stream must be the ones the next
+    forward on that stream uses -- there is no hidden NULL-stream copy to race with -- and nothing is pushed after the
+    first forward."""
+    from offk_amd.off_module import OFFUnits
+    B, L = 2, 3
+    wnp = synth.make_weights(spec.VARIANT_RGB)
+    units = OFFUnits(B, L, "rgb", precision=prec).cuda()
+    units.load_state_dict({k: torch.from_numpy(a) for k, a in wnp.items() if k in units.state_dict()}, strict=True)
+    units.eval()
+    feats_np = synth.make_features(B, L, 2)
+    feats = [dev(f) for f in feats_np]
+    tf = [torch.from_numpy(f) for f in feats_np]
+    m7 = units(feats)[2]
+    with torch.no_grad():
+        want = orc.off_unit(tf[8], orc.to_torch_weights(wnp), "5b", B, L, spec.VARIANT_RGB, orc.SLICE_FLAT)
+    assert rel_err(m7[:, 160:], want) < RTOL
+    calls = []
+    real_set = units._rt.set_weight
+    real_bind = units._rt.bind_weight
+    units._rt.set_weight = lambda *a, **k: (calls.append("set"), real_set(*a, **k))
+    units._rt.bind_weight = lambda *a, **k: (calls.append("bind"), real_bind(*a, **k))
+    side = torch.cuda.Stream()                       # torch streams are non-blocking: no implicit NULL-stream ordering
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for step in range(3):
+            with torch.no_grad():
+                for prm in units.parameters():
+                    if prm.requires_grad:
+                        prm.mul_(1.25).add_(0.01)         # "optimizer step" on the side stream
+            m28, m14, m7 = units(feats)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert calls == []                                # nothing copied, nothing re-bound
+    w2 = dict(orc.to_torch_weights(wnp))
+    w2.update((k, prm.detach().cpu()) for k, prm in units.named_parameters())
+    with torch.no_grad():
+        for si, site in ((0, "3a"), (4, "4b"), (8, "5b")):
+            want = orc.off_unit(tf[si], w2, site, B, L, spec.VARIANT_RGB, orc.SLICE_FLAT)
+            buf, off = ((m28, 0), (m14, 320), (m7, 160))[(0, 4, 8).index(si)]
+            assert rel_err(buf[:, off:off + 160], want) < RTOL, site
+    # a re-allocated parameter is re-bound (once)
+    units.motion_conv_gen_3a.weight.data = units.motion_conv_gen_3a.weight.data.clone()
+    units(feats)
+    assert calls == ["bind"]
+
+
+def test_bind_weight_argument_checks(rt):
+    from offk_amd import _lib
+    h = rt.OffForward(1, 3, spec.VARIANT_RGB, training=True)
+    with pytest.raises(_lib.OffkError, match="only the OFF units"):
+        h.bind_weight("motion_conv_trans_28.weight", torch.zeros(64, 320, 7, 7, device="cuda"))
+    with pytest.raises(_lib.OffkError, match="not an OFF"):
+        h.bind_weight("conv1_7x7_s2.weight", torch.zeros(64, 3, 7, 7, device="cuda"))
+    with pytest.raises(ValueError):
+        h.bind_weight("motion_conv_gen_3a.bias", torch.zeros(128))          # host tensor
+    with pytest.raises(_lib.OffkError, match="16-byte aligned"):
+        h.bind_weight("motion_conv_gen_3a.bias", torch.zeros(132, device="cuda")[1:129])     # contiguous view, 4 bytes in

@@ -34,6 +34,20 @@ CAND = {
     "motion_conv_trans_28": [(10, 4), (10, 5), (10, 3), (1, 6)],
 }
 
+# exact-fp32 mode: the LDS-patch kernel (6 = 128 channels per block, 7 = 64) against the built-in generic plans
+CAND_FP32 = {
+    "motion_conv_trans_28": [(3, 3), (7, 1), (7, 2), (7, 3), (7, 5)],
+    "motion_conv2_trans_28a": [(3, 1), (7, 1), (7, 2)],
+    "motion_conv2_trans_28b": [(3, 1), (7, 1), (7, 2)],
+    "motion_conv2_trans_28c": [(3, 1), (7, 1), (7, 2)],
+    "motion_conv_trans_14": [(4, 12), (7, 3), (7, 4), (7, 6), (7, 11), (6, 4), (6, 8), (6, 11)],
+    "motion_conv2_trans_14a": [(0, 3), (7, 1), (7, 2), (7, 4), (6, 2), (6, 4)],
+    "motion_conv2_trans_14b": [(0, 3), (7, 1), (7, 2), (7, 4), (6, 2), (6, 4)],
+    "motion_conv3_trans_14b": [(4, 1), (7, 1), (7, 2), (6, 1), (6, 2), (6, 4)],
+    "motion_conv_trans": [(0, 6), (7, 2), (7, 4), (7, 6), (6, 4), (6, 6), (6, 13)],
+    "motion_conv2_trans": [(4, 3), (7, 1), (7, 2), (7, 4), (6, 2), (6, 4), (6, 8)],
+}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -67,7 +81,7 @@ def main():
     chosen = {}
     best = base
     for rnd in range(a.rounds):
-        for key, cands in CAND.items():
+        for key, cands in (CAND_FP32 if a.precision == "fp32" else CAND).items():
             res = []
             for cfg, sk in cands:
                 h.set_conv_plan(key, cfg, sk)
