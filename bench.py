@@ -82,8 +82,8 @@ def cpu_baseline(feats_np, weights, length, variant, clips_large):
     """The oracle (a port of the reference's op sequence, bit-exact against it in the dev container) timed on this
     box's host cores -- reported beside the GPU number only.  SURVEY.md 8(d): at B = 1 and at the bench batch.
     torch's intra-op threading does not scale to every logical CPU on these small convs, so a few thread counts are
-    tried on an 8-clip sample (one warm-up + one run each) and the fastest is used: the baseline is the best the
-    host does, not a strawman."""
+    tried at each size (one warm-up + one run each) and the fastest is used: the baseline is the best the host
+    does, not a strawman."""
     from oracle import off_oracle as orc
     w = orc.to_torch_weights(weights)
 
@@ -94,23 +94,26 @@ def cpu_baseline(feats_np, weights, length, variant, clips_large):
         return time.perf_counter() - t0
 
     ncpu = os.cpu_count() or 1
-    default_threads = torch.get_num_threads()
-    best_t, best_n, sweep = None, default_threads, {}
-    sweep_clips = min(8, clips_large)
-    with torch.no_grad():
-        for n in sorted({default_threads, max(1, ncpu // 2), 64, 32, 16}):
+
+    def best_threads(clips, cands):
+        best_t, best_n, sweep = None, None, {}
+        for n in cands:
             if n > ncpu:
                 continue
             torch.set_num_threads(n)
-            run(sweep_clips)
-            t = run(sweep_clips)
-            sweep[n] = sweep_clips / t
+            run(clips)
+            t = run(clips)
+            sweep[n] = clips / t
             if best_t is None or t < best_t:
                 best_t, best_n = t, n
-        torch.set_num_threads(best_n)
-        run(1)
+        return best_n, sweep
+
+    with torch.no_grad():
+        n1, sweep1 = best_threads(1, sorted({min(4, ncpu), min(8, ncpu), 16, 32}))
+        torch.set_num_threads(n1)
         t1 = statistics.median([run(1) for _ in range(5)])
-        run(clips_large)
+        best_n, sweep = best_threads(clips_large, sorted({min(16, ncpu), 32, 64, max(1, ncpu // 2)}))
+        torch.set_num_threads(best_n)
         tl = statistics.median([run(clips_large) for _ in range(3)])
     model = ""
     try:
@@ -123,7 +126,8 @@ def cpu_baseline(feats_np, weights, length, variant, clips_large):
     return {"value": clips_large / tl, "unit": "clips/s", "cores": best_n, "kind": "port",
             "sample": "oracle/off_oracle.py (torch CPU ops, bit-exact vs the reference import) on the first %d clips x %d "
                       "segments of the same synthetic maps, 1 warm-up, median of 3" % (clips_large, length),
-            "batch_1": {"value": 1.0 / t1, "unit": "clips/s", "sec_per_forward": t1, "sample": "1 clip, 1 warm-up, median of 5"},
+            "batch_1": {"value": 1.0 / t1, "unit": "clips/s", "cores": n1, "sec_per_forward": t1,
+                        "sample": "1 clip, median of 5 at the fastest thread count", "clips_per_s_by_threads": sweep1},
             "cpu_model": model, "host_logical_cpus": os.cpu_count(), "sec_per_forward": tl,
             "clips_per_s_by_threads": sweep}
 

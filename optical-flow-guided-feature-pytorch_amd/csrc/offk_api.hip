@@ -204,7 +204,7 @@ void ub_plan(int H, int* strips, int* rows) {
   *rows = H >= 28 ? 7 : H;
   *strips = (H + *rows - 1) / *rows;
 }
-constexpr int kUbTpix = 64;
+constexpr int kUbTpix = 8;     // pixels per T-block of the backward: one task per thread (as K2, sobel_tdiff.hip st_tpix)
 
 void plan_workspace(offk_handle* h) {
   const size_t N = h->N, P = h->P;

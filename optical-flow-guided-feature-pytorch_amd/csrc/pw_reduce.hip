@@ -76,7 +76,24 @@ __device__ __forceinline__ void pw_mma_b3(f32x16 (&acc)[PW_TN], const char* Ahi,
   }
 }
 
-template <int PREC>
+typedef float f4v __attribute__((ext_vector_type(4)));
+// NT bit 0: the feature map is read exactly once -> non-temporal loads (weights keep the default policy: every block
+// re-reads them); bit 1: G / D are not read again before K1 ends -> non-temporal stores.
+template <int NT>
+__device__ __forceinline__ float4 ldx4(const float* q) {
+  if (NT & 1) {
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4*>(q);
+}
+template <int NT>
+__device__ __forceinline__ void stf(float* q, float v) {
+  if (NT & 2) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+
+template <int PREC, int NT>
 __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   constexpr int A_PLANE = PW_BM * B3_ROW, B_PLANE = PW_BN * B3_ROW;
   constexpr int LDS_BYTES = PREC == 0 ? (PW_BM + PW_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         rg[j] = z;
-        if (row_ok) rg[j] = *reinterpret_cast<const float4*>(base + (size_t)j * HW);
+        if (row_ok) rg[j] = ldx4<NT>(base + (size_t)j * HW);
       }
     } else if (mode == 1) {
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -300,11 +317,11 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     if (m < M) {
       float* g = S.G + (size_t)m * kGenCh + r32;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) g[t * 32] = acc[t][reg];
+      for (int t = 0; t < 4; ++t) stf<NT>(g + t * 32, acc[t][reg]);
       if (down_active) {
         int f = m / HW, pix = m - f * HW;
         int dr = down_row(f, p.L, p.P, p.slice_mode);
-        if (dr >= 0) S.D[((size_t)dr * HW + pix) * kDownCh + r32] = acc[4][reg];
+        if (dr >= 0) stf<NT>(S.D + ((size_t)dr * HW + pix) * kDownCh + r32, acc[4][reg]);
       }
     }
   }
@@ -316,8 +333,22 @@ hipError_t pw_reduce_launch(const PwParams& p_in, hipStream_t st) {
   { const char* e = getenv("OFFK_PW_ABLATE"); p.ablate = e ? atoi(e) : 0; }
 #endif
   if (p.total_blocks <= 0) return hipSuccess;
-  if (p.precision == 0) hipLaunchKernelGGL(pw_reduce_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(pw_reduce_kernel<1>, dim3(p.total_blocks), dim3(256), 0, st, p);
+  constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
+#ifdef OFFK_TUNING_KNOBS
+  const char* e = getenv("OFFK_PW_NT");
+  const int nt = e ? atoi(e) : kNT;
+#define OFFK_PW_LAUNCH(P)                                                                                             \
+  switch (nt & 3) {                                                                                                   \
+    case 0: hipLaunchKernelGGL((pw_reduce_kernel<P, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;           \
+    case 1: hipLaunchKernelGGL((pw_reduce_kernel<P, 1>), dim3(p.total_blocks), dim3(256), 0, st, p); break;           \
+    case 2: hipLaunchKernelGGL((pw_reduce_kernel<P, 2>), dim3(p.total_blocks), dim3(256), 0, st, p); break;           \
+    default: hipLaunchKernelGGL((pw_reduce_kernel<P, 3>), dim3(p.total_blocks), dim3(256), 0, st, p); break;          \
+  }
+#else
+#define OFFK_PW_LAUNCH(P) hipLaunchKernelGGL((pw_reduce_kernel<P, kNT>), dim3(p.total_blocks), dim3(256), 0, st, p);
+#endif
+  if (p.precision == 0) { OFFK_PW_LAUNCH(0) } else { OFFK_PW_LAUNCH(1) }
+#undef OFFK_PW_LAUNCH
   return hipGetLastError();
 }
 

@@ -41,7 +41,9 @@ int pt_tgroups(int L) { return L <= PT_FT ? 1 : (L - 2) / (PT_FT - 1) + 1; }
 // PC = 1 (bf16x3 only): 512 threads, waves 0-3 multiply, waves 4-7 load two K-tiles ahead, split and store into a
 // two-stage LDS ring (one block per CU); the 256-thread form holds one tile of prefetch beside 144 accumulator
 // registers and waits a memory latency per K-tile.
-template <int PREC, int PC>
+typedef float f4v __attribute__((ext_vector_type(4)));
+// NT bit 0: non-temporal loads of the feature map (read once); bit 1: non-temporal stores of T and D
+template <int PREC, int PC, int NT>
 __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p) {
   static_assert(PC == 0 || PREC == 1, "producer / consumer form is bf16x3 only");
   constexpr int A_PLANE = PT_BM * B3_ROW, B_PLANE = PT_BN * B3_ROW;
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
       const float* base = xb + ((size_t)(b * L + t0 + (ok ? j : 0)) * cpart + kl + 4 * kq) * HW + kkpx;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f4u v = *reinterpret_cast<const f4u*>(ok ? base + (size_t)i * HW : p.zeros);
+        const f4u* src = reinterpret_cast<const f4u*>(ok ? base + (size_t)i * HW : p.zeros);
+        const f4u v = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
         rg[set + 4 * half + i] = make_float4(v.x, v.y, v.z, v.w);
       }
     }
@@ -311,9 +314,12 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     if (j + 1 < nf && pix_ok) {
       float* mrow = S.M + ((pair0 + j) * HW + q0 + r32) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * h;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(mrow + 8 * g) = make_float4(acc[j + 1][4 * g] - acc[j][4 * g], acc[j + 1][4 * g + 1] - acc[j][4 * g + 1],
-                                                                acc[j + 1][4 * g + 2] - acc[j][4 * g + 2], acc[j + 1][4 * g + 3] - acc[j][4 * g + 3]);
+      for (int g = 0; g < 4; ++g) {
+        const f4v tv = {acc[j + 1][4 * g] - acc[j][4 * g], acc[j + 1][4 * g + 1] - acc[j][4 * g + 1],
+                        acc[j + 1][4 * g + 2] - acc[j][4 * g + 2], acc[j + 1][4 * g + 3] - acc[j][4 * g + 3]};
+        if (NT & 2) __builtin_nontemporal_store(tv, reinterpret_cast<f4v*>(mrow + 8 * g));
+        else *reinterpret_cast<f4v*>(mrow + 8 * g) = tv;
+      }
     }
   }
 #pragma unroll
@@ -325,9 +331,11 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
       if (dr >= 0) {
         float* drow = S.D + ((size_t)dr * HW + q0 + r32) * kDownCh + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(drow + 8 * g) = make_float4(acc[PT_FT + half][4 * g], acc[PT_FT + half][4 * g + 1],
-                                                                  acc[PT_FT + half][4 * g + 2], acc[PT_FT + half][4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+          const f4v dv = {acc[PT_FT + half][4 * g], acc[PT_FT + half][4 * g + 1], acc[PT_FT + half][4 * g + 2], acc[PT_FT + half][4 * g + 3]};
+          if (NT & 2) __builtin_nontemporal_store(dv, reinterpret_cast<f4v*>(drow + 8 * g));
+          else *reinterpret_cast<f4v*>(drow + 8 * g) = dv;
+        }
       }
     }
   }
@@ -354,19 +362,30 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   }
 #endif
   constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4, kStageB3 = 2 * (size_t)(PT_BM + PT_BN) * B3_ROW;
+  constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
+#ifdef OFFK_TUNING_KNOBS
+  const char* e = getenv("OFFK_PW_NT");
+  const int nt = e ? atoi(e) : kNT;
   // OFFK_FUSED_PC=1: the 512-thread producer / consumer form (measured slower: 0.945 vs 0.828 ms, one block per CU)
-  static const bool pc = [] { const char* e = getenv("OFFK_FUSED_PC"); return e && *e == '1'; }();
-  if (p.precision == 0) {
-    hipLaunchKernelGGL((pw_tdiff_kernel<0, 0>), dim3(p.total_blocks), dim3(256), kStage32, st, p);
-  } else if (!pc) {
-    hipLaunchKernelGGL((pw_tdiff_kernel<1, 0>), dim3(p.total_blocks), dim3(256), kStageB3, st, p);
-  } else {
-    {
-      hipError_t e = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1>), (int)(2 * kStageB3));
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((pw_tdiff_kernel<1, 1>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
+  const char* pce = getenv("OFFK_FUSED_PC");
+  if (p.precision == 1 && pce && *pce == '1') {
+    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1, 0>), (int)(2 * kStageB3));
+    if (er != hipSuccess) return er;
+    hipLaunchKernelGGL((pw_tdiff_kernel<1, 1, 0>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
+    return hipGetLastError();
   }
+#define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
+  switch (nt & 3) {                                                                                                  \
+    case 0: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
+    case 1: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 1>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
+    case 2: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 2>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
+    default: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 3>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;     \
+  }
+#else
+#define OFFK_PT_LAUNCH(P, LDS) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT>), dim3(p.total_blocks), dim3(256), LDS, st, p);
+#endif
+  if (p.precision == 0) { OFFK_PT_LAUNCH(0, kStage32) } else { OFFK_PT_LAUNCH(1, kStageB3) }
+#undef OFFK_PT_LAUNCH
   return hipGetLastError();
 }
 

@@ -76,9 +76,11 @@ int st_tchunks(int H) { return (H * H + st_tpix_for(H) - 1) / st_tpix_for(H); }
 int st_tchunks_flat(int H, int L) { return ((L - 1) * H * H + st_flat_rows() - 1) / st_flat_rows(); }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
-// Non-temporal variants: a plain float4 stream reads at 7.1 instead of 6.3 TB/s with them on this
-// chip (tools/hbm_probe.hip), but K2 is bound by its strided write side and measured no gain
-// (profiles/r01/k2_ab.txt), so they stay off by default.
+// Non-temporal variants for the T-blocks (the S-blocks always use the default policy: their D halo rows are re-read by the
+// neighbouring strip and nt made them slower).  Round 1, 64 pixels per T-block: no gain.  Round 2, one task per thread
+// (tpix 8): nt loads + nt stores take the whole kernel from 270 to 256 us on the same box (profiles/r02/k2_sweep.txt);
+// nt loads alone are slower (279), nt stores alone 262.  G is read exactly once and T is not re-read before K2 ends,
+// so neither stream has any use for a cache line.
 template <int NT>
 __device__ __forceinline__ float4 ldg4(const float* p) {
   if (NT) {
@@ -104,8 +106,11 @@ __device__ __forceinline__ float4 fma4(float4 w, float4 x, float4 acc) {
   return make_float4(fmaf(w.x, x.x, acc.x), fmaf(w.y, x.y, acc.y), fmaf(w.z, x.z, acc.z), fmaf(w.w, x.w, acc.w));
 }
 
-template <int ALGO, int NTL, int NTS, int TAPS4>
+// ROLES only names the launch (3 = the whole K2, 1 = S-blocks alone -- what follows the fused units kernel --, 2 = T-blocks
+// alone): a kernel trace (rocprofv3 --stats) then lists the full kernel apart from the partial launches.
+template <int ALGO, int NTL, int NTS, int TAPS4, int ROLES>
 __global__ __launch_bounds__(ST_THREADS, 7) void sobel_tdiff_kernel(StParams p) {
+  static_assert(ROLES >= 1 && ROLES <= 3, "roles");
   extern __shared__ __attribute__((aligned(16))) f4v tile4[];   // [(rows+2)*(W+2) tile pixels][8 quads] + taps [9][8] + bias [8]
 
   // ---- block id -> (role, index within role): proportional interleave of the two roles ----
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(ST_THREADS, 7) void sobel_tdiff_kernel(StParams p) 
     const int ty = (tp * S.twrecip) >> 16, tx = tp - ty * TW;        // tp / TW, tp % TW (exact for tp < 512, host-checked)
     const int y = y0 - 1 + ty, x = tx - 1;
     const bool inside = tp < nstage && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-    st[j] = ldg4<NTL>(inside ? d + (size_t)(y * W + x) * kDownCh + 4 * cq : p.zeros);
+    st[j] = ldg4<0>(inside ? d + (size_t)(y * W + x) * kDownCh + 4 * cq : p.zeros);   // D halo rows are re-read by the neighbour strip: keep them cached
   }
   if (tid < 80) wl4[tid] = f4v{wreg.x, wreg.y, wreg.z, wreg.w};
 #pragma unroll
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(ST_THREADS, 7) void sobel_tdiff_kernel(StParams p) 
   }
 #pragma unroll
   for (int j = 0; j < ST_OUT_MAX; ++j)
-    if (prow + 32 * j < npix) stg4<NTS>(mrow + (size_t)(q0 + prow + 32 * j) * S.s_cs, make_float4(acc[j].x, acc[j].y, acc[j].z, acc[j].w));
+    if (prow + 32 * j < npix) stg4<0>(mrow + (size_t)(q0 + prow + 32 * j) * S.s_cs, make_float4(acc[j].x, acc[j].y, acc[j].z, acc[j].w));
 }
 
 hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st) {
@@ -303,25 +308,36 @@ hipError_t sobel_tdiff_launch(const StParams& p, int algo, hipStream_t st) {
   size_t lds = (tile_px + 10) * kDownCh * sizeof(float);   // tile + taps + bias
   dim3 grid(q.total_s + q.total_t);
   if (algo < 0 || algo > 5) return hipErrorInvalidValue;
-#define OFFK_K2_LAUNCH(A, NL, NS, T4) hipLaunchKernelGGL((sobel_tdiff_kernel<A, NL, NS, T4>), grid, dim3(ST_THREADS), lds, st, q)
+  const int roles = q.total_s == 0 ? 2 : (q.total_t == 0 ? 1 : 3);
+#define OFFK_K2_LAUNCH(A, NL, NS, T4)                                                                               \
+  do {                                                                                                              \
+    if (roles == 3) hipLaunchKernelGGL((sobel_tdiff_kernel<A, NL, NS, T4, 3>), grid, dim3(ST_THREADS), lds, st, q);      \
+    else if (roles == 1) hipLaunchKernelGGL((sobel_tdiff_kernel<A, NL, NS, T4, 1>), grid, dim3(ST_THREADS), lds, st, q); \
+    else hipLaunchKernelGGL((sobel_tdiff_kernel<A, NL, NS, T4, 2>), grid, dim3(ST_THREADS), lds, st, q);                 \
+  } while (0)
+  const int nt = knob("OFFK_K2_NT", 3);     // bit 0: non-temporal loads, bit 1: non-temporal stores (T-blocks)
+  const int talgo = algo == 1 ? 1 : (algo >= 4 ? 2 : 0);
 #ifdef OFFK_TUNING_KNOBS
-  const int nt = knob("OFFK_K2_NT", 0);     // bit 0: non-temporal loads, bit 1: non-temporal stores (A/B: no gain, profiles/r01/k2_ab.txt)
-  if (algo != 1 && (nt & 3)) {
-    switch (nt & 3) {
-      case 1: OFFK_K2_LAUNCH(0, 1, 0, 0); break;
-      case 2: OFFK_K2_LAUNCH(0, 0, 1, 0); break;
-      default: OFFK_K2_LAUNCH(0, 1, 1, 0); break;
-    }
-    return hipGetLastError();
+#define OFFK_K2_NTSEL(A, T4)                       \
+  switch (nt & 3) {                                \
+    case 0: OFFK_K2_LAUNCH(A, 0, 0, T4); break;    \
+    case 1: OFFK_K2_LAUNCH(A, 1, 0, T4); break;    \
+    case 2: OFFK_K2_LAUNCH(A, 0, 1, T4); break;    \
+    default: OFFK_K2_LAUNCH(A, 1, 1, T4); break;   \
   }
+#else
+  (void)nt;
+  // rotation: nt loads + nt stores; flat form: its second read of every frame must hit a cache -> nt stores only
+#define OFFK_K2_NTSEL(A, T4) if (A == 2) OFFK_K2_LAUNCH(A, 0, 1, T4); else OFFK_K2_LAUNCH(A, 1, 1, T4);
 #endif
-  if (algo == 1) {
+  if (talgo == 1) {
     if (q.taps4) OFFK_K2_LAUNCH(1, 0, 0, 1); else OFFK_K2_LAUNCH(1, 0, 0, 0);
-  } else if (algo >= 4) {
-    if (q.taps4) OFFK_K2_LAUNCH(2, 0, 0, 1); else OFFK_K2_LAUNCH(2, 0, 0, 0);
+  } else if (talgo == 2) {
+    if (q.taps4) { OFFK_K2_NTSEL(2, 1) } else { OFFK_K2_NTSEL(2, 0) }
   } else {
-    if (q.taps4) OFFK_K2_LAUNCH(0, 0, 0, 1); else OFFK_K2_LAUNCH(0, 0, 0, 0);
+    if (q.taps4) { OFFK_K2_NTSEL(0, 1) } else { OFFK_K2_NTSEL(0, 0) }
   }
+#undef OFFK_K2_NTSEL
 #undef OFFK_K2_LAUNCH
   return hipGetLastError();
 }

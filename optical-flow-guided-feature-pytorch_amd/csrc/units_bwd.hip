@@ -29,6 +29,18 @@ constexpr int UB_THREADS = 256;
 constexpr int UB_STAGE_MAX = 9;   // as ST_STAGE_MAX / ST_OUT_MAX in sobel_tdiff.hip
 constexpr int UB_OUT_MAX = 7;
 constexpr int UB_TGROUP = 7;      // frames per temporal step (L = 7 -> one step)
+// T-blocks: one (pixel, channel quad) task per thread (8 pixels per block, offk_api.hip kUbTpix) and non-temporal
+// accesses -- G, dT are read once and dG is next read by another kernel after a GB of other traffic.  The same recipe
+// took K2 (sobel_tdiff.hip) from 270 to 227 us.
+typedef float ubf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ub_ldnt(const float* q) {
+  const ubf4 v = __builtin_nontemporal_load(reinterpret_cast<const ubf4*>(q));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ub_stnt(float* q, float4 v) {
+  const ubf4 u = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(u, reinterpret_cast<ubf4*>(q));
+}
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -88,8 +100,8 @@ __global__ __launch_bounds__(UB_THREADS, 2) void units_bwd_kernel(UbParams p) { 
         float4 gv[UB_TGROUP], dt[UB_TGROUP];
 #pragma unroll
         for (int j = 0; j < UB_TGROUP; ++j) {   // branch-free (see the S-blocks): frames past the clip read the zero page
-          gv[j] = *reinterpret_cast<const float4*>(t0 + j < L ? g + (size_t)(t0 + j) * gstride : p.zeros);
-          dt[j] = *reinterpret_cast<const float4*>(t0 + j < T ? m + (size_t)(t0 + j) * mstride : p.zeros);
+          gv[j] = ub_ldnt(t0 + j < L ? g + (size_t)(t0 + j) * gstride : p.zeros);
+          dt[j] = ub_ldnt(t0 + j < T ? m + (size_t)(t0 + j) * mstride : p.zeros);
         }
 #pragma unroll
         for (int j = 0; j < UB_TGROUP; ++j)
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(UB_THREADS, 2) void units_bwd_kernel(UbParams p) { 
             float4 v = sub4(j ? dt[j - 1] : prev, dt[j]);
             v.x = gv[j].x > 0.f ? v.x : 0.f; v.y = gv[j].y > 0.f ? v.y : 0.f;
             v.z = gv[j].z > 0.f ? v.z : 0.f; v.w = gv[j].w > 0.f ? v.w : 0.f;
-            *reinterpret_cast<float4*>(dg + (size_t)(t0 + j) * gstride) = v;
+            ub_stnt(dg + (size_t)(t0 + j) * gstride, v);
           }
         prev = dt[UB_TGROUP - 1];
       }

@@ -34,12 +34,11 @@ def timed(algo, iters=20):
 
 
 configs = [{}]
-for tp in (8, 16, 32, 128):
+for nt in (0, 1, 2):
+    configs.append({"OFFK_K2_NT": nt})
+for tp in (4, 16, 32):
     configs.append({"OFFK_K2_TPIX": tp})
-for fr in (8, 16, 32, 128, 256):
-    configs.append({"OFFK_K2_FLATROWS": fr})
-configs += [{"OFFK_K2_ROWS28": 4}, {"OFFK_K2_ROWS28": 4, "OFFK_K2_TPIX": 16}, {"OFFK_K2_NT": 1}, {"OFFK_K2_NT": 2}, {"OFFK_K2_NT": 3},
-            {"OFFK_K2_ROWS14": 7}]
+configs += [{"OFFK_K2_FLATROWS": 16}, {"OFFK_K2_FLATROWS": 32}, {"OFFK_K2_FLATROWS": 32, "OFFK_K2_NT": 0}, {"OFFK_K2_ROWS28": 4}]
 print("config                                   rot+S   flat+S   T-rot  T-flat  S-only   (us; %d algorithmic bytes)" % full)
 for rnd in range(2):
     for cfg in configs:
