@@ -38,15 +38,24 @@ struct ConvArgs {
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   float* partial;      // [splitk][M][Co] when splitk > 1
+  unsigned x_bytes, w_bytes;   // PREC 2 (fp32, buffer addressing): bytes behind p.x + p.x_coff / behind p.w, both < 2^31
 #ifdef OFFK_CONV_TIMING
   unsigned long long* dbg;   // [8] timing sums of the bf16x3 producer / consumer waves (tools only)
 #endif
 #ifdef OFFK_TUNING_KNOBS
-  int ablate;                // tools only (OFFK_CONV_ABLATE): 1 no activation loads, 2 no weight loads, 4 no LDS stores, 8 no MFMAs
+  int ablate;                // tools only (OFFK_CONV_ABLATE): 1 no activation loads, 2 no weight loads, 4 no LDS stores, 8 no MFMAs, 16 no epilogue
 #endif
 };
 
-// PREC 0: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
+// PREC 0 / 2: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
+// PREC 2 is PREC 0 with a LEAN K loop (round 2).  On gfx950 the fp32 MFMA shares the SIMD's fp32 lanes with the vector ALU:
+// tools/mfma_f32_probe.hip shows every VALU instruction in the loop coming straight out of the matrix throughput, at any
+// occupancy (92 % with none, 76 % with 32 extra per 16 MFMAs, 63 % with 64).  The PREC 0 loop spends ~12 VALU instructions
+// per activation row and K-tile on addressing (two 64-bit multiplies, pointer selects) plus zero / ReLU selects before the
+// LDS store.  PREC 2 addresses through buffer descriptors instead: the per-row offset is loop-invariant, the (tap, chunk)
+// offset is a scalar (soffset), padding taps take the out-of-range offset 0x80000000 and the hardware returns zeros --
+// five cheap VALU instructions per activation row, none per weight row.  Needs both tensors below 2^31 bytes (checked on
+// the host, PREC 0 otherwise).
 // Threads: fp32 = 256 (4 waves, every wave loads and multiplies).  bf16x3 = 512: waves 0-3 are
 // CONSUMERS (ds_read + MFMA only), waves 4-7 are PRODUCERS (global loads two K-tiles ahead, the
 // fp32 -> bf16 hi/lo split and the LDS stores).  Each SIMD then holds one wave of each kind, so the
@@ -56,7 +65,8 @@ struct ConvArgs {
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 // second launch-bound = waves per SIMD (HIP), 4 = two 8-wave blocks per CU: keeps the bf16x3 tiles within 128 VGPRs
 // (the 128x128 tile compiled to 131 and ran one block per CU)
-__global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
+  constexpr bool F32 = !(PREC & 1), LEAN = PREC >= 2;      // PREC 3: the bf16x3 core with the same buffer-addressed loader
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;                         // fp32: [2][BM][LDS_K]
@@ -109,10 +119,27 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
   // fp32: weight rows of this block's N slab, fp32 [Co][K].  bf16x3: bf16 hi plane [Co][K] then lo plane.
   const float* wbase = p.w + (size_t)(n0 + (tid >> 3)) * K + 4 * (tid & 7);   // same byte offsets in both formats
 
+  // ---- PREC 2: buffer addressing (see the header comment) ----
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  int rowoff[LEAN ? NRA : 1], woff[LEAN ? NRB : 1];
+  __amdgpu_buffer_rsrc_t xrs, wrs;
+  if constexpr (LEAN) {
+    // the descriptor base sits (pad rows + pad pixels) in front of the tensor, so that the per-row offset of the window's
+    // top-left corner is never negative; the scalar tap offset brings every VALID tap back inside the tensor
+    const int bias_px = p.pad * p.W + p.pad;
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + p.x_coff - (long)bias_px * p.x_cs, 0,
+                                            (int)(p.x_bytes + (unsigned)bias_px * p.x_cs * 4u), 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < NRA; ++r)      // hi0 + pad = ho * S, wi0 + pad = wo * S
+      rowoff[r] = hi0[r] < -50000 ? 0 : ((pix0[r] + (hi0[r] + p.pad) * p.W + (wi0[r] + p.pad)) * p.x_cs + kpos) * 4;   // rows past M: never valid
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) woff[r] = ((n0 + (tid >> 3) + 32 * r) * K + 4 * (tid & 7)) * 4;
+  }
   constexpr int NRG = NRA * VA + NRB * VB;
   // prefetch registers: A rows then B rows (one array per set: separate A / B arrays end up in scratch).
   // rg0 is the only set of the fp32 path; the bf16x3 producers alternate rg0 / rg1 (loads two tiles ahead).
-  float4 rg0[NRG], rg1[PREC == 0 ? 1 : NRG];
+  float4 rg0[NRG], rg1[F32 ? 1 : NRG];
   unsigned okm0 = 0, okm1 = 0;   // bit r: activation row r of the set is inside the image (else it reads as zero)
   // Loads are branch-free and nothing touches the loaded values here: a padding tap reads pixel 0 through a
   // selected pointer and is zeroed by store_tile, ReLU-on-load is applied there as well.  With
@@ -121,6 +148,28 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
   auto load_tile = [&](float4 (&rg)[NRG], unsigned& okm, int kt) {
     int chunk = kt / TAPS, tap = kt - chunk * TAPS, c0 = chunk * BK;
     int kh = tap / KW, kw = tap - kh * KW;
+    if constexpr (LEAN) {
+      const int soff_a = ((kh * p.W + kw) * p.x_cs + c0) * 4, soff_b = kt * BK * 4;     // scalar
+#pragma unroll
+      for (int r = 0; r < NRA; ++r) {
+#ifdef OFFK_TUNING_KNOBS
+        if (p.ablate & 1) continue;
+#endif
+        const bool ok = (unsigned)(hi0[r] + kh) < (unsigned)p.H && (unsigned)(wi0[r] + kw) < (unsigned)p.W;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? rowoff[r] : (int)0x80000000, soff_a, 0);
+        rg[r] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) {
+#ifdef OFFK_TUNING_KNOBS
+        if (p.ablate & 2) continue;
+#endif
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[r], soff_b, 0);
+        rg[NRA * VA + r] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+      okm = 0xffffffffu;      // padding taps already read as zeros
+      return;
+    }
     unsigned mask = 0;
 #pragma unroll
     for (int r = 0; r < NRA; ++r) {
@@ -150,14 +199,14 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
   char* smem_c = reinterpret_cast<char*>(smem);
   auto a_value = [&](const float4 (&rg)[NRG], unsigned okm, int r) {
     float4 t = rg[r];
-    if (!((okm >> r) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!LEAN && !((okm >> r) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
     return relu_in ? relu4(t) : t;
   };
   auto store_tile = [&](const float4 (&rg)[NRG], unsigned okm, int stage) {
 #ifdef OFFK_TUNING_KNOBS
     if (p.ablate & 4) return;
 #endif
-    if (PREC == 0) {
+    if (F32) {
       float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
       for (int r = 0; r < NRA; ++r)
@@ -218,19 +267,28 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
 
   WaveAcc<TM, TN> acc;
   acc.zero();
-  if constexpr (PREC == 0) {
+  if constexpr (F32) {
     load_tile(rg0, okm0, kt_begin);
     store_tile(rg0, okm0, 0);
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int st = (kt - kt_begin) & 1;
-      if (kt + 1 < kt_end) load_tile(rg0, okm0, kt + 1);
+      // unconditional prefetch + store (the last step re-loads its own tile into the idle stage): with
+      // `if (kt + 1 < kt_end) load_tile(...)` the two paths merge in a phi and hipcc reconciles the prefetch registers
+      // with v_mov copies of the just-issued loads -- an s_waitcnt vmcnt in FRONT of the MFMAs, i.e. a memory latency
+      // exposed per K-tile instead of hidden behind them
+      if constexpr (LEAN) {
+        load_tile(rg0, okm0, min(kt + 1, kt_end - 1));
+        __builtin_amdgcn_sched_barrier(0);    // keep the loads in FRONT of the MFMAs (hipcc sinks them behind most of them otherwise)
+      } else {
+        if (kt + 1 < kt_end) load_tile(rg0, okm0, kt + 1);     // 64-bit pointer loader: the conditional form measured faster
+      }
 #ifdef OFFK_TUNING_KNOBS
       if (!(p.ablate & 8))
 #endif
       acc.mma_ktile(As0 + st * BM * LDS_K + wm * (32 * TM) * LDS_K,
                     Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
-      if (kt + 1 < kt_end) store_tile(rg0, okm0, st ^ 1);
+      if (LEAN || kt + 1 < kt_end) store_tile(rg0, okm0, st ^ 1);
       __syncthreads();
     }
   } else {
@@ -238,8 +296,14 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
       // ---- producers: tile t is stored one step before it is consumed and loaded two steps before that
       load_tile(rg0, okm0, kt_begin);
       store_tile(rg0, okm0, 0);
-      if (kt_begin + 1 < kt_end) load_tile(rg0, okm0, kt_begin + 1);
-      if (kt_begin + 2 < kt_end) load_tile(rg1, okm1, kt_begin + 2);
+      // unconditional loads / stores with a clamped tile index (see the fp32 loop): no phi copies of in-flight loads
+      // LEAN: unconditional loads / stores with a clamped tile index (see the fp32 loop)
+      auto prefetch = [&](float4 (&rg)[NRG], unsigned& okm, int t) {
+        if constexpr (LEAN) load_tile(rg, okm, min(t, kt_end - 1));
+        else if (t < kt_end) load_tile(rg, okm, t);
+      };
+      prefetch(rg0, okm0, kt_begin + 1);
+      prefetch(rg1, okm1, kt_begin + 2);
       __syncthreads();
       int kt = kt_begin;
 #ifdef OFFK_CONV_TIMING
@@ -250,10 +314,10 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
 #endif
       for (; kt + 1 < kt_end; kt += 2) {
         OFFK_T(t_st, store_tile(rg0, okm0, 1))                 // tile kt+1 while tile kt is multiplied
-        OFFK_T(t_ld, if (kt + 3 < kt_end) load_tile(rg0, okm0, kt + 3))
+        OFFK_T(t_ld, prefetch(rg0, okm0, kt + 3))
         OFFK_T(t_pb, __syncthreads())
-        OFFK_T(t_st, if (kt + 2 < kt_end) store_tile(rg1, okm1, 0))   // tile kt+2 while tile kt+1 is multiplied
-        OFFK_T(t_ld, if (kt + 4 < kt_end) load_tile(rg1, okm1, kt + 4))
+        OFFK_T(t_st, if (LEAN || kt + 2 < kt_end) store_tile(rg1, okm1, 0))   // tile kt+2 while tile kt+1 is multiplied
+        OFFK_T(t_ld, prefetch(rg1, okm1, kt + 4))
         OFFK_T(t_pb, __syncthreads())
       }
 #undef OFFK_T
@@ -285,6 +349,19 @@ __global__ __launch_bounds__(PREC == 0 ? 256 : 512, (PREC == 1 && TM * TN <= 4) 
   }
 
   const int r32 = lane & 31, h = lane >> 5;
+#ifdef OFFK_TUNING_KNOBS
+  if (p.ablate & 16) {   // no epilogue: keep the accumulators alive without storing them
+    float sacc = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) sacc += acc.acc[tm][tn][reg];
+    if (sacc == 12345.678f) p.y[0] = sacc;
+    return;
+  }
+#endif
   if (p.splitk > 1) {   // raw partial sums; bias / ReLU / residual happen in splitk_reduce_kernel
     float* part = p.partial + (size_t)zs * p.M * p.Co;
 #pragma unroll
@@ -935,7 +1012,7 @@ static hipError_t launch_patch_shape(const ConvArgs& a, int KH, int S, int W, in
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = PREC == 0 ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64;
+  constexpr size_t lds = !(PREC & 1) ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64;
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN, PREC>;
   {
@@ -944,7 +1021,7 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   }
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;
-  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(PREC == 0 ? 256 : 512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(!(PREC & 1) ? 256 : 512), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.splitk == 1) return e;
   size_t n4 = (size_t)a.M * (a.Co / 4);
@@ -974,7 +1051,9 @@ static hipError_t launch_prec(const ConvArgs& a, int cfg, hipStream_t st) {
 }
 template <int KH, int KW, int S>
 static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t st) {
-  return prec == 0 ? launch_prec<KH, KW, S, 0>(a, cfg, st) : launch_prec<KH, KW, S, 1>(a, cfg, st);
+  // the lean (buffer-addressed) loader when both tensors fit 31-bit byte offsets
+  if (prec == 1) return a.x_bytes ? launch_prec<KH, KW, S, 3>(a, cfg, st) : launch_prec<KH, KW, S, 1>(a, cfg, st);
+  return a.x_bytes ? launch_prec<KH, KW, S, 2>(a, cfg, st) : launch_prec<KH, KW, S, 0>(a, cfg, st);
 }
 
 // Heuristic when the caller gives no plan, distilled from tools/tune_conv.py sweeps on MI355X:
@@ -1013,6 +1092,18 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.res = d.res; a.res_cs = d.res_cs; a.res_coff = d.res_coff;
   a.y = d.y; a.y_cs = d.y_cs; a.y_coff = d.y_coff;
   a.flags = d.flags;
+  {
+    // PREC 2 needs 31-bit byte offsets: input bytes behind x + x_coff (+ the descriptor bias), weight bytes
+    const unsigned long long xb = ((unsigned long long)d.n_img * d.H * d.W * d.x_cs - d.x_coff) * 4ull;
+    const unsigned long long bias = (unsigned long long)(d.pad * d.W + d.pad) * d.x_cs * 4ull;
+    const unsigned long long wb = (unsigned long long)d.Co * d.KH * d.KW * d.Ci * 4ull;
+    const bool fits = xb + bias < 0x7fffffffull && wb < 0x7fffffffull;
+    a.x_bytes = fits ? (unsigned)xb : 0u;
+    a.w_bytes = fits ? (unsigned)wb : 0u;
+#ifdef OFFK_TUNING_KNOBS
+    { const char* e = getenv("OFFK_CONV_LEAN"); if (e && !((atoi(e) >> (d.precision & 1)) & 1)) a.x_bytes = 0; }   // bit 0 fp32, bit 1 bf16x3
+#endif
+  }
   long long M = (long long)d.n_img * a.Ho * a.Wo;
   if (M <= 0 || M > 0x7fffffffLL - 256) { *why = "conv2d: bad problem size"; return hipErrorInvalidValue; }
   a.M = (int)M;

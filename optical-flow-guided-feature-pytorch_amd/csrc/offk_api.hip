@@ -50,10 +50,12 @@ const ConvSpec kConvs[kNumConvs] = {
     {"motion_conv3_trans", 1024, 256, 1, 1, 0},      {"motion_conv_branch_trans", 1024, 256, 1, 1, 0}};
 // (tile_cfg, splitk) per fusion conv measured fastest by tools/tune_conv.py at P = 384 pairs
 // (BASELINE config 2: B = 64, L = 7) on MI355X; other sizes use conv2d_auto_plan.
+// (round 2: re-tuned in situ, tools/tune_forward.py --precision fp32, after the fp32 K loop went lean -- with the addressing
+// VALU gone the 64x64 tile wins almost everywhere: 6.13 -> 5.89 ms; profiles/r02/tune_fp32_lean.txt)
 const int kTunedP384[kNumConvs][2] = {
-    {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
-    {4, 12}, {3, 1}, {0, 3}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {4, 1},                          // fusion @14
-    {0, 6}, {3, 1}, {4, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+    {3, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
+    {3, 12}, {3, 1}, {3, 2}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {3, 1},                          // fusion @14
+    {3, 6}, {3, 1}, {3, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
     {10, 4}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},  // fusion @28 (10 = half-chunk patch kernel)
@@ -125,7 +127,7 @@ struct offk_handle {
   float* merged_w[3] = {};
   float* merged_wb3[3] = {};
   float* merged_b[3] = {};
-  int merged_cfg[3] = {3, 3, 0}, merged_sk[3] = {1, 1, 1};   // merged_7 (512 -> 1024): the 128x128 tile, in-situ sweep
+  int merged_cfg[3] = {3, 3, 0}, merged_sk[3] = {1, 1, 1};   // bf16x3: merged_7 (512 -> 1024) on the 128x128 tile; fp32: 64x64 (offk_create)
   bool merged_dirty = true;
   // the 28- and 14-heads only depend on sum_28c / sum_14b: they run on a side stream beside the later
   // fusion stages and are joined back into the caller's stream before offk_forward returns
@@ -581,6 +583,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
+  if (cfg->precision == OFFK_PRECISION_FP32) h->merged_cfg[2] = 3;   // in-situ sweep of the lean fp32 kernel
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;
   for (int s = 0; s < kNumSites && rc == OFFK_OK; ++s) {

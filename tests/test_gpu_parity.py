@@ -102,6 +102,25 @@ def test_conv2d_epilogues_and_slices(rt):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
+def test_conv2d_input_slab_beyond_31_bit_offsets(rt, prec):
+    """The buffer-descriptor loader is used only while every byte offset fits 31 bits; a slice of a > 2 GiB slab must
+    take the 64-bit pointer loader and give the same answer (the last images sit beyond the 2 GiB mark)."""
+    g = torch.Generator().manual_seed(11)
+    n, H, cs, Ci, Co, coff = 46, 56, 4096, 32, 64, 2048
+    assert n * H * H * cs * 4 > 2 ** 31
+    x = torch.randn(n, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    slab = torch.empty(n, H, H, cs, device="cuda")
+    slab[..., coff:coff + Ci] = nhwc(x)
+    y = rt.conv2d_nhwc(slab, dev(w), dev(b), 1, 1, x_coff=coff, ci=Ci, precision=prec)
+    del slab
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < RTOL
+    assert rel_err(y[-1:].permute(0, 3, 1, 2), ref[-1:]) < RTOL
+
+
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("cfg,splitk", [(0, 1), (1, 3), (2, 2), (3, 4), (4, 1), (5, 2), (-1, 0)])
 def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk, prec):
     """Every tile configuration and the deterministic split-K reduction give the same conv."""

@@ -36,16 +36,27 @@ CAND = {
 
 # exact-fp32 mode: the LDS-patch kernel (6 = 128 channels per block, 7 = 64) against the built-in generic plans
 CAND_FP32 = {
-    "motion_conv_trans_28": [(3, 3), (7, 1), (7, 2), (7, 3), (7, 5)],
-    "motion_conv2_trans_28a": [(3, 1), (7, 1), (7, 2)],
-    "motion_conv2_trans_28b": [(3, 1), (7, 1), (7, 2)],
-    "motion_conv2_trans_28c": [(3, 1), (7, 1), (7, 2)],
-    "motion_conv_trans_14": [(4, 12), (7, 3), (7, 4), (7, 6), (7, 11), (6, 4), (6, 8), (6, 11)],
-    "motion_conv2_trans_14a": [(0, 3), (7, 1), (7, 2), (7, 4), (6, 2), (6, 4)],
-    "motion_conv2_trans_14b": [(0, 3), (7, 1), (7, 2), (7, 4), (6, 2), (6, 4)],
-    "motion_conv3_trans_14b": [(4, 1), (7, 1), (7, 2), (6, 1), (6, 2), (6, 4)],
-    "motion_conv_trans": [(0, 6), (7, 2), (7, 4), (7, 6), (6, 4), (6, 6), (6, 13)],
-    "motion_conv2_trans": [(4, 3), (7, 1), (7, 2), (7, 4), (6, 2), (6, 4), (6, 8)],
+    "motion_conv_trans_28": [(3, 3), (3, 2), (3, 4), (3, 6), (1, 3), (1, 6), (2, 6), (7, 2)],
+    "motion_conv1_trans_28a": [(3, 1), (1, 1)],
+    "motion_conv2_trans_28a": [(3, 1), (1, 1), (3, 2)],
+    "merged_28a": [(3, 1), (1, 1), (4, 1), (0, 1)],
+    "motion_conv1_trans_28b": [(3, 1), (1, 1)],
+    "motion_conv2_trans_28b": [(3, 1), (1, 1), (3, 2)],
+    "motion_conv3_trans_28b": [(3, 1), (1, 1), (4, 1), (0, 1)],
+    "motion_conv1_trans_28c": [(3, 1), (1, 1)],
+    "motion_conv2_trans_28c": [(3, 1), (1, 1), (3, 2)],
+    "motion_conv3_trans_28c": [(3, 1), (1, 1), (4, 1), (0, 1)],
+    "motion_conv_trans_14": [(4, 12), (4, 8), (4, 6), (3, 6), (3, 12), (0, 6), (0, 12), (1, 12)],
+    "motion_conv1_trans_14a": [(3, 1), (4, 1), (3, 2)],
+    "motion_conv2_trans_14a": [(0, 3), (4, 3), (3, 3), (3, 2), (4, 2)],
+    "merged_14a": [(3, 1), (4, 1), (0, 1)],
+    "motion_conv1_trans_14b": [(3, 2), (3, 1), (4, 1), (3, 4)],
+    "motion_conv2_trans_14b": [(0, 3), (4, 3), (3, 3), (3, 2), (4, 2)],
+    "motion_conv3_trans_14b": [(4, 1), (0, 1), (3, 1), (4, 2), (6, 2)],
+    "motion_conv_trans": [(0, 6), (0, 4), (4, 6), (4, 4), (0, 8), (3, 6), (6, 4)],
+    "motion_conv1_trans": [(3, 1), (4, 1), (0, 1)],
+    "motion_conv2_trans": [(4, 3), (0, 3), (4, 2), (3, 3), (6, 4)],
+    "merged_7": [(3, 1), (4, 1), (0, 1)],
 }
 
 
