@@ -43,8 +43,15 @@ int pt_tgroups(int L) { return L <= PT_FT ? 1 : (L - 2) / (PT_FT - 1) + 1; }
 // registers and waits a memory latency per K-tile.
 typedef float f4v __attribute__((ext_vector_type(4)));
 // NT bit 0: non-temporal loads of the feature map (read once); bit 1: non-temporal stores of T and D
-template <int PREC, int PC, int NT>
+// LEAN: buffer-descriptor addressing (every feature-map part and the weight tables < 2^31 bytes): the per-K-tile address
+// arithmetic is scalar (part pick, channel offset) plus one 24-bit multiply-add per frame slot, pixel quads are read where
+// they lie (a quad over the end of the tensor reads zeros, over the end of a plane the next plane's pixels -- rows that
+// are never written), and the prefetch is unconditional and pinned in front of the MFMAs as in conv_igemm.hip.  The
+// fp32 MFMA shares its lanes with the VALU: the ~90 64-bit address / select / shift instructions of the pointer form
+// per K-tile were matrix time.
+template <int PREC, int PC, int NT, int LEAN>
 __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p) {
+  static_assert(!(PC && LEAN), "producer / consumer form keeps the pointer loader");
   static_assert(PC == 0 || PREC == 1, "producer / consumer form is bf16x3 only");
   constexpr int A_PLANE = PT_BM * B3_ROW, B_PLANE = PT_BN * B3_ROW;
   constexpr int STAGE = PREC == 0 ? (PT_BM + PT_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   // ---- loader: thread = (k quad kq, pixel quad pq, frame select fs): frames fs and fs + 4 --------------------
   const int kq = tid & 7, pq = (tid >> 3) & 7, fs = tid >> 6;
   const int k0px = q0 + 4 * pq, kkpx = min(k0px, HW - 4);       // a quad that straddles the plane end is read from HW-4
-  const int sh = k0px < HW ? k0px - kkpx : 0;                    // and shifted into place (HW % 4 != 0 only)
+  const int sh = !LEAN && k0px < HW ? k0px - kkpx : 0;           // and shifted into place (HW % 4 != 0 only)
   const bool px_ok = k0px < HW;
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   auto locate = [&](int k0, const float*& xb, int& cpart, int& kl) {
@@ -98,9 +105,46 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   float4 rg[PC ? 2 * NRG : NRG];      // PC: two sets (one array: separate ones go to scratch)
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   const float* wdbase = S.w_down + (size_t)(tid >> 3) * C + 4 * (tid & 7);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t wrs, wdrs;
+  int jA[2], vA[2], woff = 0;
+  if constexpr (LEAN) {
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.w), 0, kGenCh * C * 4, 0x00020000);
+    wdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.w_down), 0, kDownCh * C * 4, 0x00020000);
+    woff = ((tid >> 3) * C + 4 * (tid & 7)) * 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int j = fs + 4 * half;
+      const bool ok = px_ok && j < nf;
+      jA[half] = ok ? j : 0;                                          // frame slot past the group / pixel quad past the
+      vA[half] = ok ? (4 * kq * HW + k0px) * 4 : (int)0x80000000;     // plane: an offset past every descriptor -> zeros
+    }
+  }
   auto load_tile = [&](const int set, int k0) {
     const float* xb; int cpart, kl;
     locate(k0, xb, cpart, kl);
+    if constexpr (LEAN) {
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.B * L * cpart * HW * 4, 0x00020000);
+      const int fstride = cpart * HW * 4;                                   // bytes per frame of this part (scalar)
+      const int s0 = (((b * L + t0) * cpart + kl) * HW) * 4;                // scalar: frame t0, channel kl
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int voff = jA[half] * fstride + vA[half];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s0 + i * HW * 4, 0);
+          rg[set + 4 * half + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, (32 * r * C + k0) * 4, 0);
+        rg[set + 8 + r] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wdrs, woff, k0 * 4, 0);
+      rg[set + 12] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int j = fs + 4 * half;
@@ -118,7 +162,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     rg[set + 12] = *reinterpret_cast<const float4*>(wdbase + k0);
   };
   auto shifted = [&](float4 v) {
-    if (sh == 0) return v;
+    if (LEAN || sh == 0) return v;
     return sh == 1 ? make_float4(v.y, v.z, v.w, 0.f) : (sh == 2 ? make_float4(v.z, v.w, 0.f, 0.f) : make_float4(v.w, 0.f, 0.f, 0.f));
   };
   auto store_tile = [&](const int set, int stage) {
@@ -203,7 +247,12 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
       OFFK_TICK(t_st)
       __syncthreads();
       OFFK_TICK(t_s1)
-      if (kt + 1 < nkt) load_tile(0, (kt + 1) * BK);
+      if constexpr (LEAN) {
+        load_tile(0, min(kt + 1, nkt - 1) * BK);      // unconditional (no phi copies of in-flight loads), and kept in
+        __builtin_amdgcn_sched_barrier(0);            // front of the MFMAs
+      } else {
+        if (kt + 1 < nkt) load_tile(0, (kt + 1) * BK);
+      }
       OFFK_TICK(t_ld)
     }
     const char* Ahi = lds + (PC ? (kt & 1) * STAGE : 0);
@@ -363,26 +412,37 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #endif
   constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4, kStageB3 = 2 * (size_t)(PT_BM + PT_BN) * B3_ROW;
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
+  // buffer addressing needs every byte offset below 2^31: each feature-map part and the weight tables
+  bool lean = true;
+  for (int i = 0; i < p.nsites; ++i) {
+    for (int q = 0; q < p.s[i].nparts; ++q)
+      if ((unsigned long long)p.B * p.L * p.s[i].cp[q] * p.s[i].HW * 4ull >= 0x7fffff00ull) lean = false;
+    if ((unsigned long long)kGenCh * p.s[i].C * 4ull >= 0x7fffff00ull) lean = false;
+  }
 #ifdef OFFK_TUNING_KNOBS
   const char* e = getenv("OFFK_PW_NT");
   const int nt = e ? atoi(e) : kNT;
   // OFFK_FUSED_PC=1: the 512-thread producer / consumer form (measured slower: 0.945 vs 0.828 ms, one block per CU)
   const char* pce = getenv("OFFK_FUSED_PC");
   if (p.precision == 1 && pce && *pce == '1') {
-    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1, 0>), (int)(2 * kStageB3));
+    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1, 0, 0>), (int)(2 * kStageB3));
     if (er != hipSuccess) return er;
-    hipLaunchKernelGGL((pw_tdiff_kernel<1, 1, 0>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
+    hipLaunchKernelGGL((pw_tdiff_kernel<1, 1, 0, 0>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
     return hipGetLastError();
   }
+  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = false; }   // bit 0 fp32, bit 1 bf16x3
 #define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
-  switch (nt & 3) {                                                                                                  \
-    case 0: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
-    case 1: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 1>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
-    case 2: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 2>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
-    default: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 3>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;     \
+  if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 1>), dim3(p.total_blocks), dim3(256), LDS, st, p);          \
+  else switch (nt & 3) {                                                                                             \
+    case 0: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;   \
+    case 1: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;   \
+    case 2: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 2, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;   \
+    default: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 3, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;  \
   }
 #else
-#define OFFK_PT_LAUNCH(P, LDS) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT>), dim3(p.total_blocks), dim3(256), LDS, st, p);
+#define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
+  if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 1>), dim3(p.total_blocks), dim3(256), LDS, st, p);        \
+  else hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);
 #endif
   if (p.precision == 0) { OFFK_PT_LAUNCH(0, kStage32) } else { OFFK_PT_LAUNCH(1, kStageB3) }
 #undef OFFK_PT_LAUNCH
