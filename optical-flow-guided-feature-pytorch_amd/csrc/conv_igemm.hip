@@ -122,6 +122,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   // ---- PREC 2: buffer addressing (see the header comment) ----
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   int rowoff[LEAN ? NRA : 1], woff[LEAN ? NRB : 1];
+  unsigned inv[LEAN ? NRA : 1];
   __amdgpu_buffer_rsrc_t xrs, wrs;
   if constexpr (LEAN) {
     // the descriptor base sits (pad rows + pad pixels) in front of the tensor, so that the per-row offset of the window's
@@ -131,8 +132,19 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
                                             (int)(p.x_bytes + (unsigned)bias_px * p.x_cs * 4u), 0x00020000);
     wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < NRA; ++r)      // hi0 + pad = ho * S, wi0 + pad = wo * S
+    for (int r = 0; r < NRA; ++r) {    // hi0 + pad = ho * S, wi0 + pad = wo * S
       rowoff[r] = hi0[r] < -50000 ? 0 : ((pix0[r] + (hi0[r] + p.pad) * p.W + (wi0[r] + p.pad)) * p.x_cs + kpos) * 4;   // rows past M: never valid
+      // tap validity, separable: bit kh = input row hi0 + kh outside the image, bit 16 + kw = input column outside.
+      // Per K-tile the test is then two shifts and an and-or (the fp32 MFMA shares its lanes with the VALU: every
+      // vector instruction in this loop is matrix time), against two adds, two compares and a select.
+      unsigned m = 0;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) m |= (unsigned)(hi0[r] + kh) >= (unsigned)p.H ? 1u << kh : 0u;
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) m |= (unsigned)(wi0[r] + kw) >= (unsigned)p.W ? 0x10000u << kw : 0u;
+      inv[r] = m;
+      if constexpr (TAPS == 1) rowoff[r] = m ? (int)0x80000000 : rowoff[r];
+    }
 #pragma unroll
     for (int r = 0; r < NRB; ++r) woff[r] = ((n0 + (tid >> 3) + 32 * r) * K + 4 * (tid & 7)) * 4;
   }
@@ -155,8 +167,9 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
 #ifdef OFFK_TUNING_KNOBS
         if (p.ablate & 1) continue;
 #endif
-        const bool ok = (unsigned)(hi0[r] + kh) < (unsigned)p.H && (unsigned)(wi0[r] + kw) < (unsigned)p.W;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? rowoff[r] : (int)0x80000000, soff_a, 0);
+        int voff = rowoff[r];        // a padding tap: an offset past the descriptor, the load returns zeros
+        if constexpr (TAPS > 1) voff |= (int)(((inv[r] << (31 - kh)) | (inv[r] << (15 - kw))) & 0x80000000u);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, soff_a, 0);
         rg[r] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
       }
 #pragma unroll
@@ -200,6 +213,11 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   auto a_value = [&](const float4 (&rg)[NRG], unsigned okm, int r) {
     float4 t = rg[r];
     if (!LEAN && !((okm >> r) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LEAN) {
+      // one integer max per value (a negative float is a negative integer); fmaxf costs a canonicalise + a max
+      auto rl = [](float x) { return __int_as_float(max(__float_as_int(x), 0)); };
+      return relu_in ? make_float4(rl(t.x), rl(t.y), rl(t.z), rl(t.w)) : t;
+    }
     return relu_in ? relu4(t) : t;
   };
   auto store_tile = [&](const float4 (&rg)[NRG], unsigned okm, int stage) {
@@ -271,9 +289,11 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     load_tile(rg0, okm0, kt_begin);
     store_tile(rg0, okm0, 0);
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int st = (kt - kt_begin) & 1;
-      // unconditional prefetch + store (the last step re-loads its own tile into the idle stage): with
+    // one K-tile: prefetch tile kt + 1 into registers, multiply stage `st`, store the prefetch into stage st ^ 1.
+    // `st` is a literal at both call sites (the loop is unrolled by two), so every LDS address is a register + an
+    // immediate; with st = (kt - kt_begin) & 1 each K-tile paid three vector adds for the stage offset.
+    auto step = [&](int kt, const int st) {
+      // LEAN: unconditional prefetch + store (the last step re-loads its own tile into the idle stage): with
       // `if (kt + 1 < kt_end) load_tile(...)` the two paths merge in a phi and hipcc reconciles the prefetch registers
       // with v_mov copies of the just-issued loads -- an s_waitcnt vmcnt in FRONT of the MFMAs, i.e. a memory latency
       // exposed per K-tile instead of hidden behind them
@@ -290,7 +310,13 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
                     Bs0 + st * BN * LDS_K + wn * (32 * TN) * LDS_K, lane);
       if (LEAN || kt + 1 < kt_end) store_tile(rg0, okm0, st ^ 1);
       __syncthreads();
+    };
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {      // (an exit between the two steps made hipcc copy the accumulators every round)
+      step(kt, 0);
+      step(kt + 1, 1);
     }
+    if (kt < kt_end) step(kt, 0);
   } else {
     if (wave >= 4) {
       // ---- producers: tile t is stored one step before it is consumed and loaded two steps before that

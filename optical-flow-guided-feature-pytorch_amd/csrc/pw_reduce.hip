@@ -93,7 +93,9 @@ __device__ __forceinline__ void stf(float* q, float v) {
   else *q = v;
 }
 
-template <int PREC, int NT>
+// LEAN: buffer-descriptor addressing of the weights and of the NCHW quad loader (mode 0), unconditional prefetch pinned
+// in front of the MFMAs -- as pw_tdiff.hip; needs every feature-map part and the weight tables below 2^31 bytes.
+template <int PREC, int NT, int LEAN>
 __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   constexpr int A_PLANE = PW_BM * B3_ROW, B_PLANE = PW_BN * B3_ROW;
   constexpr int LDS_BYTES = PREC == 0 ? (PW_BM + PW_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
@@ -173,6 +175,20 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   // weight rows (tid>>3) + 32 r: r = 0..3 gen rows, r = 4 the down rows (their own pointer: bound parameters need not be adjacent)
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   const float* wdbase = S.w_down + (size_t)(tid >> 3) * C + 4 * (tid & 7);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t wrs, wdrs;
+  int woff = 0, vA = 0;
+  if constexpr (LEAN) {
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.w), 0, kGenCh * C * 4, 0x00020000);
+    wdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.w_down), 0, kDownCh * C * 4, 0x00020000);
+    woff = ((tid >> 3) * C + 4 * (tid & 7)) * 4;
+    vA = row_ok ? (koff * HW + pix) * 4 : (int)0x80000000;     // rows past M: an offset past every descriptor -> zeros
+    if (!row_ok) fr = 0;
+  }
+  auto ld_b = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
   auto load_tile = [&](int k0) {
     const float* xb; int cpart, kl;
     locate(k0, xb, cpart, kl);
@@ -180,7 +196,12 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     if (p.ablate & 1) {
     } else
 #endif
-    if (mode == 0) {
+    if (LEAN && mode == 0) {
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (M / HW) * cpart * HW * 4, 0x00020000);
+      const int voff = fr * (cpart * HW * 4) + vA;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rg[j] = ld_b(xrs, voff, (kl + j) * HW * 4);
+    } else if (mode == 0) {
       // (the branch-free form -- masked rows reading a zero page through a selected pointer -- measured 5 % SLOWER here,
       // same box A/B in round 2: row_ok is false only in the last tile of a site and the branch is cheap)
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -211,6 +232,12 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
 #ifdef OFFK_TUNING_KNOBS
     if (p.ablate & 2) return;
 #endif
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int r = 0; r < PW_TN - 1; ++r) rg[4 + r] = ld_b(wrs, woff, (32 * r * C + k0) * 4);
+      rg[4 + PW_TN - 1] = ld_b(wdrs, woff, k0 * 4);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < PW_TN - 1; ++r)
       rg[4 + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * C + k0);
@@ -276,7 +303,12 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
   for (int kt = 0; kt < nkt; ++kt) {
     store_tile();
     __syncthreads();
-    if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+    if constexpr (LEAN) {
+      load_tile(min(kt + 1, nkt - 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+    }
 #ifdef OFFK_TUNING_KNOBS
     if (p.ablate & 8) {
     } else
@@ -334,18 +366,28 @@ hipError_t pw_reduce_launch(const PwParams& p_in, hipStream_t st) {
 #endif
   if (p.total_blocks <= 0) return hipSuccess;
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
+  bool lean = true;          // buffer addressing: every byte offset below 2^31
+  for (int i = 0; i < p.nsites; ++i) {
+    for (int q = 0; q < p.s[i].nparts; ++q)
+      if ((unsigned long long)p.s[i].M * p.s[i].cp[q] * 4ull >= 0x7fffff00ull) lean = false;
+    if ((unsigned long long)kGenCh * p.s[i].C * 4ull >= 0x7fffff00ull) lean = false;
+  }
 #ifdef OFFK_TUNING_KNOBS
   const char* e = getenv("OFFK_PW_NT");
   const int nt = e ? atoi(e) : kNT;
+  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = false; }
 #define OFFK_PW_LAUNCH(P)                                                                                             \
-  switch (nt & 3) {                                                                                                   \
-    case 0: hipLaunchKernelGGL((pw_reduce_kernel<P, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;           \
-    case 1: hipLaunchKernelGGL((pw_reduce_kernel<P, 1>), dim3(p.total_blocks), dim3(256), 0, st, p); break;           \
-    case 2: hipLaunchKernelGGL((pw_reduce_kernel<P, 2>), dim3(p.total_blocks), dim3(256), 0, st, p); break;           \
-    default: hipLaunchKernelGGL((pw_reduce_kernel<P, 3>), dim3(p.total_blocks), dim3(256), 0, st, p); break;          \
+  if (lean) hipLaunchKernelGGL((pw_reduce_kernel<P, 0, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);               \
+  else switch (nt & 3) {                                                                                              \
+    case 0: hipLaunchKernelGGL((pw_reduce_kernel<P, 0, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;        \
+    case 1: hipLaunchKernelGGL((pw_reduce_kernel<P, 1, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;        \
+    case 2: hipLaunchKernelGGL((pw_reduce_kernel<P, 2, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;        \
+    default: hipLaunchKernelGGL((pw_reduce_kernel<P, 3, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;       \
   }
 #else
-#define OFFK_PW_LAUNCH(P) hipLaunchKernelGGL((pw_reduce_kernel<P, kNT>), dim3(p.total_blocks), dim3(256), 0, st, p);
+#define OFFK_PW_LAUNCH(P)                                                                                             \
+  if (lean) hipLaunchKernelGGL((pw_reduce_kernel<P, kNT, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);             \
+  else hipLaunchKernelGGL((pw_reduce_kernel<P, kNT, 0>), dim3(p.total_blocks), dim3(256), 0, st, p);
 #endif
   if (p.precision == 0) { OFFK_PW_LAUNCH(0) } else { OFFK_PW_LAUNCH(1) }
 #undef OFFK_PW_LAUNCH
