@@ -53,16 +53,18 @@ const ConvSpec kConvs[kNumConvs] = {
 // (round 2: re-tuned in situ, tools/tune_forward.py --precision fp32, after the fp32 K loop went lean -- with the addressing
 // VALU gone the 64x64 tile wins almost everywhere: 6.13 -> 5.89 ms; profiles/r02/tune_fp32_lean.txt)
 const int kTunedP384[kNumConvs][2] = {
-    {3, 6}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
-    {3, 12}, {3, 1}, {3, 2}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {3, 1},                          // fusion @14
+    {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
+    {3, 6}, {3, 1}, {3, 2}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {3, 1},                           // fusion @14
     {3, 6}, {3, 1}, {3, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
-    {10, 4}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1},  // fusion @28 (10 = half-chunk patch kernel)
-    {0, 6}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {7, 1},                           // fusion @14
+    {1, 6}, {1, 1}, {7, 1}, {3, 1}, {3, 1}, {1, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {1, 1},   // fusion @28
+    {0, 8}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {3, 1}, {7, 1},                           // fusion @14
     {7, 4}, {4, 1}, {7, 1}, {3, 1}, {3, 1}};                                                   // fusion @7
-// tile_cfg 7 = the LDS-patch kernel (64 channels per block): wins the two 3x3 convs whose patch is small enough
-// for two blocks per CU (3x3 128->512 and 3x3 832->256 at 7x7)
+// tile_cfg 7 = the LDS-patch kernel (64 channels per block), 10 = its half-chunk form.  Round 2, after the generic kernel got
+// the buffer-addressed loader (tools/tune_forward.py, profiles/r02/tune_bf16x3_lean.txt): the generic tiles with split-K win
+// the 7x7 (128x64, split 6) back from the half-chunk patch kernel (5x5: 128x128, split 8); cfg 7 keeps the 3x3 convs at 7x7
+// (128->512, 832->256, 256->256: a tie with the generic tiles in the sweep, ahead in bench.py) and takes the 3x3 64->64 of block 28a
 // (re-tuned inside the whole forward with tools/tune_forward.py after the bf16x3 kernels were bounded to 128
 // VGPRs: the 128x128 tile now runs two blocks per CU and wins the 5x5 back from 64x128)
 // (main 1x1, branch 1x1) pairs whose outputs are summed: RGB_OFF.py:663-666, :768-770, :839-841
@@ -127,7 +129,7 @@ struct offk_handle {
   float* merged_w[3] = {};
   float* merged_wb3[3] = {};
   float* merged_b[3] = {};
-  int merged_cfg[3] = {3, 3, 0}, merged_sk[3] = {1, 1, 1};   // bf16x3: merged_7 (512 -> 1024) on the 128x128 tile; fp32: 64x64 (offk_create)
+  int merged_cfg[3] = {3, 4, 0}, merged_sk[3] = {1, 1, 1};   // bf16x3 (in-situ sweep, round 2); fp32: 64x64 everywhere (offk_create)
   bool merged_dirty = true;
   // the 28- and 14-heads only depend on sum_28c / sum_14b: they run on a side stream beside the later
   // fusion stages and are joined back into the caller's stream before offk_forward returns
@@ -583,7 +585,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
-  if (cfg->precision == OFFK_PRECISION_FP32) h->merged_cfg[2] = 3;   // in-situ sweep of the lean fp32 kernel
+  if (cfg->precision == OFFK_PRECISION_FP32) h->merged_cfg[1] = h->merged_cfg[2] = 3;   // in-situ sweep of the lean fp32 kernel
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;
   for (int s = 0; s < kNumSites && rc == OFFK_OK; ++s) {

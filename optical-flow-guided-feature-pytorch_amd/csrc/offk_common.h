@@ -38,26 +38,35 @@ struct WaveAcc {
   }
 
   // As / Bs: first LDS row of this wave's A / B slab.
+  // The operand quads of k-group g + 1 are read from LDS BEFORE the MFMAs of group g are issued (two register sets,
+  // a scheduling barrier pins the order): hipcc otherwise issues a group's reads behind the previous group's MFMAs
+  // and the wave sits out an LDS latency per group.
   __device__ __forceinline__ void mma_ktile(const float* As, const float* Bs, int lane) {
     const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      float4 a[TM], b[TN];
+    float4 a[2][TM], b[2][TN];
+    auto rd = [&](int g, float4 (&aa)[TM], float4 (&bb)[TN]) {
 #pragma unroll
       for (int t = 0; t < TM; ++t)
-        a[t] = *reinterpret_cast<const float4*>(As + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
+        aa[t] = *reinterpret_cast<const float4*>(As + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
 #pragma unroll
       for (int t = 0; t < TN; ++t)
-        b[t] = *reinterpret_cast<const float4*>(Bs + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
+        bb[t] = *reinterpret_cast<const float4*>(Bs + (t * 32 + r) * LDS_K + 8 * g + 4 * h);
+    };
+    rd(0, a[0], b[0]);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      if (g + 1 < BK / 8) rd(g + 1, a[(g + 1) & 1], b[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].x, b[g & 1][tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].y, b[g & 1][tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].z, b[g & 1][tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].w, b[g & 1][tn].w, acc[tm][tn], 0, 0, 0);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 };

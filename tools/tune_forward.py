@@ -15,6 +15,9 @@ import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
 CAND = {
+    "motion_conv2_trans_28a": [(1, 1), (7, 1), (3, 1), (4, 1)],
+    "motion_conv2_trans_28b": [(1, 1), (7, 1), (3, 1), (4, 1)],
+    "motion_conv2_trans_28c": [(1, 1), (7, 1), (3, 1), (4, 1)],
     "motion_conv1_trans_28a": [(3, 1), (1, 1)],
     "motion_conv1_trans_28b": [(3, 1), (1, 1)],
     "motion_conv1_trans_28c": [(3, 1), (1, 1)],
@@ -36,7 +39,7 @@ CAND = {
 
 # exact-fp32 mode: the LDS-patch kernel (6 = 128 channels per block, 7 = 64) against the built-in generic plans
 CAND_FP32 = {
-    "motion_conv_trans_28": [(3, 3), (3, 2), (3, 4), (3, 6), (1, 3), (1, 6), (2, 6), (7, 2)],
+    "motion_conv_trans_28": [(3, 6), (3, 3), (4, 6), (4, 3), (0, 6), (0, 3), (1, 6), (3, 4)],
     "motion_conv1_trans_28a": [(3, 1), (1, 1)],
     "motion_conv2_trans_28a": [(3, 1), (1, 1), (3, 2)],
     "merged_28a": [(3, 1), (1, 1), (4, 1), (0, 1)],
@@ -46,14 +49,14 @@ CAND_FP32 = {
     "motion_conv1_trans_28c": [(3, 1), (1, 1)],
     "motion_conv2_trans_28c": [(3, 1), (1, 1), (3, 2)],
     "motion_conv3_trans_28c": [(3, 1), (1, 1), (4, 1), (0, 1)],
-    "motion_conv_trans_14": [(4, 12), (4, 8), (4, 6), (3, 6), (3, 12), (0, 6), (0, 12), (1, 12)],
+    "motion_conv_trans_14": [(3, 12), (3, 6), (4, 12), (4, 6), (0, 6), (0, 12), (1, 12), (3, 8)],
     "motion_conv1_trans_14a": [(3, 1), (4, 1), (3, 2)],
     "motion_conv2_trans_14a": [(0, 3), (4, 3), (3, 3), (3, 2), (4, 2)],
     "merged_14a": [(3, 1), (4, 1), (0, 1)],
     "motion_conv1_trans_14b": [(3, 2), (3, 1), (4, 1), (3, 4)],
     "motion_conv2_trans_14b": [(0, 3), (4, 3), (3, 3), (3, 2), (4, 2)],
     "motion_conv3_trans_14b": [(4, 1), (0, 1), (3, 1), (4, 2), (6, 2)],
-    "motion_conv_trans": [(0, 6), (0, 4), (4, 6), (4, 4), (0, 8), (3, 6), (6, 4)],
+    "motion_conv_trans": [(3, 6), (4, 6), (0, 6), (0, 4), (4, 4), (3, 4), (1, 6)],
     "motion_conv1_trans": [(3, 1), (4, 1), (0, 1)],
     "motion_conv2_trans": [(4, 3), (0, 3), (4, 2), (3, 3), (6, 4)],
     "merged_7": [(3, 1), (4, 1), (0, 1)],
