@@ -71,14 +71,21 @@ const int kTunedP384B3[kNumConvs][2] = {
 struct MergedSpec { const char* name; int main_id, branch_id; };
 const MergedSpec kMerged[3] = {{"merged_28a", C3_28A, CB_28A}, {"merged_14a", C3_14A, CE_14A}, {"merged_7", C3_7, CB_7}};
 // test-time shape of the reference eval scripts: 10 crops x 25 segments -> P = 240 (test_rgb_off.py:24-25)
+// (round 2: both tables re-tuned in situ with the buffer-addressed loaders, tools/tune_forward.py --batch 10 --length 25 --wide:
+// fp32 3.64 -> 3.54 ms, bf16x3 1.77 -> 1.68 ms; profiles/r02/tune_p240_*.txt; splits the sweep reports beyond the slab space of
+// the workspace run unsplit and are written as 1 here)
 const int kTunedP240[kNumConvs][2] = {
     {3, 8}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},
-    {4, 8}, {3, 1}, {3, 2}, {3, 1}, {3, 1}, {3, 1}, {3, 2}, {4, 2},
-    {0, 8}, {3, 1}, {3, 1}, {3, 1}, {3, 1}};
-const int kTunedP240B3[kNumConvs][2] = {   // re-tuned in situ (tools/tune_forward.py --batch 10 --length 25): 2.02 -> 1.89 ms
-    {1, 4}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {4, 1}, {3, 1}, {3, 1}, {4, 1},
-    {0, 12}, {3, 1}, {4, 1}, {4, 1}, {4, 1}, {3, 1}, {3, 1}, {7, 1},
-    {7, 2}, {3, 1}, {7, 2}, {4, 1}, {4, 1}};
+    {3, 8}, {1, 1}, {3, 2}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1},
+    {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}};
+const int kTunedP240B3[kNumConvs][2] = {
+    {1, 2}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1},
+    {0, 12}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 2}, {3, 1}, {3, 1},
+    {7, 2}, {4, 1}, {3, 1}, {3, 1}, {3, 1}};
+// plans of the three merged 1x1 convs (kMerged order): [P == 240][bf16x3][conv] = {tile_cfg, splitk}
+const int kMergedPlan[2][2][3][2] = {
+    {{{3, 1}, {3, 1}, {3, 1}}, {{3, 1}, {4, 1}, {0, 1}}},                                         // P = 384 (and the default)
+    {{{1, 1}, {3, 1}, {3, 1}}, {{4, 1}, {1, 1}, {0, 1}}}};                                               // P = 240
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -129,7 +136,7 @@ struct offk_handle {
   float* merged_w[3] = {};
   float* merged_wb3[3] = {};
   float* merged_b[3] = {};
-  int merged_cfg[3] = {3, 4, 0}, merged_sk[3] = {1, 1, 1};   // bf16x3 (in-situ sweep, round 2); fp32: 64x64 everywhere (offk_create)
+  int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};   // kMergedPlan at offk_create
   bool merged_dirty = true;
   // the 28- and 14-heads only depend on sum_28c / sum_14b: they run on a side stream beside the later
   // fusion stages and are joined back into the caller's stream before offk_forward returns
@@ -585,7 +592,11 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
-  if (cfg->precision == OFFK_PRECISION_FP32) h->merged_cfg[1] = h->merged_cfg[2] = 3;   // in-situ sweep of the lean fp32 kernel
+  for (int m = 0; m < 3; ++m) {
+    const int (*mp)[2] = kMergedPlan[h->P == 240][cfg->precision == OFFK_PRECISION_BF16X3];
+    h->merged_cfg[m] = mp[m][0];
+    h->merged_sk[m] = mp[m][1];
+  }
   DeviceGuard guard(cfg->device);
   int rc = OFFK_OK;
   for (int s = 0; s < kNumSites && rc == OFFK_OK; ++s) {

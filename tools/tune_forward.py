@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--wide", action="store_true", help="every generic tile x a split-K ladder per conv (other batch shapes)")
     a = ap.parse_args()
     B, L = a.batch, a.length
     h = runtime.OffForward(B, L, spec.VARIANT_RGB, precision=a.precision)
@@ -95,7 +96,15 @@ def main():
     chosen = {}
     best = base
     for rnd in range(a.rounds):
-        for key, cands in (CAND_FP32 if a.precision == "fp32" else CAND).items():
+        table = CAND_FP32 if a.precision == "fp32" else CAND
+        if a.wide:
+            table = {}
+            for key in CAND_FP32:
+                small = "conv1_" in key or "merged" in key or "conv3_trans_28" in key
+                table[key] = [(c, k) for c in (3, 4, 1, 0) for k in ((1, 2) if small else (1, 2, 3, 4, 6, 8, 12))]
+                if not small and a.precision != "fp32":
+                    table[key] += [(7, 1), (7, 2), (7, 4), (10, 4), (5, 2), (5, 4)]
+        for key, cands in table.items():
             res = []
             for cfg, sk in cands:
                 h.set_conv_plan(key, cfg, sk)
