@@ -113,6 +113,7 @@ struct offk_handle {
   // packed device weights
   float* pw_w[kNumSites] = {};   // [160][C]
   float* pw_wb3[kNumSites] = {}; // bf16x3 mode: the same matrix pre-split per K-tile (hi 32 | lo 32)
+  float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   bool pw_dirty = true;
   bool pw_presplit = true;
   float* pw_b[kNumSites] = {};   // [160]
@@ -428,6 +429,8 @@ int finalize_pw(offk_handle* h, hipStream_t st) {
   if (h->cfg.precision == OFFK_PRECISION_BF16X3)
     for (int s = 0; s < kNumSites; ++s)
       HIP_TRY(h, split_bf16_launch(h->pw_w[s], (size_t)kUnitCh * kSites[s].C, h->pw_wb3[s], st));
+  for (int s = 0; s < kNumSites; ++s)
+    HIP_TRY(h, pw_pack_direct_launch(h->pw_w[s], kSites[s].C, h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0, h->pw_wt[s], st));
   h->pw_dirty = false;
   return OFFK_OK;
 }
@@ -470,6 +473,10 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   pt.precision = h->cfg.precision;
   pt.presplit = pw_presplit_now(h);
   pt.zeros = h->zero_page;
+  // the operand-order weight image is the library's own copy: not with contraction weights bound in place
+  pt.bdirect = 1;
+  for (int s = 0; s < kNumSites; ++s)
+    if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
@@ -479,6 +486,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
     for (int q = 0; q < 4; ++q) { o.xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o.cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
     o.nparts = fp.n_parts;
     pw_weight_ptrs(h, s, pt.presplit, &o.w, &o.w_down, &o.bias, &o.bias_down);
+    o.wt = h->pw_wt[s];
     o.D = region(h, ws, (std::string("D_") + kSites[s].name).c_str());
     o.M = region(h, ws, fus[kSiteFusion[s]]);
     o.m_cs = kFusionC[kSiteFusion[s]]; o.m_coff = kSiteCoff[s];
@@ -608,6 +616,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     add_slot(h, "motion_spatial_down_" + n + ".bias", {kDownCh}, SK_DOWN_B, s);
     rc = dev_alloc(h, &h->pw_w[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wb3[s], (size_t)kUnitCh * C);
+    if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_wt[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
     if (cfg->variant == OFFK_VARIANT_RGB_LEARNED_DW && rc == OFFK_OK) {
       add_slot(h, "motion_spatial_grad_" + n + ".weight", {kDownCh, 1, 3, 3}, SK_DW_W, s);

@@ -73,6 +73,7 @@ struct PtSite {
   int nparts;
   const float* w;       // gen rows [128][C] fp32, or pre-split for bf16x3 (as PwSite)
   const float* w_down;  // down rows [32][C]
+  const float* wt;      // PtParams.bdirect: all 160 rows packed in MFMA-operand order (pw_pack_direct_launch), read straight into registers
   const float* bias;    // [128]
   const float* bias_down;   // [32]
   float* D;             // [P*HW][32]
@@ -87,6 +88,7 @@ struct PtParams {
   int nsites, total_blocks;
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
+  int bdirect;               // every site carries wt: the weight operand bypasses LDS (two LDS stages for the feature-map tile)
   const float* zeros;
 #ifdef OFFK_PT_TIMING
   unsigned long long* dbg;   // cycle-counter sums (tools only)
@@ -94,6 +96,8 @@ struct PtParams {
 };
 int pt_tgroups(int L);
 hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);
+// w160: [160][C] fp32 (gen rows, then down rows) -> out (160 * C floats), the operand-order image pw_tdiff reads with bdirect
+hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float* out, hipStream_t st);
 
 // ---- K2 ------------------------------------------------------------------------
 struct StSite {
