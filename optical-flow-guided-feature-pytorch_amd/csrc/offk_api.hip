@@ -491,11 +491,8 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
     o.M = region(h, ws, fus[kSiteFusion[s]]);
     o.m_cs = kFusionC[kSiteFusion[s]]; o.m_coff = kSiteCoff[s];
     o.C = kSites[s].C; o.HW = kSites[s].H * kSites[s].H;
-    o.chunks = (o.HW + 31) / 32;
-    o.blk_begin = blk;
-    blk += h->cfg.batch * o.chunks * pt.tgroups;
   }
-  pt.total_blocks = blk;
+  (void)blk;     // block layout (chunks, leftover blocks, blk_begin, total_blocks): pw_tdiff_launch
   if (ev) HIP_TRY(h, hipEventRecord(ev[0], st));
   HIP_TRY(h, pw_tdiff_launch(pt, st));
   if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));

@@ -80,7 +80,13 @@ struct PtSite {
   float* M;             // fusion buffer: T goes to channels [m_coff + 32, m_coff + 160)
   int m_cs, m_coff;
   int C, HW;
-  int chunks;           // ceil(HW / 32) pixel chunks per clip
+  // block layout of the site, filled by pw_tdiff_launch: per temporal group, batch * chunks blocks of one (clip, 32-pixel
+  // chunk) each, then nrem blocks for the HW % 32 leftover pixels.  Buffer-addressed kernels pack the leftovers of
+  // 32 >> rsh ... clips into one block when HW % 32 is 4, 8 or 16 (28x28: two clips, 14x14: eight clips per block) --
+  // the seven 14x14 chunks of a clip were 6.125 chunks of work.
+  int chunks;           // pixel chunks of 32 per clip (packed: floor, else ceil)
+  int nrem;             // leftover blocks per temporal group (0: none)
+  int rsh;              // log2(leftover pixels per clip) in a packed leftover block; 5: one clip per block
   int blk_begin;
 };
 struct PtParams {

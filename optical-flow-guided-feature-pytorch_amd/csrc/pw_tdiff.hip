@@ -29,9 +29,9 @@ namespace {
 constexpr int PT_FT = 7;                 // frames (row tiles) per block
 constexpr int PT_BM = 32 * PT_FT, PT_BN = 160;
 
-__device__ __forceinline__ int pt_down_row(int f, int L, int P, int slice_mode) {
-  if (slice_mode == 0) return f < P ? f : -1;
-  const int b = f / L, t = f - b * L;
+// row of D for frame t of clip b (quirk Q1: reference_flat slices the flat frame axis)
+__device__ __forceinline__ int pt_down_row(int b, int t, int L, int P, int slice_mode) {
+  if (slice_mode == 0) { const int f = b * L + t; return f < P ? f : -1; }
   return t < L - 1 ? b * (L - 1) + t : -1;
 }
 }  // namespace
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   S.w = p.s[i].w; S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;           \
   S.w_down = p.s[i].w_down; S.bias_down = p.s[i].bias_down; S.wt = p.s[i].wt;                            \
   S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
+  S.nrem = p.s[i].nrem; S.rsh = p.s[i].rsh;                                                            \
   S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
   nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;          \
   S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
@@ -87,8 +88,12 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   const int C = S.C, HW = S.HW, L = p.L;
   int local = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site);   // neighbouring pixel chunks of a clip on one XCD
   const int tg = local % p.tgroups; local /= p.tgroups;
-  const int chunk = local % S.chunks, b = local / S.chunks;
-  const int q0 = chunk * 32;
+  // (clip, chunk) blocks first, then the leftover blocks (PtSite): a leftover block covers clips b .. b + (32 >> rsh) - 1
+  const int nfull = p.B * S.chunks;
+  const bool leftover = local >= nfull;
+  const int rsh = leftover ? S.rsh : 5, rmask = (1 << rsh) - 1;
+  const int b = leftover ? (local - nfull) << (5 - rsh) : local / S.chunks;
+  const int q0 = (leftover ? S.chunks : local - b * S.chunks) * 32;
   const int t0 = tg * (PT_FT - 1);
   const int nf = min(PT_FT, L - t0);          // frames of this block (>= 2)
   const bool last_group = tg == p.tgroups - 1;
@@ -97,9 +102,10 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 
   // ---- loader: thread = (k quad kq, pixel quad pq, frame select fs): frames fs and fs + 4 --------------------
   const int kq = tid & 7, pq = (tid >> 3) & 7, fs = tid >> 6;
-  const int k0px = q0 + 4 * pq, kkpx = min(k0px, HW - 4);       // a quad that straddles the plane end is read from HW-4
+  const int cq = (4 * pq) >> rsh;                                // clip of this thread's pixel quad within the block (0 unless packed)
+  const int k0px = q0 + ((4 * pq) & rmask), kkpx = min(k0px, HW - 4);   // a quad that straddles the plane end is read from HW-4
   const int sh = !LEAN && k0px < HW ? k0px - kkpx : 0;           // and shifted into place (HW % 4 != 0 only)
-  const bool px_ok = k0px < HW;
+  const bool px_ok = k0px < HW && b + cq < p.B;
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   auto locate = [&](int k0, const float*& xb, int& cpart, int& kl) {
     xb = S.xp[0]; cpart = S.cp[0]; kl = k0;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     for (int half = 0; half < 2; ++half) {
       const int j = fs + 4 * half;
       const bool ok = px_ok && j < nf;
-      jA[half] = ok ? j : 0;                                          // frame slot past the group / pixel quad past the
+      jA[half] = ok ? j + cq * L : 0;                                 // frame slot past the group / pixel quad past the
       vA[half] = ok ? (4 * kq * HW + k0px) * 4 : (int)0x80000000;     // plane: an offset past every descriptor -> zeros
     }
   }
@@ -446,12 +452,13 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
       asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
       acc[t][4 * g] = v.x; acc[t][4 * g + 1] = v.y; acc[t][4 * g + 2] = v.z; acc[t][4 * g + 3] = v.w;
     }
-  const size_t pair0 = (size_t)b * (L - 1) + t0;
-  const bool pix_ok = q0 + r32 < HW;
+  const int bl = b + (r32 >> rsh), pixl = q0 + (r32 & rmask);      // this lane's clip and pixel
+  const size_t pair0 = (size_t)bl * (L - 1) + t0;
+  const bool pix_ok = pixl < HW && bl < p.B;
 #pragma unroll
   for (int j = 0; j + 1 < PT_FT; ++j) {
     if (j + 1 < nf && pix_ok) {
-      float* mrow = S.M + ((pair0 + j) * HW + q0 + r32) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * h;
+      float* mrow = S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f4v tv = {acc[j + 1][4 * g] - acc[j][4 * g], acc[j + 1][4 * g + 1] - acc[j][4 * g + 1],
@@ -466,9 +473,9 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     const int j = wave + 4 * half;
     // the frame shared with the next temporal group belongs to that group
     if (j < nf && (last_group || j < PT_FT - 1) && pix_ok) {
-      const int dr = pt_down_row(b * L + t0 + j, L, p.P, p.slice_mode);
+      const int dr = pt_down_row(bl, t0 + j, L, p.P, p.slice_mode);
       if (dr >= 0) {
-        float* drow = S.D + ((size_t)dr * HW + q0 + r32) * kDownCh + 4 * h;
+        float* drow = S.D + ((size_t)dr * HW + pixl) * kDownCh + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f4v dv = {acc[PT_FT + half][4 * g], acc[PT_FT + half][4 * g + 1], acc[PT_FT + half][4 * g + 2], acc[PT_FT + half][4 * g + 3]};
@@ -515,7 +522,7 @@ hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float*
 
 hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   PtParams p = p_in;
-  if (p.total_blocks <= 0) return hipSuccess;
+  if (p.nsites <= 0 || p.B <= 0) return hipSuccess;
 #ifdef OFFK_PT_TIMING
   {
     static unsigned long long* dbg = nullptr;
@@ -548,19 +555,42 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
     if ((unsigned long long)kGenCh * p.s[i].C * 4ull >= 0x7fffff00ull) lean = false;
   }
   bool bd = lean && p.bdirect;
+  bool pack = lean;          // leftover pixels of several clips in one block: per-thread clip offsets need the buffer loader
+#ifdef OFFK_TUNING_KNOBS
+  { const char* pe = getenv("OFFK_PW_PACK"); if (pe && *pe == '0') pack = false; }
+  { const char* be = getenv("OFFK_PW_BDIRECT"); if (be && *be == '0') bd = false; }
+  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = bd = pack = false; }   // bit 0 fp32, bit 1 bf16x3
+  const char* pce = getenv("OFFK_FUSED_PC");
+  const bool pc_form = p.precision == 1 && pce && *pce == '1';
+  if (pc_form) lean = bd = pack = false;
+#endif
+  auto layout = [&]() {      // block layout of every site (PtSite)
+    int blk = 0;
+    for (int i = 0; i < p.nsites; ++i) {
+      PtSite& o = p.s[i];
+      const int rem = o.HW % 32;
+      // 16-byte pieces (4 leftover pixels per clip) cost a whole sector each: worth it where the kernel is MFMA-bound
+      // (fp32: 1.45 -> 1.36 ms), a loss where it is bound by the feature-map reads (bf16x3: 0.68 -> 0.76 ms)
+      const bool packed = pack && (rem == 16 || (p.precision == 0 && (rem == 4 || rem == 8)));
+      o.chunks = packed ? o.HW / 32 : (o.HW + 31) / 32;
+      o.rsh = packed ? (rem == 4 ? 2 : rem == 8 ? 3 : 4) : 5;
+      o.nrem = packed ? (p.B + (32 >> o.rsh) - 1) / (32 >> o.rsh) : 0;
+      o.blk_begin = blk;
+      blk += (p.B * o.chunks + o.nrem) * p.tgroups;
+    }
+    p.total_blocks = blk;
+  };
+  layout();
 #ifdef OFFK_TUNING_KNOBS
   const char* e = getenv("OFFK_PW_NT");
   const int nt = e ? atoi(e) : kNT;
-  { const char* be = getenv("OFFK_PW_BDIRECT"); if (be && *be == '0') bd = false; }
   // OFFK_FUSED_PC=1: the 512-thread producer / consumer form (measured slower: 0.945 vs 0.828 ms, one block per CU)
-  const char* pce = getenv("OFFK_FUSED_PC");
-  if (p.precision == 1 && pce && *pce == '1') {
+  if (pc_form) {
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1, 0, 0, 0>), (int)(2 * kStageB3));
     if (er != hipSuccess) return er;
     hipLaunchKernelGGL((pw_tdiff_kernel<1, 1, 0, 0, 0>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
     return hipGetLastError();
   }
-  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = false; }   // bit 0 fp32, bit 1 bf16x3
 #define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
   if (bd) OFFK_PT_LAUNCH_BD(P)                                                                                       \
   else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);  \
