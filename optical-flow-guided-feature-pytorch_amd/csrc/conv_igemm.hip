@@ -38,6 +38,7 @@ struct ConvArgs {
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   float* partial;      // [splitk][M][Co] when splitk > 1
+  int no_dma;                  // tools: keep the register-staged loader (OFFK_CONV_DMA=0 in the tuning build)
   unsigned x_bytes, w_bytes;   // PREC 2 (fp32, buffer addressing): bytes behind p.x + p.x_coff / behind p.w, both < 2^31
 #ifdef OFFK_CONV_TIMING
   unsigned long long* dbg;   // [8] timing sums of the bf16x3 producer / consumer waves (tools only)
@@ -56,17 +57,27 @@ struct ConvArgs {
 // offset is a scalar (soffset), padding taps take the out-of-range offset 0x80000000 and the hardware returns zeros --
 // five cheap VALU instructions per activation row, none per weight row.  Needs both tensors below 2^31 bytes (checked on
 // the host, PREC 0 otherwise).
+// PREC 4 is PREC 2 with the tiles moved global -> LDS by the load unit itself (`buffer_load_dwordx4 ... lds`): no
+// prefetch registers, no ds_write, no s_waitcnt vmcnt in front of an LDS store.  The probe prices four ds_write_b128 per
+// K-tile at 8-9 % of the matrix throughput (92 -> 84 %), which is what separated the PREC 2 loop from the probe's rate.
+// A wave instruction lands 64 x 16 B contiguously (8 rows of 128 B), so rows cannot be padded: position (row, slot) holds
+// the row's 16-byte chunk slot ^ ((row >> 1) & 7) -- the swizzle goes into each lane's SOURCE offset -- and the
+// ds_read_b128 of 16 consecutive rows stays conflict-free.  No ReLU-on-load (the data never passes a register): convs
+// with OFFK_CONV_RELU_IN use PREC 2.
 // Threads: fp32 = 256 (4 waves, every wave loads and multiplies).  bf16x3 = 512: waves 0-3 are
 // CONSUMERS (ds_read + MFMA only), waves 4-7 are PRODUCERS (global loads two K-tiles ahead, the
 // fp32 -> bf16 hi/lo split and the LDS stores).  Each SIMD then holds one wave of each kind, so the
 // split's VALU work and the LDS stores run beside the other wave's MFMAs instead of in front of
 // them (measured before the split: 39 % matrix-pipe busy with 20 % VALU and 26 % LDS time serialised
 // in the same waves).  One s_barrier per K-tile hands a filled LDS stage over.
+constexpr int kDmaStages = 2;   // 3 (tiles two ahead, 48 KB for the 64x64 tile = 3 blocks per CU) measured 2 % slower than 2
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 // second launch-bound = waves per SIMD (HIP), 4 = two 8-wave blocks per CU: keeps the bf16x3 tiles within 128 VGPRs
 // (the 128x128 tile compiled to 131 and ran one block per CU)
 __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr bool F32 = !(PREC & 1), LEAN = PREC >= 2;      // PREC 3: the bf16x3 core with the same buffer-addressed loader
+  constexpr bool DMA = PREC == 4;                          // fp32 core, tiles DMA'd into swizzled 128-byte LDS rows
+  constexpr int DST = kDmaStages;                          // DMA: LDS stages (tiles run DST - 1 ahead of the MFMAs)
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;                         // fp32: [2][BM][LDS_K]
@@ -98,7 +109,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   constexpr int RSH = 3, RSTEP = 32;
   constexpr int NRA = BM / RSTEP, NRB = BN / RSTEP;  // row visits per thread
   constexpr int VA = 1, VB = 1;
-  const int kpos = 4 * (tid & 7);
+  const int kpos = DMA ? 4 * ((tid & 7) ^ ((tid >> 4) & 7)) : 4 * (tid & 7);    // DMA: the chunk this LDS slot holds (row = (tid >> 3) + 32 r)
 
   int hi0[NRA], wi0[NRA];
   int pix0[NRA];      // image * H * W (fits: M and the feature maps are < 2^31 elements)
@@ -146,8 +157,44 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       if constexpr (TAPS == 1) rowoff[r] = m ? (int)0x80000000 : rowoff[r];
     }
 #pragma unroll
-    for (int r = 0; r < NRB; ++r) woff[r] = ((n0 + (tid >> 3) + 32 * r) * K + 4 * (tid & 7)) * 4;
+    for (int r = 0; r < NRB; ++r) woff[r] = ((n0 + (tid >> 3) + 32 * r) * K + kpos) * 4;
   }
+  // DMA: tile kt straight into LDS stage `stage`: wave w lands rows 8w + 32r .. + 7 of the A / B image, 1 KB per instruction.
+  // The instruction is issued through inline asm: with the builtin hipcc treats every later ds_read as a possible reader of
+  // the landing zone and puts s_waitcnt vmcnt(0) between the DMA and the MFMAs of the OTHER stage -- the overlap this
+  // path exists for.  Ordering is explicit instead: s_waitcnt vmcnt(0) + barrier before a stage is read.
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 xdesc = {0, 0, 0, 0}, wdesc = {0, 0, 0, 0};
+  unsigned lds_base = 0;
+  if constexpr (DMA) {
+    const int bias_px = p.pad * p.W + p.pad;
+    const unsigned long long xa = reinterpret_cast<unsigned long long>(p.x + p.x_coff - (long)bias_px * p.x_cs);
+    const unsigned long long wa = reinterpret_cast<unsigned long long>(p.w);
+    xdesc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, (int)(p.x_bytes + (unsigned)bias_px * p.x_cs * 4u), 0x00020000};
+    wdesc = i32x4{(int)(unsigned)wa, (int)(unsigned)(wa >> 32) & 0xffff, (int)p.w_bytes, 0x00020000};
+    lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) +
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (8 * 128);
+  }
+  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory");
+  };
+  auto dma_tile = [&](int kt, const int stage) {
+    if constexpr (DMA) {
+      int chunk = kt / TAPS, tap = kt - chunk * TAPS, c0 = chunk * BK;
+      int kh = tap / KW, kw = tap - kh * KW;
+      const int soff_a = ((kh * p.W + kw) * p.x_cs + c0) * 4, soff_b = kt * BK * 4;     // scalar
+      const unsigned la = lds_base + stage * (BM * 128), lb = lds_base + DST * (BM * 128) + stage * (BN * 128);
+#pragma unroll
+      for (int r = 0; r < NRA; ++r) {
+        int voff = rowoff[r];
+        if constexpr (TAPS > 1) voff |= (int)(((inv[r] << (31 - kh)) | (inv[r] << (15 - kw))) & 0x80000000u);
+        dma16(xdesc, la + r * 32 * 128, voff, soff_a);
+      }
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) dma16(wdesc, lb + r * 32 * 128, woff[r], soff_b);
+    }
+  };
   constexpr int NRG = NRA * VA + NRB * VB;
   // prefetch registers: A rows then B rows (one array per set: separate A / B arrays end up in scratch).
   // rg0 is the only set of the fp32 path; the bf16x3 producers alternate rg0 / rg1 (loads two tiles ahead).
@@ -285,7 +332,75 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
 
   WaveAcc<TM, TN> acc;
   acc.zero();
-  if constexpr (F32) {
+  if constexpr (DMA) {
+    // per-lane LDS byte offsets of the four k-groups: row r32 of the wave's slab, chunk (2g + h) ^ swizzle(row)
+    const int r32 = lane & 31, hh = lane >> 5, sw = hh ^ ((r32 >> 1) & 7);
+    int aoff[BK / 8], boff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      aoff[g] = (wm * (32 * TM) + r32) * 128 + ((sw ^ (2 * g)) << 4);
+      boff[g] = DST * (BM * 128) + (wn * (32 * TN) + r32) * 128 + ((sw ^ (2 * g)) << 4);
+    }
+    const char* const lds_c8 = reinterpret_cast<const char*>(smem);
+    auto mma = [&](const int st) {
+      float4 a[2][TM], b[2][TN];
+      auto rd = [&](const int g, float4 (&aa)[TM], float4 (&bb)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) aa[t] = *reinterpret_cast<const float4*>(lds_c8 + st * (BM * 128) + t * 32 * 128 + aoff[g]);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bb[t] = *reinterpret_cast<const float4*>(lds_c8 + st * (BN * 128) + t * 32 * 128 + boff[g]);
+      };
+      rd(0, a[0], b[0]);
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        if (g + 1 < BK / 8) rd(g + 1, a[(g + 1) & 1], b[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc.acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].x, b[g & 1][tn].x, acc.acc[tm][tn], 0, 0, 0);
+            acc.acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].y, b[g & 1][tn].y, acc.acc[tm][tn], 0, 0, 0);
+            acc.acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].z, b[g & 1][tn].z, acc.acc[tm][tn], 0, 0, 0);
+            acc.acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].w, b[g & 1][tn].w, acc.acc[tm][tn], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // s_waitcnt vmcnt(n): all but this thread's newest n DMA loads have landed (gfx9 encoding: vmcnt = bits 3:0 and 15:14)
+    constexpr int NL = NRA + NRB;
+    constexpr int kWaitTile = DST == 3 ? (0x0F70 | (NL & 15) | ((NL >> 4) << 14)) : 0x0F70;
+    dma_tile(kt_begin, 0);
+    if constexpr (DST == 3) dma_tile(min(kt_begin + 1, kt_end - 1), 1);
+    __builtin_amdgcn_s_waitcnt(kWaitTile);   // the first tile is in LDS
+    __syncthreads();
+    // one K-tile: the load unit fills the stage every wave left at the last barrier with tile kt + DST - 1 while the MFMAs
+    // read stage st (a literal: the loop is unrolled by DST)
+    auto step = [&](int kt, const int st) {
+      dma_tile(min(kt + DST - 1, kt_end - 1), (st + DST - 1) % DST);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(st);
+      __builtin_amdgcn_s_waitcnt(kWaitTile);   // tile kt + 1 has landed
+      __syncthreads();
+    };
+    int kt = kt_begin;
+    if constexpr (DST == 3) {
+      for (; kt + 2 < kt_end; kt += 3) {
+        step(kt, 0);
+        step(kt + 1, 1);
+        step(kt + 2, 2);
+      }
+      if (kt < kt_end) step(kt, 0);
+      if (kt + 1 < kt_end) step(kt + 1, 1);
+    } else {
+      for (; kt + 1 < kt_end; kt += 2) {
+        step(kt, 0);
+        step(kt + 1, 1);
+      }
+      if (kt < kt_end) step(kt, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // nothing of this block may still be landing when its LDS is handed on
+  } else if constexpr (F32) {
     load_tile(rg0, okm0, kt_begin);
     store_tile(rg0, okm0, 0);
     __syncthreads();
@@ -1038,7 +1153,8 @@ static hipError_t launch_patch_shape(const ConvArgs& a, int KH, int S, int W, in
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr size_t lds = !(PREC & 1) ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64;
+  constexpr size_t lds = PREC == 4 ? kDmaStages * (size_t)(BM + BN) * 128
+                                   : (!(PREC & 1) ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64);
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN, PREC>;
   {
@@ -1079,6 +1195,9 @@ template <int KH, int KW, int S>
 static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t st) {
   // the lean (buffer-addressed) loader when both tensors fit 31-bit byte offsets
   if (prec == 1) return a.x_bytes ? launch_prec<KH, KW, S, 3>(a, cfg, st) : launch_prec<KH, KW, S, 1>(a, cfg, st);
+  // (the 128x128 and 128x256 tiles keep the register-staged loader: their DMA stages would pass 64 KB of LDS, destinations up
+  // there are untested)
+  if (a.x_bytes && !(a.flags & OFFK_CONV_RELU_IN_) && !a.no_dma && cfg != 5 && (cfg != 0 || kDmaStages == 2)) return launch_prec<KH, KW, S, 4>(a, cfg, st);
   return a.x_bytes ? launch_prec<KH, KW, S, 2>(a, cfg, st) : launch_prec<KH, KW, S, 0>(a, cfg, st);
 }
 
@@ -1126,7 +1245,12 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
     const bool fits = xb + bias < 0x7fffffffull && wb < 0x7fffffffull;
     a.x_bytes = fits ? (unsigned)xb : 0u;
     a.w_bytes = fits ? (unsigned)wb : 0u;
+    a.no_dma = 0;
+#ifdef OFFK_NO_CONV_DMA      // A/B builds (tools)
+    a.no_dma = 1;
+#endif
 #ifdef OFFK_TUNING_KNOBS
+    { const char* e = getenv("OFFK_CONV_DMA"); if (e && *e == '0') a.no_dma = 1; }
     { const char* e = getenv("OFFK_CONV_LEAN"); if (e && !((atoi(e) >> (d.precision & 1)) & 1)) a.x_bytes = 0; }   // bit 0 fp32, bit 1 bf16x3
 #endif
   }
