@@ -1259,7 +1259,7 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.M = (int)M;
   const int nkt = d.KH * d.KW * (d.Ci / 32);
   int cfg = d.tile_cfg, sk = d.splitk;
-  if (cfg < 0 || sk < 1) conv2d_auto_plan(M, d.Co, nkt, &cfg, &sk);
+  if (cfg < 0 || sk < 1) conv2d_auto_plan(d.plan_n_img > 0 ? (long long)d.plan_n_img * a.Ho * a.Wo : M, d.Co, nkt, &cfg, &sk);
   if (sk > nkt) sk = nkt;
   if (narrow) sk = 1;
   a.co_limit = narrow ? d.co_limit : d.Co;

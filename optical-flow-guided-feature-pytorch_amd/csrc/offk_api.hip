@@ -143,6 +143,8 @@ struct offk_handle {
   // fusion stages and are joined back into the caller's stream before offk_forward returns
   hipStream_t side = nullptr;   // stays null with OFFK_SIDE_STREAM=0 in the environment at offk_create: heads on the caller's stream
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
+  hipStream_t pipe = nullptr;   // second half of the two-half fusion pipeline (offk_forward); only with OFFK_PIPELINE=1 at offk_create
+  hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
 
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
@@ -251,7 +253,7 @@ void plan_workspace(offk_handle* h) {
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64],
   // 3x3 @7: [P*49, 256]); a conv whose plan needs more falls back to fewer slices
   h->splitk_floats = 8 * P * 196 * 64;
-  add_region(h, "splitk", h->splitk_floats);
+  add_region(h, "splitk", h->splitk_floats + 128);     // + slack: the two-half pipeline cuts the slab at a 64-float boundary
   h->ws_bytes = align_up(h->ws_bytes, 256);
 
   // ---- training side: backward regions behind the forward layout (offk_train_workspace_bytes) ----
@@ -514,6 +516,7 @@ int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, i
   d.tile_cfg = cfg; d.splitk = sk;
   d.partial = h->cur_splitk; d.partial_floats = h->splitk_floats;
   d.precision = h->cfg.precision;
+  d.plan_n_img = h->P;                    // the two-half pipeline calls with half the pairs: same plan, same bits
   const char* why = nullptr;
   hipError_t e = conv2d_launch(d, st, &why);
   if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
@@ -672,6 +675,16 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     offk_destroy(h);
     return OFFK_ERR_HIP;
   }
+  const char* pipe_env = getenv("OFFK_PIPELINE");
+  if (pipe_env && *pipe_env == '1' &&
+      (hipStreamCreateWithFlags(&h->pipe, hipStreamNonBlocking) != hipSuccess ||
+       hipEventCreateWithFlags(&h->ev_pipe[0], hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&h->ev_pipe[1], hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&h->ev_pipe[2], hipEventDisableTiming) != hipSuccess)) {
+    g_err = "offk_create: could not create the pipeline stream";
+    offk_destroy(h);
+    return OFFK_ERR_HIP;
+  }
   *out = h;
   return OFFK_OK;
 }
@@ -684,6 +697,8 @@ int offk_destroy(offk_handle* h) {
   if (h->ev_fork[1]) (void)hipEventDestroy(h->ev_fork[1]);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side) (void)hipStreamDestroy(h->side);
+  for (hipEvent_t e : h->ev_pipe) if (e) (void)hipEventDestroy(e);
+  if (h->pipe) (void)hipStreamDestroy(h->pipe);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return OFFK_OK;
@@ -962,67 +977,108 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   float* l28 = cons ? region(h, ws, "logit_28") : out28;
   // each head = a pooling launch (1536 blocks at C = 1024) + a latency-oriented FC launch
   auto run_head = [&](hipStream_t hs, int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool,
-                      const char* pooled_name, float* logits) -> int {
-    float* pooled = region(h, ws, pooled_name);
-    hipError_t e = pool_launch(x, x_cs, x_coff, P, Hh, Hh, C, maxpool, pooled, hs);
-    if (e == hipSuccess) e = fc_launch(pooled, P, C, h->fc_w[k], h->fc_b[k], ncls, logits, hs);
+                      const char* pooled_name, float* logits, int i0, int n) -> int {
+    float* pooled = region(h, ws, pooled_name) + (size_t)i0 * C;
+    hipError_t e = pool_launch(x + (size_t)i0 * Hh * Hh * x_cs, x_cs, x_coff, n, Hh, Hh, C, maxpool, pooled, hs);
+    if (e == hipSuccess) e = fc_launch(pooled, n, C, h->fc_w[k], h->fc_b[k], ncls, logits + (size_t)i0 * ncls, hs);
     if (e != hipSuccess) return fail_hip(h, e, "head");
     return OFFK_OK;
   };
-  // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
-  // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
   float *xt = region(h, ws, "xt_28"), *t1 = region(h, ws, "t1_28");
   float *sa = region(h, ws, "sa_28"), *sb = region(h, ws, "sb_28");
-  TRY(conv(h, st, C_T28, P, 28, View{F28, 320, 0}, nullptr, 0, 0, 0, xt, 128, 64));             // :657 x0, pre-ReLU kept for the branch
-  TRY(conv(h, st, C1_28A, P, 14, View{xt, 128, 64}, nullptr, 0, 0, RI | RP, t1, 64, 0));        // :658-660
-  TRY(conv(h, st, C2_28A, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :661-662 t2
-  TRY(conv_merged(h, st, 0, P, 14, View{xt, 128, 0}, RO, sa, 256, 0));                           // :663-667
-  TRY(conv(h, st, C1_28B, P, 14, View{sa, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));              // :670-671
-  TRY(conv(h, st, C2_28B, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :672-673
-  TRY(conv(h, st, C3_28B, P, 14, View{xt, 128, 0}, sa, 256, 0, RO, sb, 256, 0));                // :674-676
-  TRY(conv(h, st, C1_28C, P, 14, View{sb, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));              // :679-680
-  TRY(conv(h, st, C2_28C, P, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));              // :681-682
-  TRY(conv(h, st, C3_28C, P, 14, View{xt, 128, 0}, sb, 256, 0, RO, F14, 1056, 800));            // :683-685 -> cat at :760
-  if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
-  if (out28) {   // 28-head (:782-787) beside fusion@14: only reads sum_28c
-    if (forked) {
-      HIP_TRY(h, hipEventRecord(h->ev_fork[0], st));
-      HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[0], 0));
-    }
-    TRY(run_head(side, 1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28));
-  }
-
-  // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
   float *xu = region(h, ws, "xu_14"), *u1 = region(h, ws, "u1_14"), *s14 = region(h, ws, "sa_14");   // xu = [u2 | x1]
-  TRY(conv(h, st, C_T14, P, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128));          // :762-763 x1
-  TRY(conv(h, st, C1_14A, P, 7, View{xu, 256, 128}, nullptr, 0, 0, RP, u1, 128, 0));            // :764-765
-  TRY(conv(h, st, C2_14A, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));              // :766-767 u2
-  TRY(conv_merged(h, st, 1, P, 7, View{xu, 256, 0}, RO, s14, 512, 0));                           // :768-771
-  TRY(conv(h, st, C1_14B, P, 7, View{s14, 512, 0}, nullptr, 0, 0, RP, u1, 128, 0));             // :773-774
-  TRY(conv(h, st, C2_14B, P, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));              // :775-776
-  TRY(conv(h, st, C3_14B, P, 7, View{xu, 256, 0}, s14, 512, 0, RP | RO, F7, 832, 320));         // :777-780 -> cat at :832
-  if (ev) HIP_TRY(h, hipEventRecord(ev[4], st));
-  {              // 14-head (:789-793) beside fusion@7: only reads sum_14b
-    if (forked) {
-      HIP_TRY(h, hipEventRecord(h->ev_fork[1], st));
-      HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[1], 0));
-    }
-    TRY(run_head(side, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));
-  }
-
-  // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
   float *xv = region(h, ws, "xv_7"), *v1 = region(h, ws, "v1_7"), *s7 = region(h, ws, "sum_7");   // xv = [v2 | x2]
-  TRY(conv(h, st, C_T7, P, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256));              // :833-834 x2
-  TRY(conv(h, st, C1_7, P, 7, View{xv, 512, 256}, nullptr, 0, 0, RP, v1, 256, 0));              // :835-836
-  TRY(conv(h, st, C2_7, P, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0));                // :837-838 v2
-  TRY(conv_merged(h, st, 2, P, 7, View{xv, 512, 0}, 0, s7, 1024, 0));                            // :839-841 (no ReLU)
-  if (ev) HIP_TRY(h, hipEventRecord(ev[5], st));
-
-  // ---- 7-head on the caller's stream, join the side-stream heads, consensus -----------------
-  TRY(run_head(st, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7));                                  // :843-847
-  if (forked) {
-    HIP_TRY(h, hipEventRecord(h->ev_join, side));
-    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+  // The three fusion stages + heads for the pairs [i0, i0 + n) on stream s.  Every buffer is pair-major, so a range of
+  // pairs is a pointer offset; results do not depend on how the pairs are split (same plans, same K order per output).
+  // side_heads: the 28- and 14-heads go to the handle's side stream (joined by the caller); after_first: recorded behind
+  // the first conv (the stagger point of the two-half pipeline below).
+  auto fusion = [&](hipStream_t s, int i0, int n, bool side_heads, hipEvent_t after_first, hipEvent_t* sev) -> int {
+    auto at = [&](float* base, int Hh, int cs) { return base + (size_t)i0 * Hh * Hh * cs; };
+    hipStream_t hs = side_heads ? side : s;
+    // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
+    // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
+    float *xt_ = at(xt, 14, 128), *t1_ = at(t1, 14, 64), *sa_ = at(sa, 14, 256), *sb_ = at(sb, 14, 256);
+    float *F28_ = at(F28, 28, 320), *F14_ = at(F14, 14, 1056), *F7_ = at(F7, 7, 832);
+    TRY(conv(h, s, C_T28, n, 28, View{F28_, 320, 0}, nullptr, 0, 0, 0, xt_, 128, 64));             // :657 x0, pre-ReLU kept for the branch
+    if (after_first) HIP_TRY(h, hipEventRecord(after_first, s));
+    TRY(conv(h, s, C1_28A, n, 14, View{xt_, 128, 64}, nullptr, 0, 0, RI | RP, t1_, 64, 0));        // :658-660
+    TRY(conv(h, s, C2_28A, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :661-662 t2
+    TRY(conv_merged(h, s, 0, n, 14, View{xt_, 128, 0}, RO, sa_, 256, 0));                           // :663-667
+    TRY(conv(h, s, C1_28B, n, 14, View{sa_, 256, 0}, nullptr, 0, 0, RP, t1_, 64, 0));              // :670-671
+    TRY(conv(h, s, C2_28B, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :672-673
+    TRY(conv(h, s, C3_28B, n, 14, View{xt_, 128, 0}, sa_, 256, 0, RO, sb_, 256, 0));                // :674-676
+    TRY(conv(h, s, C1_28C, n, 14, View{sb_, 256, 0}, nullptr, 0, 0, RP, t1_, 64, 0));              // :679-680
+    TRY(conv(h, s, C2_28C, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :681-682
+    TRY(conv(h, s, C3_28C, n, 14, View{xt_, 128, 0}, sb_, 256, 0, RO, F14_, 1056, 800));            // :683-685 -> cat at :760
+    if (sev) HIP_TRY(h, hipEventRecord(sev[3], s));
+    if (out28) {   // 28-head (:782-787) beside fusion@14: only reads sum_28c
+      if (side_heads && forked) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork[0], s));
+        HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[0], 0));
+      }
+      TRY(run_head(hs, 1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28, i0, n));
+    }
+    // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
+    float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);
+    TRY(conv(h, s, C_T14, n, 14, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128));          // :762-763 x1
+    TRY(conv(h, s, C1_14A, n, 7, View{xu_, 256, 128}, nullptr, 0, 0, RP, u1_, 128, 0));            // :764-765
+    TRY(conv(h, s, C2_14A, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :766-767 u2
+    TRY(conv_merged(h, s, 1, n, 7, View{xu_, 256, 0}, RO, s14_, 512, 0));                           // :768-771
+    TRY(conv(h, s, C1_14B, n, 7, View{s14_, 512, 0}, nullptr, 0, 0, RP, u1_, 128, 0));             // :773-774
+    TRY(conv(h, s, C2_14B, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :775-776
+    TRY(conv(h, s, C3_14B, n, 7, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320));         // :777-780 -> cat at :832
+    if (sev) HIP_TRY(h, hipEventRecord(sev[4], s));
+    {              // 14-head (:789-793) beside fusion@7: only reads sum_14b
+      if (side_heads && forked) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork[1], s));
+        HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[1], 0));
+      }
+      TRY(run_head(hs, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14, i0, n));
+    }
+    // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
+    float *xv_ = at(xv, 7, 512), *v1_ = at(v1, 7, 256), *s7_ = at(s7, 7, 1024);
+    TRY(conv(h, s, C_T7, n, 7, View{F7_, 832, 0}, nullptr, 0, 0, RP, xv_, 512, 256));              // :833-834 x2
+    TRY(conv(h, s, C1_7, n, 7, View{xv_, 512, 256}, nullptr, 0, 0, RP, v1_, 256, 0));              // :835-836
+    TRY(conv(h, s, C2_7, n, 7, View{v1_, 256, 0}, nullptr, 0, 0, RP, xv_, 512, 0));                // :837-838 v2
+    TRY(conv_merged(h, s, 2, n, 7, View{xv_, 512, 0}, 0, s7_, 1024, 0));                            // :839-841 (no ReLU)
+    if (sev) HIP_TRY(h, hipEventRecord(sev[5], s));
+    // ---- 7-head on the chain's stream (:843-847)
+    TRY(run_head(s, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7, i0, n));
+    return OFFK_OK;
+  };
+  // Two-half pipeline (opt-in: OFFK_PIPELINE=1 at offk_create): the bottleneck chains between the big convs are small,
+  // latency-bound launches (a partial wave of blocks, 2-18 K-tiles each) that leave the matrix pipe half idle.  With the
+  // pairs split in two halves on two streams, the second half one big conv behind the first, a half's chain runs beside the
+  // other half's big conv.  Bit-identical to the single-stream order (per-output arithmetic does not depend on the split).
+  // Measured at B = 64 (same box): bf16x3 2.644 -> 2.622 ms, fp32 5.35 -> 5.44 ms (two MFMA-bound kernels sharing the CUs
+  // lose more than the chains gain) -- hence not the default.  Off while stage timing is on.
+  const bool pipelined = h->pipe && !ev && P >= 96;
+  if (!pipelined) {
+    TRY(fusion(st, 0, P, true, nullptr, ev));
+    if (forked) {
+      HIP_TRY(h, hipEventRecord(h->ev_join, side));
+      HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+  } else {
+    const int nA = (P + 1) / 2, nB = P - nA;
+    float* slab = h->cur_splitk;
+    // each half gets its share of the split-K slab (rounded up; the region carries 128 floats of slack)
+    const size_t all = h->splitk_floats, half = ((all * (size_t)nA / (size_t)P) + 63) & ~(size_t)63;
+    HIP_TRY(h, hipEventRecord(h->ev_pipe[0], st));                 // units done
+    HIP_TRY(h, hipStreamWaitEvent(h->pipe, h->ev_pipe[0], 0));
+    h->splitk_floats = half;
+    int rc = fusion(st, 0, nA, false, h->ev_pipe[1], nullptr);
+    if (rc == OFFK_OK) {
+      hipError_t e = hipStreamWaitEvent(h->pipe, h->ev_pipe[1], 0);   // half B starts behind half A's first conv
+      h->cur_splitk = slab + half;
+      h->splitk_floats = all + 128 - half;
+      if (e == hipSuccess) rc = fusion(h->pipe, nA, nB, false, nullptr, nullptr);
+      else rc = fail_hip(h, e, "pipeline");
+    }
+    h->cur_splitk = slab; h->splitk_floats = all;
+    if (rc != OFFK_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_pipe[2], h->pipe));
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_pipe[2], 0));
   }
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;

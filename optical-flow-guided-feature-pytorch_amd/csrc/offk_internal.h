@@ -29,6 +29,8 @@ struct ConvDesc {
   size_t partial_floats = 0;
   int precision = 0;                      // 0 = exact fp32 MFMA, 1 = bf16x3
   int co_limit = 0;                       // > 0: store only output channels < co_limit (weights padded to Co); needs splitk == 1
+  int plan_n_img = 0;                     // > 0: the automatic plan is the one of this many images (a call on part of a batch
+                                          // then splits K exactly as the whole-batch call: same bits)
 };
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);

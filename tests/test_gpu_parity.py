@@ -491,6 +491,25 @@ def test_fused_units_path_bit_identical(rt, prec, B, L, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
+@pytest.mark.parametrize("variant,B,L", [(spec.VARIANT_RGB, 17, 7), (spec.VARIANT_FLOW, 16, 8)])
+def test_two_half_pipeline_bit_identical(rt, variant, B, L, prec, monkeypatch):
+    """OFFK_PIPELINE=1 at offk_create runs the fusion stages of the two halves of the pairs on two streams, one big conv
+    apart (offk_api.hip).  Every buffer is pair-major and the per-output arithmetic does not depend on the split: the
+    logits are the single-stream bits, with an odd pair count (17 * 6 = 102 -> 51 + 51; 16 * 7 = 112) and with the
+    consensus of the Flow variant behind the join."""
+    feats = [dev(f) for f in synth.make_features(B, L, 3)]
+    h0, _ = make_handle(rt, B, L, variant, precision=prec)
+    monkeypatch.setenv("OFFK_PIPELINE", "1")
+    h1, _ = make_handle(rt, B, L, variant, precision=prec)
+    monkeypatch.delenv("OFFK_PIPELINE")
+    ref = h0.forward(feats)
+    for _ in range(2):                       # twice: the second run re-uses the events / the split-K slabs
+        got = h1.forward(feats)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("variant", [spec.VARIANT_RGB, spec.VARIANT_FLOW])
 def test_test_time_shape_vs_oracle(rt, variant, prec):
     """The reference's eval shape: 10 crops x 25 segments per video, model built with batch = 10 (test_rgb_off.py:24-25,
