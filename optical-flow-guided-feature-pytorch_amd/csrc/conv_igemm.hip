@@ -1195,9 +1195,8 @@ template <int KH, int KW, int S>
 static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t st) {
   // the lean (buffer-addressed) loader when both tensors fit 31-bit byte offsets
   if (prec == 1) return a.x_bytes ? launch_prec<KH, KW, S, 3>(a, cfg, st) : launch_prec<KH, KW, S, 1>(a, cfg, st);
-  // (the 128x128 and 128x256 tiles keep the register-staged loader: their DMA stages would pass 64 KB of LDS, destinations up
-  // there are untested)
-  if (a.x_bytes && !(a.flags & OFFK_CONV_RELU_IN_) && !a.no_dma && cfg != 5 && (cfg != 0 || kDmaStages == 2)) return launch_prec<KH, KW, S, 4>(a, cfg, st);
+  // (LDS-DMA destinations above 64 KB work: tools/lds_dma_probe_hi.hip lands rows up to 139 KB into a 144 KB allocation)
+  if (a.x_bytes && !(a.flags & OFFK_CONV_RELU_IN_) && !a.no_dma) return launch_prec<KH, KW, S, 4>(a, cfg, st);
   return a.x_bytes ? launch_prec<KH, KW, S, 2>(a, cfg, st) : launch_prec<KH, KW, S, 0>(a, cfg, st);
 }
 
