@@ -48,18 +48,19 @@ struct ConvArgs {
 #endif
 };
 
-// PREC 0 / 2: exact fp32 MFMA core.  PREC 1: bf16x3 core (see offk_common.h).
+// PREC 0 / 2 / 4: exact fp32 MFMA core.  PREC 1 / 3: bf16x3 core (see offk_common.h; 3 = behind the PREC 2 loader).
 // PREC 2 is PREC 0 with a LEAN K loop (round 2).  On gfx950 the fp32 MFMA shares the SIMD's fp32 lanes with the vector ALU:
 // tools/mfma_f32_probe.hip shows every VALU instruction in the loop coming straight out of the matrix throughput, at any
 // occupancy (92 % with none, 76 % with 32 extra per 16 MFMAs, 63 % with 64).  The PREC 0 loop spends ~12 VALU instructions
 // per activation row and K-tile on addressing (two 64-bit multiplies, pointer selects) plus zero / ReLU selects before the
 // LDS store.  PREC 2 addresses through buffer descriptors instead: the per-row offset is loop-invariant, the (tap, chunk)
 // offset is a scalar (soffset), padding taps take the out-of-range offset 0x80000000 and the hardware returns zeros --
-// five cheap VALU instructions per activation row, none per weight row.  Needs both tensors below 2^31 bytes (checked on
-// the host, PREC 0 otherwise).
+// three VALU instructions per activation row visit (two shifts and an and-or on precomputed separable tap masks), none per
+// weight row, none for LDS addresses (the K loop is unrolled by two: stages are literals).  Needs both tensors below 2^31
+// bytes (checked on the host, PREC 0 otherwise).
 // PREC 4 is PREC 2 with the tiles moved global -> LDS by the load unit itself (`buffer_load_dwordx4 ... lds`): no
 // prefetch registers, no ds_write, no s_waitcnt vmcnt in front of an LDS store.  The probe prices four ds_write_b128 per
-// K-tile at 8-9 % of the matrix throughput (92 -> 84 %), which is what separated the PREC 2 loop from the probe's rate.
+// K-tile at 8-9 % of the matrix throughput (92 -> 84 %); in the forward the step is worth 1.4 % (same-box 5.40 -> 5.33 ms).
 // A wave instruction lands 64 x 16 B contiguously (8 rows of 128 B), so rows cannot be padded: position (row, slot) holds
 // the row's 16-byte chunk slot ^ ((row >> 1) & 7) -- the swizzle goes into each lane's SOURCE offset -- and the
 // ds_read_b128 of 16 consecutive rows stays conflict-free.  No ReLU-on-load (the data never passes a register): convs
