@@ -1,5 +1,5 @@
 """Shape fuzz on the GPU: forward (both variants, both precisions, both slice modes) and units backward against the oracle
-for random (B, L).  Test-infrastructure use of the oracle only.   python tests/tools/fuzz_shapes.py [n_cases] [seed]"""
+for random (B, L).  Test-infrastructure use of the oracle only.   python tests/tools/fuzz_shapes.py [n_cases] [seed] [max_B]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,7 @@ from test_gpu_backward import cotangents, grad_views, device_relu_masks, unit_dr
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+max_B = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 
 
 def rel(a, b):
@@ -22,7 +23,7 @@ def rel(a, b):
 
 worst = 0.0
 for case in range(n_cases):
-    B, L = rng.randint(1, 5), rng.randint(2, 9)
+    B, L = rng.randint(1, max_B), rng.randint(2, 9)
     variant = rng.choice([spec.VARIANT_RGB, spec.VARIANT_FLOW])
     prec = rng.choice(["fp32", "bf16x3"])
     sm = rng.choice([spec.SLICE_FLAT, spec.SLICE_PER_CLIP])
