@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 4
+#define OFFK_ABI_VERSION 5
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -113,9 +113,12 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
  * every later launch reads it in place, so an in-place optimizer update needs NO call at all -- it only has to be ordered
  * before the next launch, which it is when both are enqueued on the same stream.  The caller keeps the storage alive and
  * re-binds if the tensor is re-allocated.  A later offk_set_weight of the same key replaces the binding by a copy.  In
- * bf16x3 mode bound weights are split on the fly by the kernel (the pre-split copy is not used).  Not blocking, no
- * allocation, no kernel launch. */
-int offk_bind_weight(offk_handle* h, const char* key, const float* device_data);
+ * bf16x3 mode bound weights are split on the fly by the kernel: binding ANY gen / down weight moves all nine sites off the
+ * pre-split copies and off the operand-order weight image of the fused units kernel (a performance fallback, same bits).
+ * `shape` / `ndim` are checked against the key's reference shape, and the allocation behind `device_data` must hold that
+ * many bytes (hipMemGetAddressRange): every later launch sizes its buffer descriptors from the key, not from the tensor.
+ * Not blocking, no allocation, no kernel launch. */
+int offk_bind_weight(offk_handle* h, const char* key, const float* device_data, const int64_t* shape, int ndim);
 /* Number of weights still unset (0 = ready); if buf != NULL the first missing key is copied there. */
 int offk_missing_weights(const offk_handle* h, char* buf, size_t buflen);
 
@@ -153,8 +156,15 @@ int offk_workspace_region(const offk_handle* h, const char* name, size_t* offset
  * Stage order: 0 pw_reduce (K1), 1 sobel_tdiff (K2), 2 fusion_28, 3 fusion_14,
  * 4 fusion_7, 5 heads+consensus. */
 #define OFFK_NUM_STAGES 6
-int offk_set_profiling(offk_handle* h, int enable);
+int offk_set_profiling(offk_handle* h, int enable);   /* 0 off, 1 per-stage events, 2 per-launch trace (below) */
 int offk_stage_times(offk_handle* h, double ms[OFFK_NUM_STAGES], int64_t calls[OFFK_NUM_STAGES], int reset);
+/* Per-launch trace (offk_set_profiling(h, 2)): offk_forward records one HIP event on the caller's stream in front of every
+ * launch group -- the units kernels, each fusion conv by its state_dict name (a split-K conv includes its reduction), each
+ * head, the consensus -- with the side-stream heads folded back in line.  Returns the number of distinct groups seen since
+ * the last reset; the first min(n, max_entries) are written: names as one '\n'-separated string into `names`, accumulated
+ * milliseconds and call counts into `ms` / `calls`.  An event between two short kernels costs a few microseconds of
+ * command-processor time: use rocprofv3's kernel trace for absolute times of the small launches. */
+int offk_launch_times(offk_handle* h, char* names, size_t names_len, double* ms, int64_t* calls, int max_entries, int reset);
 
 /* ---- stage entry points (the same kernels offk_forward launches) ------------------ */
 

@@ -45,7 +45,7 @@ SIGNATURES = {
     "offk_create": (_I, [_c.POINTER(OffkConfig), _c.POINTER(_P)]),
     "offk_destroy": (_I, [_P]),
     "offk_set_weight": (_I, [_P, _c.c_char_p, _F, _c.POINTER(_c.c_int64), _I]),
-    "offk_bind_weight": (_I, [_P, _c.c_char_p, _F]),
+    "offk_bind_weight": (_I, [_P, _c.c_char_p, _F, _c.POINTER(_c.c_int64), _I]),
     "offk_missing_weights": (_I, [_P, _c.c_char_p, _c.c_size_t]),
     "offk_workspace_bytes": (_c.c_size_t, [_P]),
     "offk_forward": (_I, [_P, _P, _c.POINTER(_F), _F, _F, _F, _P]),
@@ -53,6 +53,7 @@ SIGNATURES = {
     "offk_workspace_region": (_I, [_P, _c.c_char_p, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     "offk_set_profiling": (_I, [_P, _I]),
     "offk_stage_times": (_I, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _I]),
+    "offk_launch_times": (_I, [_P, _c.c_char_p, _c.c_size_t, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _I, _I]),
     "offk_pw_reduce": (_I, [_P, _P, _I, _F, _F, _F]),
     "offk_sobel_tdiff": (_I, [_P, _P, _I, _F, _F, _F, _I, _I, _I]),
     "offk_sobel_tdiff_all": (_I, [_P, _P, _P, _I]),
@@ -96,7 +97,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 4:
+    if lib.offk_abi_version() != 5:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

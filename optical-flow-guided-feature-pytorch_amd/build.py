@@ -6,6 +6,8 @@ hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GP
 with the working tree.
 """
 import os
+import re
+import shutil
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -20,9 +22,12 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-fno-gpu-rdc", "-ffp-contract=fast"]
 # heads.hip: no SLP vectoriser.  It pairs the FC accumulators of neighbouring classes into v_pk_fma_f32 with
 # op_sel operand swizzles, and on MI355X those produced wrong low-half results whenever the kernel shared
-# CUs with another stream's MFMA kernel (measured, DESIGN.md section 9); scalar FMAs are exact and the
+# CUs with another stream's MFMA kernel (measured, DESIGN.md section 8); scalar FMAs are exact and the
 # kernels in that file are latency-bound anyway.
-EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"], "units_bwd.hip": ["-fno-slp-vectorize"]}
+# conv_igemm.hip: its LDS-DMA inline asm writes m0 and says so in the clobber list (the compiler must not assume an m0 value
+# of its own survives the statement); clang answers every such statement with "clobber list contains reserved registers".
+EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"], "units_bwd.hip": ["-fno-slp-vectorize"],
+               "conv_igemm.hip": ["-Wno-inline-asm"]}
 
 
 def _hipcc():
@@ -33,10 +38,15 @@ def _hipcc():
 
 
 def _llvm_objdump():
-    for c in ("/opt/rocm/lib/llvm/bin/llvm-objdump", "llvm-objdump"):
-        if not os.path.isabs(c) or os.path.exists(c):
-            return c
-    return None
+    if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        return "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    return shutil.which("llvm-objdump")
+
+
+# v_pk_{fma,mul,add}_f32 with a NON-DEFAULT op_sel operand (the implicated form: op_sel:[0,1,0] = low half of the result
+# reads the HIGH half of a source).  op_sel_hi alone is not it: the default op_sel_hi is all ones
+# and a harmless instruction may print a non-default one.
+_OPSEL_RE = re.compile(r"\bv_pk_\w+_f32\b.*\bop_sel:\[")
 
 
 def check_isa(obj):
@@ -48,7 +58,11 @@ def check_isa(obj):
     add the file to EXTRA_FLAGS with -fno-slp-vectorize, or break the pairing in the source)."""
     objdump = _llvm_objdump()
     if objdump is None:
-        raise RuntimeError("llvm-objdump not found: cannot run the op_sel ISA check")
+        if os.environ.get("OFFK_SKIP_ISA_CHECK") == "1":
+            print("WARNING: llvm-objdump not found, op_sel ISA check of %s SKIPPED (OFFK_SKIP_ISA_CHECK=1)" % obj, file=sys.stderr)
+            return
+        raise RuntimeError("llvm-objdump not found: cannot run the op_sel ISA check (DESIGN.md section 8); "
+                           "OFFK_SKIP_ISA_CHECK=1 builds without it")
     r = subprocess.run([objdump, "--offloading", obj], capture_output=True, text=True, cwd=os.path.dirname(obj))
     bad = []
     found = False
@@ -57,7 +71,7 @@ def check_isa(obj):
             found = True
             path = os.path.join(os.path.dirname(obj), f)
             d = subprocess.run([objdump, "-d", path], capture_output=True, text=True)
-            bad += [ln.strip() for ln in d.stdout.splitlines() if "v_pk_" in ln and "_f32" in ln and "op_sel" in ln]
+            bad += [ln.strip() for ln in d.stdout.splitlines() if _OPSEL_RE.search(ln)]
             os.remove(path)
         elif f.startswith(os.path.basename(obj) + ".") and "host" in f:
             os.remove(os.path.join(os.path.dirname(obj), f))

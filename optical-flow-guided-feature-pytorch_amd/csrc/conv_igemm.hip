@@ -178,7 +178,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   }
   auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory");   // (m0 is reserved: hipcc keeps no value in it across statements)
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
   };
   auto dma_tile = [&](int kt, const int stage) {
     if constexpr (DMA) {

@@ -162,10 +162,13 @@ struct offk_handle {
   // workspace plan
   std::map<std::string, std::pair<size_t, size_t>> regions;
   size_t ws_bytes = 0;
-  // profiling
-  bool profiling = false;
+  // profiling: 0 off, 1 per-stage events, 2 per-launch trace (one event in front of every launch group, by name)
+  int profiling = 0;
   std::vector<hipEvent_t> events;   // groups of OFFK_NUM_STAGES + 1
   size_t ev_used = 0;
+  std::vector<hipEvent_t> tr_events;
+  std::vector<int> tr_marks;        // per recorded event: index into tr_names, -1 = end of a forward
+  std::vector<std::string> tr_names;
   mutable std::string err;
 };
 
@@ -184,6 +187,27 @@ int fail_hip(offk_handle* h, hipError_t e, const char* what) {
     hipError_t e__ = (expr);                               \
     if (e__ != hipSuccess) return fail_hip(h, e__, #expr); \
   } while (0)
+
+// per-launch trace (offk_set_profiling(h, 2)): an event on `st` in front of the launch group `name`; name == nullptr closes
+// the forward.  The time of a group is the distance to the next mark on the same stream.
+constexpr size_t kTraceMaxEvents = 1 << 16;
+int trace_mark(offk_handle* h, hipStream_t st, const char* name) {
+  if (h->profiling != 2 || h->tr_marks.size() >= kTraceMaxEvents) return OFFK_OK;
+  int id = -1;
+  if (name) {
+    for (size_t i = 0; i < h->tr_names.size() && id < 0; ++i)
+      if (h->tr_names[i] == name) id = (int)i;
+    if (id < 0) { id = (int)h->tr_names.size(); h->tr_names.push_back(name); }
+  }
+  if (h->tr_marks.size() >= h->tr_events.size()) {
+    hipEvent_t e;
+    HIP_TRY(h, hipEventCreate(&e));
+    h->tr_events.push_back(e);
+  }
+  HIP_TRY(h, hipEventRecord(h->tr_events[h->tr_marks.size()], st));
+  h->tr_marks.push_back(id);
+  return OFFK_OK;
+}
 
 int dev_alloc(offk_handle* h, float** p, size_t nfloats) {
   void* q = nullptr;
@@ -457,9 +481,11 @@ int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[],
   }
   pp.total_blocks = blk;
   if (ev) HIP_TRY(h, hipEventRecord(ev[0], st));
+  { int rc = trace_mark(h, st, "units:pw_reduce (K1)"); if (rc != OFFK_OK) return rc; }
   HIP_TRY(h, pw_reduce_launch(pp, st));
   if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
 
+  { int rc = trace_mark(h, st, "units:sobel_tdiff (K2)"); if (rc != OFFK_OK) return rc; }
   { int rc = run_sobel_tdiff_all(h, st, ws, 0, drop); if (rc != OFFK_OK) return rc; }
   if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
   return OFFK_OK;
@@ -496,8 +522,10 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   }
   (void)blk;     // block layout (chunks, leftover blocks, blk_begin, total_blocks): pw_tdiff_launch
   if (ev) HIP_TRY(h, hipEventRecord(ev[0], st));
+  { int rc = trace_mark(h, st, "units:pw_tdiff (K1T)"); if (rc != OFFK_OK) return rc; }
   HIP_TRY(h, pw_tdiff_launch(pt, st));
   if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
+  { int rc = trace_mark(h, st, "units:sobel S-blocks (K2 spatial half)"); if (rc != OFFK_OK) return rc; }
   { int rc = run_sobel_tdiff_all(h, st, ws, 3); if (rc != OFFK_OK) return rc; }   // S-blocks only: M[.., coff .. coff+32)
   if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
   return OFFK_OK;
@@ -518,6 +546,7 @@ int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, i
   d.precision = h->cfg.precision;
   d.plan_n_img = h->P;                    // the two-half pipeline calls with half the pairs: same plan, same bits
   const char* why = nullptr;
+  { int rc = trace_mark(h, st, name); if (rc != OFFK_OK) return rc; }
   hipError_t e = conv2d_launch(d, st, &why);
   if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
   return OFFK_OK;
@@ -693,6 +722,7 @@ int offk_destroy(offk_handle* h) {
   if (!h) return OFFK_OK;
   DeviceGuard guard(h->cfg.device);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->tr_events) (void)hipEventDestroy(e);
   if (h->ev_fork[0]) (void)hipEventDestroy(h->ev_fork[0]);
   if (h->ev_fork[1]) (void)hipEventDestroy(h->ev_fork[1]);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -789,18 +819,33 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
   return rc;
 }
 
-int offk_bind_weight(offk_handle* h, const char* key, const float* device_data) {
-  if (!h || !key || !device_data) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: null argument");
+int offk_bind_weight(offk_handle* h, const char* key, const float* device_data, const int64_t* shape, int ndim) {
+  if (!h || !key || !device_data || !shape) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: null argument");
   std::string k(key);
   if (k.compare(0, 7, "module.") == 0) k = k.substr(7);
   auto it = h->index.find(k);
   if (it == h->index.end()) return fail(h, OFFK_ERR_UNKNOWN_KEY, "offk_bind_weight: not an OFF sub-network key for this variant: " + k);
   Slot& s = h->slots[it->second];
+  // the tensor is read in place by every later launch (buffer descriptors sized from the key's shape): check it IS that shape
+  bool shape_ok = ndim == (int)s.shape.size();
+  size_t need = sizeof(float);
+  for (int i = 0; shape_ok && i < ndim; ++i) { shape_ok = shape[i] == s.shape[i]; need *= (size_t)s.shape[i]; }
+  if (!shape_ok) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: shape mismatch for " + k);
   if ((reinterpret_cast<uintptr_t>(device_data) & 15) != 0) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: pointer must be 16-byte aligned: " + k);
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, device_data) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != h->cfg.device) {
     (void)hipGetLastError();
     return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: needs a device pointer on the handle's device: " + k);
+  }
+  {   // ... and that the allocation behind the pointer really holds that many bytes from there on
+    hipDeviceptr_t base = nullptr;
+    size_t asz = 0;
+    if (hipMemGetAddressRange(&base, &asz, const_cast<float*>(device_data)) == hipSuccess) {
+      const size_t off = (size_t)(reinterpret_cast<const char*>(device_data) - reinterpret_cast<const char*>(base));
+      if (off > asz || asz - off < need) return fail(h, OFFK_ERR_INVALID, "offk_bind_weight: allocation too small for " + k);
+    } else {
+      (void)hipGetLastError();
+    }
   }
   const int i = s.idx;
   switch (s.kind) {
@@ -842,8 +887,36 @@ int offk_workspace_region(const offk_handle* h, const char* name, size_t* offset
 
 int offk_set_profiling(offk_handle* h, int enable) {
   if (!h) return OFFK_ERR_INVALID;
-  h->profiling = enable != 0;
+  if (enable < 0 || enable > 2) return fail(h, OFFK_ERR_INVALID, "offk_set_profiling: 0 off, 1 per-stage events, 2 per-launch trace");
+  h->profiling = enable;
   return OFFK_OK;
+}
+
+int offk_launch_times(offk_handle* h, char* names, size_t names_len, double* ms, int64_t* calls, int max_entries, int reset) {
+  if (!h || max_entries < 0 || (max_entries > 0 && (!ms || !calls))) return fail(h, OFFK_ERR_INVALID, "offk_launch_times: bad argument");
+  DeviceGuard guard(h->cfg.device);
+  const int n = (int)h->tr_names.size();
+  std::vector<double> sum(n, 0.0);
+  std::vector<int64_t> cnt(n, 0);
+  if (!h->tr_marks.empty()) HIP_TRY(h, hipEventSynchronize(h->tr_events[h->tr_marks.size() - 1]));
+  for (size_t i = 0; i + 1 < h->tr_marks.size(); ++i) {
+    const int id = h->tr_marks[i];
+    if (id < 0) continue;
+    float t = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&t, h->tr_events[i], h->tr_events[i + 1]));
+    sum[id] += t;
+    cnt[id] += 1;
+  }
+  std::string all;
+  for (int i = 0; i < n && i < max_entries; ++i) {
+    ms[i] = sum[i];
+    calls[i] = cnt[i];
+    all += h->tr_names[i];
+    all += '\n';
+  }
+  if (names && names_len) snprintf(names, names_len, "%s", all.c_str());
+  if (reset) { h->tr_marks.clear(); h->tr_names.clear(); }
+  return n;
 }
 
 int offk_stage_times(offk_handle* h, double ms[OFFK_NUM_STAGES], int64_t calls[OFFK_NUM_STAGES], int reset) {
@@ -947,7 +1020,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   const int P = h->P, ncls = h->cfg.num_classes;
 
   hipEvent_t* ev = nullptr;
-  if (h->profiling) {
+  if (h->profiling == 1) {
     const size_t per = OFFK_NUM_STAGES + 1;
     if ((h->ev_used + 1) * per > h->events.size() && h->events.size() < 4096 * per) {
       for (size_t i = 0; i < per; ++i) {
@@ -969,7 +1042,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   const int RI = OFFK_CONV_RELU_IN_, RP = OFFK_CONV_RELU_PRE_, RO = OFFK_CONV_RELU_POST_;
 
   TRY(finalize_merged(h, st));
-  const bool forked = h->side != nullptr;
+  const bool forked = h->side != nullptr && h->profiling != 2;   // per-launch trace: everything in line on the caller's stream
   hipStream_t side = forked ? h->side : st;
   const bool cons = h->cfg.consensus == OFFK_CONSENSUS_AVG;
   float* l7 = cons ? region(h, ws, "logit_7") : out7;
@@ -979,6 +1052,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   auto run_head = [&](hipStream_t hs, int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool,
                       const char* pooled_name, float* logits, int i0, int n) -> int {
     float* pooled = region(h, ws, pooled_name) + (size_t)i0 * C;
+    { int rc = trace_mark(h, hs, k == 0 ? "head_7 (pool + fc)" : k == 1 ? "head_28 (pool + fc)" : "head_14 (pool + fc)"); if (rc != OFFK_OK) return rc; }
     hipError_t e = pool_launch(x + (size_t)i0 * Hh * Hh * x_cs, x_cs, x_coff, n, Hh, Hh, C, maxpool, pooled, hs);
     if (e == hipSuccess) e = fc_launch(pooled, n, C, h->fc_w[k], h->fc_b[k], ncls, logits + (size_t)i0 * ncls, hs);
     if (e != hipSuccess) return fail_hip(h, e, "head");
@@ -1052,7 +1126,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   // other half's big conv.  Bit-identical to the single-stream order (per-output arithmetic does not depend on the split).
   // Measured at B = 64 (same box): bf16x3 2.644 -> 2.622 ms, fp32 5.35 -> 5.44 ms (two MFMA-bound kernels sharing the CUs
   // lose more than the chains gain) -- hence not the default.  Off while stage timing is on.
-  const bool pipelined = h->pipe && !ev && P >= 96;
+  const bool pipelined = h->pipe && !ev && h->profiling == 0 && P >= 96;
   if (!pipelined) {
     TRY(fusion(st, 0, P, true, nullptr, ev));
     if (forked) {
@@ -1082,11 +1156,13 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   }
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;
+    TRY(trace_mark(h, st, "consensus (K6)"));
     HIP_TRY(h, consensus_launch(l7, B, T, ncls, out7, st));                                       // Flow_OFF.py:874
     HIP_TRY(h, consensus_launch(l14, B, T, ncls, out14, st));                                     // Flow_OFF.py:876
     if (out28) HIP_TRY(h, consensus_launch(l28, B, T, ncls, out28, st));                          // Flow_OFF.py:875
   }
   if (ev) HIP_TRY(h, hipEventRecord(ev[6], st));
+  TRY(trace_mark(h, st, nullptr));
   return OFFK_OK;
 }
 

@@ -5,9 +5,11 @@
 //   S = depthwise3x3(D) (+bias)                               :611   (RGB_OFF: learned)
 //     = SobelFilter_Diagonal(D)                               Flow_OFF.py:622, util.py:52-77
 //   motion_s = cat(S, T); fusion = cat(motion_*, carried)     :616, :656, :760, :832
-// Neither concat exists as a copy, and since round 2 not even as a buffer: S goes to a dense [P*HW][32] buffer and
-// T to a dense [P*HW][128] buffer per site, the fusion convolutions read them through a per-chunk source table
-// (ChunkSrc, offk_internal.h).  The stage entry point offk_sobel_tdiff still takes a channel-sliced destination.  dropout(p=0.8) (:612) is the
+// Neither concat exists as a copy: S and T are written straight into the channel slice [coff, coff + 32) / [coff + 32,
+// coff + 160) of the site's fusion buffer (fusion_28 / fusion_14 / fusion_7, channels-last rows of 320 / 1056 / 832
+// floats).  The kernel takes the two halves as separate destination views (StSite::Ms / Mt with their own stride and
+// offset) -- in the library both alias the same fusion buffer (fill_st_site, offk_api.hip); a layout with dense per-site
+// S / T buffers was built in round 2, measured and reverted.  dropout(p=0.8) (:612) is the
 // identity in eval mode; in training mode (StParams.drop_thresh != 0, offk_off_units_train) the S half is
 // multiplied by the reproducible keep-mask / (1 - p) of units_bwd.hip.
 //

@@ -52,6 +52,24 @@ def gather_scores(local, group=None):
     return out[0] if squeeze else out
 
 
+def gather_scores_allreduce(local, group=None, rank=None):
+    """The literal north-star form of the same exchange ("RCCL ... only for the final consensus all-reduce"; SURVEY.md
+    section 8(e)): every rank writes its shard into a zeroed [heads, B, classes] buffer at its clips' rows and ONE sum
+    all-reduce assembles the whole batch on every rank.  x + 0 is exact, so the result equals gather_scores bit for bit;
+    it moves world x the bytes (still <= 620 KB at 8 GPUs: latency-bound either way)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    r = dist.get_rank(group) if rank is None else rank
+    squeeze = local.dim() == 2
+    x = local.unsqueeze(0) if squeeze else local
+    heads, b, c = x.shape
+    buf = torch.zeros(heads, world * b, c, dtype=x.dtype, device=x.device)
+    buf[:, r * b:(r + 1) * b] = x
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[0] if squeeze else buf
+
+
 def fuse_scores_allreduce(weighted_local, group=None):
     """Late two-stream fusion when the RGB and Flow streams live on different ranks
     (score_fusion.ipynb lines 300-301: sum_i w_i * score_i): every rank passes its own

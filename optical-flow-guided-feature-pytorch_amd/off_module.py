@@ -16,6 +16,8 @@ Flow_OFF.py:370-887).  This file provides
 The nn.Conv2d / nn.Linear children are parameter containers only: they are never
 called.  All arithmetic happens in the HIP library; without it every forward raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -65,8 +67,13 @@ class OFFSubNetwork(nn.Module):
 
     # -- weights -> library ---------------------------------------------------------
     def mark_weights_dirty(self):
-        """Force a re-push of every weight on the next forward (only needed after writing a parameter through a
-        path that bypasses torch's version counter, e.g. a raw-pointer write by foreign code)."""
+        """Force a re-push of every weight on the next forward.  Needed after writing a parameter through a path that
+        bypasses the parameter's version counter: a raw-pointer write by foreign code, and IN-PLACE WRITES THROUGH
+        ``.data`` (``p.data.copy_(w)``, ``p.data.mul_(0.9)`` -- common in TSN-era code; ``.data`` is a tensor with its own
+        version counter, so ``p._version`` does not move and the storage pointer stays the same).  ``p.copy_`` / ``p.mul_``
+        under ``torch.no_grad()``, optimizer steps, ``load_state_dict`` and ``p.data = new_tensor`` are all seen without this
+        call.  OFFK_ALWAYS_PUSH=1 in the environment re-pushes everything on every forward (debugging stale weights; slow).
+        The same blind spot exists for the parameter-written-between-forward-and-backward check of OFFUnits."""
         self._pushed = {}
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -92,6 +99,8 @@ class OFFSubNetwork(nn.Module):
         # that goes through torch -- load_state_dict of this module OR of a parent (which calls _load_from_state_dict
         # and never reaches the override above), optimizer steps, param.copy_(), param.data = ... -- either bumps the
         # tensor's version counter or replaces its storage, and both are part of the tag.
+        if os.environ.get("OFFK_ALWAYS_PUSH") == "1":
+            self._pushed = {}
         for k, v in self.state_dict(keep_vars=True).items():
             tag = (v.data_ptr(), v._version)
             if self._pushed.get(k) != tag:
@@ -318,7 +327,9 @@ class BNInception_OFF(nn.Module):
             if fgs is None:
                 raise ValueError("modality_fuse adds the backbone's Feature_Generation_Score (Flow_OFF.py:881): "
                                  "attach a backbone that returns it")
-            return fc7 + fgs + fc14                                            # Flow_OFF.py:881
+            # Flow_OFF.py:881 `fc7 + fgs + fc14`: K7 with unit weights and one "crop" (offk_score_fusion), not a torch op
+            fused, _ = runtime.score_fusion([fc7, fgs.to(fc7.dtype).contiguous(), fc14], (1.0, 1.0, 1.0), want_pred=False)
+            return fused
         if self.variant_name == "rgb_v2":
             return fc7, fgs, fc14, conv2                                       # RGB_OFF_v2.py:891
         return fc7, fgs, fc14                                                  # Flow_OFF.py:884

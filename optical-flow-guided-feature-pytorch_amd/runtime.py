@@ -83,7 +83,12 @@ class OffForward:
         """offk_bind_weight: the library reads ``tensor`` (a contiguous fp32 parameter on this device, reference layout)
         in place from now on -- no copy now, none after an optimizer step.  The caller keeps it alive."""
         _check_dev(tensor, key, self.device)
-        _lib.check(self.lib.offk_bind_weight(self._h, key.encode(), ctypes.c_void_p(tensor.data_ptr())), self._h)
+        kk = key[7:] if key.startswith("module.") else key
+        want = spec.weight_shapes(self.variant).get(kk)
+        if want is not None and tuple(tensor.shape) != tuple(want):
+            raise ValueError("%s has shape %s, the reference's is %s" % (key, tuple(tensor.shape), tuple(want)))
+        shape = (ctypes.c_int64 * tensor.dim())(*tensor.shape)
+        _lib.check(self.lib.offk_bind_weight(self._h, key.encode(), ctypes.c_void_p(tensor.data_ptr()), shape, tensor.dim()), self._h)
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts a reference-format state_dict (extra backbone keys are ignored;
@@ -259,7 +264,20 @@ class OffForward:
 
     # ---- profiling ---------------------------------------------------------------------
     def set_profiling(self, on):
-        _lib.check(self.lib.offk_set_profiling(self._h, int(bool(on))), self._h)
+        """False / 0 off, True / 1 per-stage events (stage_times), 2 per-launch trace (launch_times)."""
+        _lib.check(self.lib.offk_set_profiling(self._h, int(on)), self._h)
+
+    def launch_times(self, reset=True, max_entries=128):
+        """Per-launch trace: OrderedDict name -> (accumulated ms, calls), in first-launch order."""
+        from collections import OrderedDict
+        ms = (ctypes.c_double * max_entries)()
+        calls = (ctypes.c_int64 * max_entries)()
+        buf = ctypes.create_string_buffer(64 * max_entries)
+        n = self.lib.offk_launch_times(self._h, buf, len(buf), ms, calls, max_entries, int(reset))
+        if n < 0:
+            _lib.check(n, self._h)
+        names = buf.value.decode().split("\n")
+        return OrderedDict((names[i], (ms[i], int(calls[i]))) for i in range(min(n, max_entries)))
 
     def stage_times(self, reset=True):
         ms = (ctypes.c_double * _lib.NUM_STAGES)()

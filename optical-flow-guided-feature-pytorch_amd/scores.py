@@ -44,7 +44,18 @@ def reorder_index(target_list, source_list):
     """Index vector that re-orders arrays stored in ``source_list`` order into ``target_list`` order
     (score_fusion.ipynb cell 1: flow list -> rgb list; entries are the split-file lines)."""
     pos = {k: i for i, k in enumerate(source_list)}
+    missing = [k for k in target_list if k not in pos]
+    if missing:   # the notebook's dict.get would put None there and fail later, at the indexing in cell 5
+        raise KeyError("%d entries of the target list are not in the source list, first: %r" % (len(missing), missing[0]))
     return [pos[k] for k in target_list]
+
+
+def read_split_list(path):
+    """A TSN split file (data/ucf101_*_split_*.txt: ``<frame dir> <num frames> <label>`` per line) as the notebook's cell 1
+    reads it: one string per line without the newline.  Returns (lines, labels)."""
+    with open(path, "r") as f:
+        lines = [x.rstrip("\n") for x in f.readlines()]
+    return lines, np.array([int(x.split()[-1]) for x in lines], dtype=np.int64)
 
 
 def late_fusion(score_sets, weights):

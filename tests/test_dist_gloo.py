@@ -41,6 +41,9 @@ def _worker(rank, world, port, B, L, out_dir):
         local = torch.stack((c7, c14, c28), 0)                 # [heads, b, classes]
         res[mode] = odist.gather_scores(local)
         assert res[mode].shape == (3, B, 101)
+        # the all-reduce form of the same exchange (zeroed [heads, B, classes] buffer + sum): identical bits
+        assert torch.equal(odist.gather_scores_allreduce(local), res[mode])
+        assert torch.equal(odist.gather_scores_allreduce(local[0]), res[mode][0])
     fused = odist.fuse_scores_allreduce((1.0 + rank) * res[orc.SLICE_PER_CLIP][0])
     if rank == 0:
         np.savez(os.path.join(out_dir, "out.npz"), flat=res[0].numpy(), per_clip=res[1].numpy(), fused=fused.numpy())

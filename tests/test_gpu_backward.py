@@ -412,3 +412,16 @@ def test_bind_weight_argument_checks(rt):
         h.bind_weight("motion_conv_gen_3a.bias", torch.zeros(128))          # host tensor
     with pytest.raises(_lib.OffkError, match="16-byte aligned"):
         h.bind_weight("motion_conv_gen_3a.bias", torch.zeros(132, device="cuda")[1:129])     # contiguous view, 4 bytes in
+    # a tensor of the wrong shape is refused on the host side and by the library itself (raw ABI call)
+    with pytest.raises(ValueError, match="reference"):
+        h.bind_weight("motion_conv_gen_3a.weight", torch.zeros(128, 192, 1, 1, device="cuda"))
+    import ctypes
+    t = torch.zeros(64, device="cuda")
+    shp = (ctypes.c_int64 * 1)(64)
+    rc = h.lib.offk_bind_weight(h._h, b"motion_conv_gen_3a.bias", ctypes.c_void_p(t.data_ptr()), shp, 1)
+    assert rc == -1 and b"shape mismatch" in h.lib.offk_last_error(h._h)
+    # right shape claimed, allocation behind the pointer too small: [128] floats asked for, 64 floats left
+    big = torch.zeros(4 << 20, device="cuda")           # its own allocation block (not a slice of a pooled small block)
+    shp = (ctypes.c_int64 * 1)(128)
+    rc = h.lib.offk_bind_weight(h._h, b"motion_conv_gen_3a.bias", ctypes.c_void_p(big.data_ptr() + (big.numel() - 64) * 4), shp, 1)
+    assert rc == -1 and b"allocation too small" in h.lib.offk_last_error(h._h)

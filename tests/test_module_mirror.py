@@ -113,6 +113,19 @@ def test_changed_parameters_are_repushed_to_the_library(monkeypatch):
     net.motion_conv_trans_28.weight.data = torch.zeros_like(net.motion_conv_trans_28.weight)   # new storage
     net._handle("cuda:0")
     assert rt.pushed == ["motion_conv_trans_28.weight"]
+    # an in-place write through .data moves neither the parameter's version counter nor its storage --
+    # the documented blind spot; mark_weights_dirty() (or OFFK_ALWAYS_PUSH=1) is the remedy
+    rt.pushed.clear()
+    net.motion_conv_gen_3a.bias.data.mul_(2.0)
+    net._handle("cuda:0")
+    assert rt.pushed == []
+    net.mark_weights_dirty()
+    net._handle("cuda:0")
+    assert len(rt.pushed) == nkeys
+    rt.pushed.clear()
+    monkeypatch.setenv("OFFK_ALWAYS_PUSH", "1")
+    net._handle("cuda:0")
+    assert len(rt.pushed) == nkeys
 
 
 class _TinyBackbone(torch.nn.Module):
