@@ -365,7 +365,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if over:    # several ranks per device: RCCL refuses that, the scores travel over gloo (host-staged)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo's C++ side prints its "[Gloo] Rank ..." banner on fd 1: keep stdout for the one JSON line
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         backend = dist.get_backend()

@@ -420,8 +420,12 @@ def test_bind_weight_argument_checks(rt):
     shp = (ctypes.c_int64 * 1)(64)
     rc = h.lib.offk_bind_weight(h._h, b"motion_conv_gen_3a.bias", ctypes.c_void_p(t.data_ptr()), shp, 1)
     assert rc == -1 and b"shape mismatch" in h.lib.offk_last_error(h._h)
-    # right shape claimed, allocation behind the pointer too small: [128] floats asked for, 64 floats left
-    big = torch.zeros(4 << 20, device="cuda")           # its own allocation block (not a slice of a pooled small block)
+    # right shape claimed, allocation behind the pointer too small: [128] floats asked for, 64 floats left in the
+    # device allocation (its real extent comes from the HIP runtime: a torch tensor may sit inside a larger cached segment)
+    hip = ctypes.CDLL("libamdhip64.so")
+    big = torch.zeros(4 << 20, device="cuda")
+    base, size = ctypes.c_void_p(), ctypes.c_size_t()
+    assert hip.hipMemGetAddressRange(ctypes.byref(base), ctypes.byref(size), ctypes.c_void_p(big.data_ptr())) == 0
     shp = (ctypes.c_int64 * 1)(128)
-    rc = h.lib.offk_bind_weight(h._h, b"motion_conv_gen_3a.bias", ctypes.c_void_p(big.data_ptr() + (big.numel() - 64) * 4), shp, 1)
+    rc = h.lib.offk_bind_weight(h._h, b"motion_conv_gen_3a.bias", ctypes.c_void_p(base.value + size.value - 64 * 4), shp, 1)
     assert rc == -1 and b"allocation too small" in h.lib.offk_last_error(h._h)
