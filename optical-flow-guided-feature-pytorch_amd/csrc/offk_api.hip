@@ -149,6 +149,7 @@ struct offk_handle {
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
+  bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
   std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
@@ -505,6 +506,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   pt.bdirect = 1;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
+  pt.dma = h->pw_dma ? 1 : 0;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
@@ -693,6 +695,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   }
   // inference: K1 fused with the temporal difference (pw_tdiff.hip) unless OFFK_FUSED_UNITS=0 at offk_create
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_PW_DMA"); h->pw_dma = !(e && *e == '0'); }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&

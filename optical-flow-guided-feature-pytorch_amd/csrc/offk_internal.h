@@ -97,6 +97,7 @@ struct PtParams {
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
   int bdirect;               // every site carries wt: the weight operand bypasses LDS (two LDS stages for the feature-map tile)
+  int dma;                   // fp32 + bdirect: the LDS-DMA form (pw_tdiff_dma_kernel); 0 with OFFK_PW_DMA=0 at offk_create
   const float* zeros;
 #ifdef OFFK_PT_TIMING
   unsigned long long* dbg;   // cycle-counter sums (tools only)

@@ -19,6 +19,7 @@
 // Training keeps the unfused pair (the backward needs G for the ReLU mask).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "offk_common.h"
 #include "offk_internal.h"
@@ -490,6 +491,234 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// DMA form (exact fp32 only, round 3): the feature-map tile goes global -> LDS by the load unit itself
+// (`buffer_load_dwordx4 ... lds`, 1 KB per wave instruction) in the layout the maps already have -- per frame [32 k][32
+// pixels], a k row = one 128-byte run of NCHW -- so there is no prefetch register set, no register transpose (32 v_mov per
+// thread and K-tile in the BD form) and no ds_write in the K loop.  Lane (r32, h) of MFMA (g, e) needs
+// X[k = 8g + 4h + e][pixel r32]: one dword read, 256 contiguous bytes per wave instruction (conflict-free), so the x
+// operand is read as plain dwords (the ISA of the BD form showed each ds_read_b128 issued right in front of its first
+// MFMA, i.e. one exposed LDS latency per eight MFMAs; here the reads of unit u + 2 are issued before the MFMAs of unit u).
+// The weight operand stays direct-to-register (pw_pack_direct_kernel image) but is loaded through inline asm with
+// hand-counted `s_waitcnt vmcnt`: the compiler does not see the DMA instructions, so the counts it would emit for
+// builtin loads treat every DMA issued in between as a load that must have landed (a memory latency per K-tile).
+// Queue per step, in issue order: 7 DMAs (tile kt + 1), then after k-group g the two weight loads of (kt + 1, g); in
+// front of group g the weights of (kt, g) must be there = all but the 13 newest operations; at the end of the step the
+// DMAs = all but the 8 newest.  `wave` is made an SGPR (readfirstlane): as a VGPR it turned the scalar offset of every
+// weight load into a waterfall loop inside the MFMA stream.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
+  constexpr int FRAME_B = 32 * 128;              // one frame's K-tile image [32 k][32 pixels] fp32
+  constexpr int STAGE_B = PT_FT * FRAME_B;       // 28 KB; two stages
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  PtSite S;
+  int nblk_site;
+#define OFFK_PT_PICK(i)                                                                                \
+  S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;                           \
+  S.bias_down = p.s[i].bias_down; S.wt = p.s[i].wt;                                                    \
+  S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
+  S.nrem = p.s[i].nrem; S.rsh = p.s[i].rsh;                                                            \
+  S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
+  nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;          \
+  S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
+  S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
+  OFFK_PT_PICK(0)
+#pragma unroll
+  for (int i = 1; i < kNumSites; ++i)
+    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PT_PICK(i) }
+#undef OFFK_PT_PICK
+  const int C = S.C, HW = S.HW, L = p.L;
+  int local = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site);
+  const int tg = local % p.tgroups; local /= p.tgroups;
+  const int nfull = p.B * S.chunks;
+  const bool leftover = local >= nfull;
+  const int rsh = leftover ? S.rsh : 5, rmask = (1 << rsh) - 1;
+  const int b = leftover ? (local - nfull) << (5 - rsh) : local / S.chunks;
+  const int q0 = (leftover ? S.chunks : local - b * S.chunks) * 32;
+  const int t0 = tg * (PT_FT - 1);
+  const int nf = min(PT_FT, L - t0);
+  const bool last_group = tg == p.tgroups - 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r32 = lane & 31, h = lane >> 5;
+
+  // ---- DMA lane mapping: k row 8 * wave + (lane >> 3) of the K-tile, pixel quad lane & 7; instruction i = frame i ----
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int pq = lane & 7;
+  const int cq = (4 * pq) >> rsh;                                  // clip of the quad within the block (0 unless packed)
+  const int k0px = q0 + ((4 * pq) & rmask);
+  const bool px_ok = k0px < HW && b + cq < p.B;
+  const int vbase = px_ok ? ((8 * wave + (lane >> 3)) * HW + k0px) * 4 : (int)0x80000000;   // past every descriptor -> zeros
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + (unsigned)wave * 1024u;
+  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
+  };
+  auto dma_tile = [&](int kt, const int stage) {
+    const float* xb = S.xp[0]; int cpart = S.cp[0], kl = kt * BK;
+    if (S.nparts > 1 && kl >= S.cp[0]) {
+      kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
+      if (S.nparts > 2 && kl >= S.cp[1]) {
+        kl -= S.cp[1]; xb = S.xp[2]; cpart = S.cp[2];
+        if (S.nparts > 3 && kl >= S.cp[2]) { kl -= S.cp[2]; xb = S.xp[3]; cpart = S.cp[3]; }
+      }
+    }
+    const unsigned long long xa = reinterpret_cast<unsigned long long>(xb);
+    const i32x4 desc = {(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
+    const int fstride = cpart * HW * 4;                                   // bytes per frame of this part (scalar)
+    const int s0 = (((b * L + t0) * cpart + kl) * HW) * 4;                // scalar: frame t0, channel kl
+    const int vclip = cq * L * fstride + vbase;                           // an invalid vbase stays >= 2^31 (the sum is < 2^30 more)
+#pragma unroll
+    for (int i = 0; i < PT_FT; ++i) {
+      const int voff = i < nf ? vclip + i * fstride : (int)0x80000000;   // frame slot past the group: zeros
+      dma16(desc, lds_base + stage * STAGE_B + i * FRAME_B, voff, s0);
+    }
+  };
+
+  // ---- weight operand: asm loads into bq (hand-counted waits, see the header) ----
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 bq[8];                  // [0..3]: this wave's 32 gen rows, k-group g; [4..7]: the 32 down rows
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4 wdesc;
+  {
+    const unsigned long long wa = reinterpret_cast<unsigned long long>(S.wt);
+    wdesc = i32x4{(int)(unsigned)wa, (int)(unsigned)(wa >> 32) & 0xffff, kUnitCh * C * 4, 0x00020000};
+  }
+  const int wlane = lane * 16;
+  auto load_w = [&](const int sel, const int g, int kt) {
+    const int soff = ((kt * 5 + (sel ? 4 : wave)) * 4 + g) * 1024;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(bq[sel * 4 + g]) : "v"(wlane), "s"(wdesc), "s"(soff));
+  };
+  // all but the newest N vector-memory operations are done; ties the registers the MFMAs of group g read to the wait
+#define OFFK_WAIT_W(N, g) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[g]), "+v"(bq[4 + (g)]))
+
+  f32x16 acc[PT_FT + 2];
+#pragma unroll
+  for (int t = 0; t < PT_FT + 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const bool d1 = wave + 4 < PT_FT;          // waves 0-2 own a second down tile
+  const int nkt = C / BK;
+  // x operand of unit (g, t): lane (r32, h) reads k rows 8g + 4h + e, e = 0..3, of frame f(t) at pixel r32
+  const char* const xl = lds + h * 512 + r32 * 4;
+  const char* const xld = xl + wave * FRAME_B;
+  const char* const xld2 = xl + min(wave + 4, PT_FT - 1) * FRAME_B;     // wave 3 has no second down tile: its unit 8 reads are unused
+  auto rdx = [&](float (&x)[4], const int st, const int g, const int t) {
+    const char* q = (t < PT_FT ? xl + t * FRAME_B : (t == PT_FT ? xld : xld2)) + st * STAGE_B + g * 1024;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = *reinterpret_cast<const float*>(q + e * 128);
+  };
+  auto mm4 = [&](f32x16& c, const f32x4& w, const float (&x)[4]) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x[3], c, 0, 0, 0);
+  };
+  // one K-tile out of stage `st`: nine units per k-group (7 gen tiles, the down tiles of frames `wave` and, waves 0-2,
+  // wave + 4), x reads two units ahead; behind group g the weight registers of group g are re-loaded for tile ktn
+  auto mma = [&](const int st, int ktn) {
+    constexpr int NU = PT_FT + 2, TOT = 4 * NU;
+    float x[3][4];
+    rdx(x[0], st, 0, 0);
+    rdx(x[1], st, 0, 1);
+#pragma unroll
+    for (int u = 0; u < TOT; ++u) {
+      const int g = u / NU, t = u % NU;
+      if (u + 2 < TOT) rdx(x[(u + 2) % 3], st, (u + 2) / NU, (u + 2) % NU);
+      if (t == 0) {
+        if (g == 0) OFFK_WAIT_W(13, 0); else if (g == 1) OFFK_WAIT_W(13, 1); else if (g == 2) OFFK_WAIT_W(13, 2); else OFFK_WAIT_W(13, 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t < NU - 1 || d1) mm4(acc[t], bq[t < PT_FT ? g : 4 + g], x[u % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t == NU - 1) { load_w(0, g, ktn); load_w(1, g, ktn); }
+    }
+  };
+  auto step = [&](int kt, const int st) {
+    dma_tile(min(kt + 1, nkt - 1), st ^ 1);        // every wave has left stage st ^ 1 at the last barrier
+    __builtin_amdgcn_sched_barrier(0);
+    mma(st, min(kt + 1, nkt - 1));
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's DMAs of the step have landed
+    __syncthreads();
+  };
+  // prologue: tile 0 and the weights of tile 0 (queue: 7 DMAs, 8 weight loads), then as every step leaves it:
+  // 8 weight loads in flight in front of the next step's DMAs
+  dma_tile(0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { load_w(0, g, 0); load_w(1, g, 0); }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    step(kt, 0);
+    step(kt + 1, 1);
+  }
+  if (kt < nkt) step(kt, 0);
+  // nothing may still be landing when the LDS is handed on -- and the weight registers stay allocated until the last asm load
+  // into them has returned: with their values dead after the last step the compiler re-used them as temporaries while
+  // the loads were still in flight (wrong x operands in the tail step of the two odd-K sites)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bq[4]), "+v"(bq[5]), "+v"(bq[6]), "+v"(bq[7]) :: "memory");
+#undef OFFK_WAIT_W
+
+  // ---- epilogue (as pw_tdiff_kernel): G = relu(acc + bias) in registers, T = G[j+1] - G[j] -> M; D -> HBM ----
+  float4 bg4[4], bd4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bg4[g] = *reinterpret_cast<const float4*>(S.bias + wave * 32 + 8 * g + 4 * h);
+    bd4[g] = *reinterpret_cast<const float4*>(S.bias_down + 8 * g + 4 * h);
+  }
+#pragma unroll
+  for (int j = 0; j < PT_FT; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(fmaxf(acc[j][4 * g] + bg4[g].x, 0.f), fmaxf(acc[j][4 * g + 1] + bg4[g].y, 0.f),
+                             fmaxf(acc[j][4 * g + 2] + bg4[g].z, 0.f), fmaxf(acc[j][4 * g + 3] + bg4[g].w, 0.f));
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+      acc[j][4 * g] = v.x; acc[j][4 * g + 1] = v.y; acc[j][4 * g + 2] = v.z; acc[j][4 * g + 3] = v.w;
+    }
+#pragma unroll
+  for (int t = PT_FT; t < PT_FT + 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(acc[t][4 * g] + bd4[g].x, acc[t][4 * g + 1] + bd4[g].y, acc[t][4 * g + 2] + bd4[g].z, acc[t][4 * g + 3] + bd4[g].w);
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+      acc[t][4 * g] = v.x; acc[t][4 * g + 1] = v.y; acc[t][4 * g + 2] = v.z; acc[t][4 * g + 3] = v.w;
+    }
+  const int bl = b + (r32 >> rsh), pixl = q0 + (r32 & rmask);      // this lane's clip and pixel
+  const size_t pair0 = (size_t)bl * (L - 1) + t0;
+  const bool pix_ok = pixl < HW && bl < p.B;
+#pragma unroll
+  for (int j = 0; j + 1 < PT_FT; ++j) {
+    if (j + 1 < nf && pix_ok) {
+      float* mrow = S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f4v tv = {acc[j + 1][4 * g] - acc[j][4 * g], acc[j + 1][4 * g + 1] - acc[j][4 * g + 1],
+                        acc[j + 1][4 * g + 2] - acc[j][4 * g + 2], acc[j + 1][4 * g + 3] - acc[j][4 * g + 3]};
+        *reinterpret_cast<f4v*>(mrow + 8 * g) = tv;
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int j = wave + 4 * half;
+    if (j < nf && (last_group || j < PT_FT - 1) && pix_ok) {
+      const int dr = pt_down_row(bl, t0 + j, L, p.P, p.slice_mode);
+      if (dr >= 0) {
+        float* drow = S.D + ((size_t)dr * HW + pixl) * kDownCh + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f4v dv = {acc[PT_FT + half][4 * g], acc[PT_FT + half][4 * g + 1], acc[PT_FT + half][4 * g + 2], acc[PT_FT + half][4 * g + 3]};
+          *reinterpret_cast<f4v*>(drow + 8 * g) = dv;
+        }
+      }
+    }
+  }
+}
+
 // Operand-order image of a site's 160 weight rows for the BD form.  One 16-byte item per (K-tile, slab, i, lane):
 //   fp32  : i = k-group g          -> W[slab*32 + r32][kt*32 + 8g + 4h + 0..3]
 //   bf16x3: i = plane*2 + s2       -> bf16 hi (plane 0) / lo (plane 1) of W[slab*32 + r32][kt*32 + 16 s2 + 8h + 0..7]
@@ -541,7 +770,12 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
   constexpr size_t kStageA32 = (size_t)PT_BM * LDS_K * 4, kStageAB3 = 2 * (size_t)PT_BM * B3_ROW;   // BD: feature-map tile only, two stages
 #define OFFK_PT_LAUNCH_BD(P)                                                                                         \
-  {                                                                                                                  \
+  if (P == 0 && p.dma) {                                                                                             \
+    constexpr int kDmaLds = 2 * PT_FT * 32 * 128;                                                                    \
+    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_dma_kernel), kDmaLds);                      \
+    if (er != hipSuccess) return er;                                                                                 \
+    hipLaunchKernelGGL(pw_tdiff_dma_kernel, dim3(p.total_blocks), dim3(256), kDmaLds, st, p);                        \
+  } else {                                                                                                                  \
     const size_t bytes = 2 * (P == 0 ? kStageA32 : kStageAB3);                                                       \
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<P, 0, 0, 1, 1>), (int)bytes);        \
     if (er != hipSuccess) return er;                                                                                 \
