@@ -502,10 +502,19 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 // The weight operand stays direct-to-register (pw_pack_direct_kernel image) but is loaded through inline asm with
 // hand-counted `s_waitcnt vmcnt`: the compiler does not see the DMA instructions, so the counts it would emit for
 // builtin loads treat every DMA issued in between as a load that must have landed (a memory latency per K-tile).
-// Queue per step, in issue order: 7 DMAs (tile kt + 1), then after k-group g the two weight loads of (kt + 1, g); in
-// front of group g the weights of (kt, g) must be there = all but the 13 newest operations; at the end of the step the
-// DMAs = all but the 8 newest.  `wave` is made an SGPR (readfirstlane): as a VGPR it turned the scalar offset of every
-// weight load into a waterfall loop inside the MFMA stream.
+// Queue per step, in issue order: the seven DMAs of tile kt + 1 go out one behind each of the first seven units (bunched
+// at the top of the step they cost the wave 60-180 cycles each with nothing multiplying behind them: 1.335 -> 1.318 ms),
+// and behind k-group g the two weight loads of (kt + 1, g).  In front of group 0 the weights of (kt, 0) must be there =
+// all but the 6 newest operations; in front of groups 1-3 all but the 13 newest; at the end of the step the DMAs = all but
+// the 8 newest.  `wave` is made an SGPR (readfirstlane): as a VGPR it turned the scalar offset of every weight load into
+// a waterfall loop inside the MFMA stream.
+// Measured and not kept (profiles/r03/k1t_experiments.txt): a persistent form (2 x CUs resident blocks pulling items from
+// a device-side queue, the K-tile stream running across items: 1.335 ms, no gain -- dispatch gaps and prologues were not
+// the loss); MFMAs of two units interleaved so that no two consecutive ones share an accumulator (1.35 ms, no gain).  The
+// timing build (-DOFFK_PT_TIMING) says why: with two blocks per CU a K-tile takes a wave 17.6 k cycles of issue + 1.9 k at
+// the barrier against 18.4 k for two waves sharing a SIMD's pipe; a block ALONE on its CU needs 11.1 k per K-tile against
+// 9.2 k (83 %), so whenever the partner block is in its epilogue (~19 k cycles per item) or at a barrier the pipe is not
+// full, and three blocks per CU do not fit (202 VGPRs, 56 KB of LDS).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
   constexpr int FRAME_B = 32 * 128;              // one frame's K-tile image [32 k][32 pixels] fp32
@@ -555,7 +564,13 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
   };
-  auto dma_tile = [&](int kt, const int stage) {
+  // tile kt -> LDS stage: dma_prep computes the descriptor and offsets (scalar + one vector multiply-add), dma_issue sends
+  // frame i.  In the K loop the seven DMAs go out one behind each of the first seven units of a step: issued in a bunch at
+  // the top of the step they cost the wave ~60-180 cycles each with nothing multiplying behind them (a block alone on its
+  // CU ran at 74 % of the matrix pipe, two at 84 %).
+  i32x4 dm_desc = {0, 0, 0, 0};
+  int dm_fstride = 0, dm_s0 = 0, dm_vclip = 0;
+  auto dma_prep = [&](int kt) {
     const float* xb = S.xp[0]; int cpart = S.cp[0], kl = kt * BK;
     if (S.nparts > 1 && kl >= S.cp[0]) {
       kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
@@ -565,15 +580,19 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
       }
     }
     const unsigned long long xa = reinterpret_cast<unsigned long long>(xb);
-    const i32x4 desc = {(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
-    const int fstride = cpart * HW * 4;                                   // bytes per frame of this part (scalar)
-    const int s0 = (((b * L + t0) * cpart + kl) * HW) * 4;                // scalar: frame t0, channel kl
-    const int vclip = cq * L * fstride + vbase;                           // an invalid vbase stays >= 2^31 (the sum is < 2^30 more)
+    dm_desc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
+    dm_fstride = cpart * HW * 4;                                      // bytes per frame of this part (scalar)
+    dm_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;                   // scalar: frame t0, channel kl
+    dm_vclip = cq * L * dm_fstride + vbase;                           // an invalid vbase stays >= 2^31 (the sum is < 2^30 more)
+  };
+  auto dma_issue = [&](const int i, const int stage) {
+    const int voff = i < nf ? dm_vclip + i * dm_fstride : (int)0x80000000;   // frame slot past the group: zeros
+    dma16(dm_desc, lds_base + stage * STAGE_B + i * FRAME_B, voff, dm_s0);
+  };
+  auto dma_tile = [&](int kt, const int stage) {
+    dma_prep(kt);
 #pragma unroll
-    for (int i = 0; i < PT_FT; ++i) {
-      const int voff = i < nf ? vclip + i * fstride : (int)0x80000000;   // frame slot past the group: zeros
-      dma16(desc, lds_base + stage * STAGE_B + i * FRAME_B, voff, s0);
-    }
+    for (int i = 0; i < PT_FT; ++i) dma_issue(i, stage);
   };
 
   // ---- weight operand: asm loads into bq (hand-counted waits, see the header) ----
@@ -628,21 +647,29 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
     for (int u = 0; u < TOT; ++u) {
       const int g = u / NU, t = u % NU;
       if (u + 2 < TOT) rdx(x[(u + 2) % 3], st, (u + 2) / NU, (u + 2) % NU);
-      if (t == 0) {
-        if (g == 0) OFFK_WAIT_W(13, 0); else if (g == 1) OFFK_WAIT_W(13, 1); else if (g == 2) OFFK_WAIT_W(13, 2); else OFFK_WAIT_W(13, 3);
+      if (t == 0) {      // group 0 waits before this step's DMAs are in the queue: 6 newer weight loads only
+        if (g == 0) OFFK_WAIT_W(6, 0); else if (g == 1) OFFK_WAIT_W(13, 1); else if (g == 2) OFFK_WAIT_W(13, 2); else OFFK_WAIT_W(13, 3);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (t < NU - 1 || d1) mm4(acc[t], bq[t < PT_FT ? g : 4 + g], x[u % 3]);
       __builtin_amdgcn_sched_barrier(0);
+      if (g == 0 && t < PT_FT) dma_issue(t, st ^ 1);      // every wave has left stage st ^ 1 at the last barrier
       if (t == NU - 1) { load_w(0, g, ktn); load_w(1, g, ktn); }
     }
   };
+#ifdef OFFK_PT_TIMING
+  unsigned long long tm_mma = 0, tm_wait = 0, tm_bar = 0;
+  const unsigned long long tm_begin = __builtin_readcyclecounter();
+#define OFFK_STAMP(var, stmt) { const unsigned long long q0_ = __builtin_readcyclecounter(); stmt; var += __builtin_readcyclecounter() - q0_; }
+#else
+#define OFFK_STAMP(var, stmt) stmt;
+#endif
   auto step = [&](int kt, const int st) {
-    dma_tile(min(kt + 1, nkt - 1), st ^ 1);        // every wave has left stage st ^ 1 at the last barrier
+    OFFK_STAMP(tm_mma, dma_prep(min(kt + 1, nkt - 1));
     __builtin_amdgcn_sched_barrier(0);
-    mma(st, min(kt + 1, nkt - 1));
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's DMAs of the step have landed
-    __syncthreads();
+    mma(st, min(kt + 1, nkt - 1)))
+    OFFK_STAMP(tm_wait, asm volatile("s_waitcnt vmcnt(8)" ::: "memory"))   // this wave's DMAs of the step have landed
+    OFFK_STAMP(tm_bar, __syncthreads())
   };
   // prologue: tile 0 and the weights of tile 0 (queue: 7 DMAs, 8 weight loads), then as every step leaves it:
   // 8 weight loads in flight in front of the next step's DMAs
@@ -651,12 +678,19 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
   for (int g = 0; g < 4; ++g) { load_w(0, g, 0); load_w(1, g, 0); }
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __syncthreads();
+#ifdef OFFK_PT_TIMING
+  const unsigned long long tm_loop = __builtin_readcyclecounter();
+#endif
   int kt = 0;
   for (; kt + 1 < nkt; kt += 2) {
     step(kt, 0);
     step(kt + 1, 1);
   }
   if (kt < nkt) step(kt, 0);
+#ifdef OFFK_PT_TIMING
+  const unsigned long long tm_epi = __builtin_readcyclecounter();
+#endif
+#undef OFFK_STAMP
   // nothing may still be landing when the LDS is handed on -- and the weight registers stay allocated until the last asm load
   // into them has returned: with their values dead after the last step the compiler re-used them as temporaries while
   // the loads were still in flight (wrong x operands in the tail step of the two odd-K sites)
@@ -717,6 +751,15 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
       }
     }
   }
+#ifdef OFFK_PT_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.dbg && lane == 0 && wave == 0) {
+    const unsigned long long tm_end = __builtin_readcyclecounter();
+    atomicAdd(p.dbg + 0, tm_loop - tm_begin); atomicAdd(p.dbg + 1, tm_epi - tm_loop); atomicAdd(p.dbg + 2, tm_end - tm_epi);
+    atomicAdd(p.dbg + 3, tm_mma); atomicAdd(p.dbg + 4, tm_wait); atomicAdd(p.dbg + 5, tm_bar);
+    atomicAdd(p.dbg + 6, (unsigned long long)nkt); atomicAdd(p.dbg + 7, 1ull);
+  }
+#endif
 }
 
 // Operand-order image of a site's 160 weight rows for the BD form.  One 16-byte item per (K-tile, slab, i, lane):
@@ -755,14 +798,16 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #ifdef OFFK_PT_TIMING
   {
     static unsigned long long* dbg = nullptr;
-    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64); (void)hipMemset(dbg, 0, 64); }
+    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 256); (void)hipMemset(dbg, 0, 256); }
     p.dbg = dbg;
     if (getenv("OFFK_PT_TIMING_DUMP")) {
-      unsigned long long hb[8];
-      (void)hipMemcpy(hb, dbg, 64, hipMemcpyDeviceToHost);
+      unsigned long long hb[32];
+      (void)hipMemcpy(hb, dbg, 256, hipMemcpyDeviceToHost);
       fprintf(stderr, "[pt timing] store %llu sync1 %llu load-issue %llu mma %llu sync2 %llu | ktiles %llu blocks %llu epilogue %llu\n",
               hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
-      (void)hipMemset(dbg, 0, 64);
+      fprintf(stderr, "[pt timing, dma form, wave 0 cycles] prologue %llu loop %llu epilogue+drain %llu | in loop: dma-issue+mma %llu dma-wait %llu barrier %llu | ktiles %llu blocks %llu\n",
+              hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
+      (void)hipMemset(dbg, 0, 256);
     }
   }
 #endif
@@ -770,7 +815,7 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
   constexpr size_t kStageA32 = (size_t)PT_BM * LDS_K * 4, kStageAB3 = 2 * (size_t)PT_BM * B3_ROW;   // BD: feature-map tile only, two stages
 #define OFFK_PT_LAUNCH_BD(P)                                                                                         \
-  if (P == 0 && p.dma) {                                                                                             \
+  if (P == 0 && p.dma) {                                                                                      \
     constexpr int kDmaLds = 2 * PT_FT * 32 * 128;                                                                    \
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_dma_kernel), kDmaLds);                      \
     if (er != hipSuccess) return er;                                                                                 \
