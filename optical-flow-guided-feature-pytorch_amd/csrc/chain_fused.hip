@@ -1,0 +1,362 @@
+// K4c: one bottleneck chain of the fusion stage at 14x14 in ONE kernel (exact fp32, gfx950).
+//
+// Stands for the 1x1 -> 3x3 -> 1x1 (+ residual) blocks of fusion@28 (reference RGB_OFF.py):
+//   28a :658-667   t1 = relu(c1(relu(x0)));  t2 = relu(c2_3x3(t1));  sa = relu(c3(t2) + branch(x0))   (x0 pre-ReLU, :657)
+//   28b :670-676   t1 = relu(c1(sa));        t2 = relu(c2_3x3(t1));  sb = relu(c3(t2) + sa)
+//   28c :679-685   same on sb -> motion_sum_28c (the 256 channels at offset 800 of the fusion@14 buffer, :760)
+// As separate launches these are ten short-K convolutions at 20-55 % of the fp32 matrix peak: a launch with nothing in it
+// costs 9-13 us (dispatch of ~1200 blocks, block prologue, drain in front of the dependent successor), the epilogue another
+// 3-12 us, against 4-35 us of MFMA floor, and the 64-channel intermediates make an HBM / L2 round trip each
+// (profiles/r02/small_conv_ablation.txt, profiles/r03/bench_b64_start_of_round.json -> roofline_in_path).
+//
+// Every dependency of a chain is image-local (the 3x3 never leaves the image), so a block that owns whole image rows needs
+// no other block: here a block owns HALF an image (7 of the 14 rows) and computes t1 for the 8 rows it needs (one halo row
+// re-computed: c1 is 12-24 % of a chain, so 1.5-3 % more MFMAs).  Halves, not whole images: P = 384 images are 1.5 per CU,
+// 768 halves are exactly three resident blocks per CU (LDS 52.5 KB, <= 168 VGPRs), i.e. one full round with three waves per
+// SIMD to cover each other's barriers.
+//
+// Geometry: an image row is one 16-wide MFMA tile -- slot 0 and slot 15 are the zero padding of the 3x3, slots 1..14 the
+// pixels -- so tap (dy, dx) of output row r reads the t1 tile of row r + dy shifted by dx slots: plain LDS addresses, no
+// per-tap index arithmetic.  (14 of 16 slots used: the 12.5 % the 14x14 geometry costs on 16- or 32-row MFMA tiles.)
+// v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand: D rows = output channels, lanes = pixels, so a lane holds four
+// consecutive channels of one pixel = one 16-byte store (LDS or global).  Wave w owns output channels [16w, 16w + 16) of
+// c1 / c2 and [64w, 64w + 64) of c3 and reads its weight rows straight from global (L2) into MFMA operand registers; the
+// activations are shared through LDS:
+//   phase 1  c1 (1x1, Cin -> 64): input tiles of 16 channels by LDS-DMA into a two-stage ring (swizzled 64-byte rows), the
+//            wave's whole weight slab in registers before the loop (no tracked loads beside the DMAs); t1 -> LDS, 9 rows
+//            of 16 slots x 64 channels (256-byte slot rows, 16-byte chunk c stored at c ^ slot: the 16 lanes of a read
+//            group hit 16 distinct chunks)
+//   phase 2  c2 (3x3, 64 -> 64) for 4 (then 3) output rows: A = weights from global four steps ahead, B = shifted t1 tiles;
+//            t2 -> LDS (the ring's 16 KB: 4 rows)
+//   phase 3  c3 (1x1, 64 -> 256; 28a: 128 -> 256 over [t2 | x0], x0 read from global) + bias + residual + ReLU -> global
+// Phases 2 and 3 run twice (rows 0-3, rows 4-6) so that t2 fits the ring's 16 KB and three blocks fit a CU.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "offk_common.h"
+#include "offk_internal.h"
+
+namespace offk {
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSlot = 256;                              // bytes of one pixel slot of t1 / t2: 64 fp32 channels
+constexpr int kT1Rows = 9;                              // 7 output rows + one halo row either side
+constexpr int kT1Off = kSlot;                           // one guard slot in front (tap dx = -1 of slot 0 of the first row)
+constexpr int kR2Off = kT1Off + kT1Rows * 16 * kSlot + kSlot;   // guard slot behind; then the ring / t2 region
+constexpr int kR2Bytes = 16384;                         // 2 x 8 KB ring stages (128 slots x 16 channels), later 4 rows of t2
+constexpr int kChainLds = kR2Off + kR2Bytes;            // 53,760 B: three blocks per CU
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float relu_i(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+}  // namespace
+
+// NKT1 = Cin / 16 (4 or 16); MERGED: c3 contracts [t2 | x] (28a: the branch conv on the pre-ReLU chain input folded in)
+template <int NKT1, bool MERGED>
+__global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int li = lane & 15, kq = lane >> 4;
+  // blocks b and b + 8 share an XCD (round-robin placement): the two halves of an image, which read the same halo rows
+  const int grp = blockIdx.x >> 4, within = blockIdx.x & 15;
+  const int img = grp * 8 + (within & 7), hf = within >> 3;
+  if (img >= a.n_img) return;
+  const int R0 = 7 * hf;                  // first output row of this block
+  const int Rf = hf ? 6 : 0;              // first of the 8 image rows whose t1 is computed
+  const int jf = hf ? 0 : 1;              // its t1 row index; t1 row (hf ? 8 : 0) lies outside the image: zeros
+  constexpr int Cin = NKT1 * 16;
+#ifdef OFFK_CHAIN_TIMING
+  unsigned long long tm[4] = {0, 0, 0, 0};
+  unsigned long long tm_q = __builtin_readcyclecounter();
+  const unsigned long long tm_begin = tm_q;
+#define OFFK_LAP(i) { const unsigned long long q_ = __builtin_readcyclecounter(); tm[i] += q_ - tm_q; tm_q = q_; }
+#else
+#define OFFK_LAP(i)
+#endif
+
+  // ================= phase 1: t1 = relu(W1 . x + b1) for 8 rows x 16 slots =================
+  {
+    // the wave's weight slab: rows 16w + li, per 16-channel step the four k of group kq
+    f32x4 w1[NKT1];
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b1 + 16 * wave + 4 * kq);
+    {
+      const float* wr = a.w1 + (size_t)(16 * wave + li) * Cin + 4 * kq;
+#pragma unroll
+      for (int kt = 0; kt < NKT1; ++kt) w1[kt] = *reinterpret_cast<const f32x4*>(wr + 16 * kt);
+    }
+    // Input tiles of 32 channels (128 slots x 128 B = 16 KB) by LDS-DMA into a ring of up to three stages that spans the
+    // whole allocation: t1 / t2 do not exist yet.  Tiles run two ahead of the MFMAs (the first version -- 16-channel tiles,
+    // two stages in the t2 region, one tile ahead -- spent 105 k of a chain's 245 k cycles here for 16 k of MFMA issue).
+    // Wave w lands slots 32w .. 32w + 31 (four instructions of 8 slots); position (slot, chunk cp) holds the slot's
+    // k chunk cp ^ ((slot >> 1) & 7): the 16 lanes of a read group then cover 16 distinct 16-byte chunks.
+    constexpr int NK = NKT1 / 2, NST = NK < 3 ? NK : 3;
+    static_assert(NST * 16384 <= kChainLds, "ring does not fit");
+    const unsigned long long xa = reinterpret_cast<unsigned long long>(a.x + a.x_coff);
+    const i32x4 xdesc = {(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, (int)a.x_bytes, 0x00020000};
+    int voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sl = 32 * wave + 8 * q + (lane >> 3);           // slot of the tile: t1 row sl >> 4, slot sl & 15
+      const int irow = Rf + (sl >> 4), icol = (sl & 15) - 1;
+      const int kch = (lane & 7) ^ ((sl >> 1) & 7);
+      voff[q] = (unsigned)icol < 14u ? ((img * 196 + irow * 14 + icol) * a.x_cs + 4 * kch) * 4 : (int)0x80000000;   // padding slots: zeros
+    }
+    const unsigned ring = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + (unsigned)wave * 4096u;
+    auto dma_tile = [&](const int kt, const int stage) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(ring + stage * 16384 + q * 1024), "v"(voff[q]), "s"(xdesc), "s"(kt * 128) : "memory", "m0");
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* const rd0 = lds + li * 128 + ((kq ^ ((li >> 1) & 7)) << 4);
+    const char* const rd1 = lds + li * 128 + (((4 + kq) ^ ((li >> 1) & 7)) << 4);
+    dma_tile(0, 0);
+    if (NK > 1) dma_tile(1, 1);
+    if (NK > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tile 0 (and the weight slab) are there
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      const int st = kt % NST;
+      if (kt + 2 < NK) dma_tile(kt + 2, (kt + 2) % NST);    // every wave has left that stage at the last barrier
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        f32x4 xv[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          xv[m] = *reinterpret_cast<const f32x4*>((sp ? rd1 : rd0) + st * 16384 + m * 2048);
+          if (a.relu_in) xv[m] = f32x4{relu_i(xv[m].x), relu_i(xv[m].y), relu_i(xv[m].z), relu_i(xv[m].w)};
+        }
+        const f32x4 w = w1[2 * kt + sp];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = mfma4(w.x, xv[m].x, acc[m]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = mfma4(w.y, xv[m].y, acc[m]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = mfma4(w.z, xv[m].z, acc[m]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = mfma4(w.w, xv[m].w, acc[m]);
+      }
+      if (kt + 2 < NK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile kt + 1 has landed (tile kt + 2 may be in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // t1 -> LDS: lane = (slot li, channels 16w + 4kq .. + 3); padding slots and the row outside the image are zeros
+    const bool pad = li == 0 || li == 15;
+    char* const wr = lds + kT1Off + li * kSlot + (((4 * wave + kq) ^ li) << 4);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      f32x4 v = acc[m] + b1;
+      v = pad ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      *reinterpret_cast<f32x4*>(wr + (jf + m) * 16 * kSlot) = v;
+    }
+    *reinterpret_cast<f32x4*>(lds + kT1Off + (hf ? 8 : 0) * 16 * kSlot + threadIdx.x * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  OFFK_LAP(0)
+
+  // ================= phases 2 + 3, rows [r0, r0 + NR) of the block's seven =================
+  // per-lane LDS offsets: t1 read for tap column dx and channel step s; t2 write / read
+  int t1off[3][4], t2rd[4];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int sl = li + dx - 1;                          // -1 .. 16: the guard slots take the two ends
+      t1off[dx][s] = kT1Off + sl * kSlot + (((4 * s + kq) ^ (sl & 15)) << 4);
+    }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) t2rd[s] = kR2Off + li * kSlot + (((4 * s + kq) ^ li) << 4);
+  const int t2wr = kR2Off + li * kSlot + (((4 * wave + kq) ^ li) << 4);
+  const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.b2 + 16 * wave + 4 * kq);
+  // c2 weight of step q = (tap, s): packed [co][ci / 32][tap][32] (pack_conv_weight_launch), 4 consecutive ci
+  const float* const w2r = a.w2 + (size_t)(16 * wave + li) * 576 + 4 * kq;
+  auto w2_load = [&](const int q) {
+    const int tap = q >> 2, s = q & 3;
+    return *reinterpret_cast<const f32x4*>(w2r + ((s >> 1) * 9 + tap) * 32 + 16 * (s & 1));
+  };
+  constexpr int K3 = MERGED ? 128 : 64, KS3 = K3 / 16;
+  const float* const w3r = a.w3 + (size_t)(64 * wave + li) * K3 + 4 * kq;       // + 16 n' rows, + 16 s
+  const bool px_ok = li >= 1 && li <= 14;
+  const int pix0 = img * 196 + R0 * 14 + (px_ok ? li - 1 : 0);                // + row * 14
+
+  auto pass = [&](const int r0, auto nr_tag) {
+    constexpr int NR = decltype(nr_tag)::value;
+    // ---- phase 2: t2 = relu(W2 * t1 + b2) ----
+    {
+      f32x4 acc[NR];
+#pragma unroll
+      for (int m = 0; m < NR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 wq[4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wq[q] = w2_load(q);
+      // activations one step ahead of the MFMAs (two register sets), weights three steps ahead
+      f32x4 xv[2][NR];
+      auto x_load = [&](f32x4 (&x)[NR], const int q) {
+        const int tap = q >> 2, sq = q & 3, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) x[m] = *reinterpret_cast<const f32x4*>(lds + t1off[dx][sq] + (r0 + m + dy) * 16 * kSlot);
+      };
+      x_load(xv[0], 0);
+#pragma unroll
+      for (int q = 0; q < 36; ++q) {
+        if (q + 3 < 36) wq[(q + 3) & 3] = w2_load(q + 3);
+        if (q + 1 < 36) x_load(xv[(q + 1) & 1], q + 1);
+        __builtin_amdgcn_sched_barrier(0);       // (hipcc otherwise hoists the weight loads of all 36 steps to the top: spills)
+        const f32x4 w = wq[q & 3];
+        const f32x4 (&x)[NR] = xv[q & 1];
+#pragma unroll
+        for (int m = 0; m < NR; ++m) acc[m] = mfma4(w.x, x[m].x, acc[m]);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) acc[m] = mfma4(w.y, x[m].y, acc[m]);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) acc[m] = mfma4(w.z, x[m].z, acc[m]);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) acc[m] = mfma4(w.w, x[m].w, acc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        const f32x4 v = acc[m] + b2;
+        *reinterpret_cast<f32x4*>(lds + t2wr + m * 16 * kSlot) = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      }
+    }
+    __syncthreads();
+    OFFK_LAP(1)
+    // ---- phase 3: y = post(W3 * [t2 | x] + b3 + res), output channels 64w + 16n' + 4kq .. + 3, two n' at a time ----
+#pragma unroll
+    for (int np = 0; np < 2; ++np) {
+      f32x4 acc[2][NR];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < NR; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // weights three steps ahead of their MFMAs (a step is 1024 cycles of one wave's MFMAs; one step ahead left the L2
+      // latency of every load exposed: phase 3 took 77-113 k of a block's 250 k cycles for 14 k cycles of MFMA issue)
+      f32x4 wq[4][2];
+      auto w3_load = [&](f32x4 (&w)[2], const int s) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) w[n] = *reinterpret_cast<const f32x4*>(w3r + (size_t)(16 * (2 * np + n)) * K3 + 16 * s);
+      };
+      f32x4 xg[MERGED ? NR : 1];       // MERGED: the chain input (pre-ReLU) of this lane's pixels, channel step s - 4, from global
+      auto xg_load = [&](const int s) {
+        if constexpr (MERGED) {
+#pragma unroll
+          for (int m = 0; m < NR; ++m)
+            xg[m] = *reinterpret_cast<const f32x4*>(a.x + (size_t)(pix0 + (r0 + m) * 14) * a.x_cs + a.x_coff + 16 * (s - 4) + 4 * kq);
+        }
+      };
+#pragma unroll
+      for (int s = 0; s < 3 && s < KS3; ++s) w3_load(wq[s], s);
+      // bias and the residual rows of both n' go out in front of the MFMAs (loaded in the epilogue they cost it an L2 latency each)
+      f32x4 rv[MERGED ? 1 : 2][MERGED ? 1 : NR], bb[2];      // (the merged form has its branch conv in K: no residual)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int ch = 64 * wave + 16 * (2 * np + n) + 4 * kq;
+        bb[n] = *reinterpret_cast<const f32x4*>(a.b3 + ch);
+        if constexpr (!MERGED) {
+#pragma unroll
+          for (int m = 0; m < NR; ++m)
+            rv[n][m] = a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(pix0 + (r0 + m) * 14) * a.res_cs + a.res_coff + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      if constexpr (MERGED) xg_load(4);
+#pragma unroll
+      for (int s = 0; s < KS3; ++s) {
+        if (s + 3 < KS3) w3_load(wq[(s + 3) & 3], s + 3);
+        f32x4 xv[NR];
+        if (s < 4) {
+#pragma unroll
+          for (int m = 0; m < NR; ++m) xv[m] = *reinterpret_cast<const f32x4*>(lds + t2rd[s] + m * 16 * kSlot);
+        } else {
+#pragma unroll
+          for (int m = 0; m < NR; ++m) xv[m] = xg[m];
+        }
+        if (MERGED && s >= 4 && s + 1 < KS3) xg_load(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const f32x4 w = wq[s & 3][n];
+#pragma unroll
+          for (int m = 0; m < NR; ++m) acc[n][m] = mfma4(w.x, xv[m].x, acc[n][m]);
+#pragma unroll
+          for (int m = 0; m < NR; ++m) acc[n][m] = mfma4(w.y, xv[m].y, acc[n][m]);
+#pragma unroll
+          for (int m = 0; m < NR; ++m) acc[n][m] = mfma4(w.z, xv[m].z, acc[n][m]);
+#pragma unroll
+          for (int m = 0; m < NR; ++m) acc[n][m] = mfma4(w.w, xv[m].w, acc[n][m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // epilogue: one 16-byte residual load and one 16-byte store per (n', row)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int ch = 64 * wave + 16 * (2 * np + n) + 4 * kq;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+          f32x4 v = acc[n][m] + bb[n];
+          if constexpr (!MERGED) v += rv[n][m];
+          if (a.relu_out) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+          if (px_ok) *reinterpret_cast<f32x4*>(a.y + (size_t)(pix0 + (r0 + m) * 14) * a.y_cs + a.y_coff + ch) = v;
+        }
+      }
+    }
+    __syncthreads();        // t2 is overwritten by the next pass
+    OFFK_LAP(2)
+  };
+  pass(0, std::integral_constant<int, 4>());
+  pass(4, std::integral_constant<int, 3>());
+#ifdef OFFK_CHAIN_TIMING
+  if (a.dbg && threadIdx.x == 0) {
+    atomicAdd(a.dbg + 0, tm[0]); atomicAdd(a.dbg + 1, tm[1]); atomicAdd(a.dbg + 2, tm[2]);
+    atomicAdd(a.dbg + 3, __builtin_readcyclecounter() - tm_begin); atomicAdd(a.dbg + 4, 1ull);
+  }
+#endif
+#undef OFFK_LAP
+}
+
+hipError_t chain14_launch(const ChainArgs& a_in, hipStream_t st, const char** why) {
+  ChainArgs a = a_in;
+  *why = nullptr;
+#ifdef OFFK_CHAIN_TIMING
+  {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64); (void)hipMemset(dbg, 0, 64); }
+    a.dbg = dbg;
+    if (getenv("OFFK_CHAIN_TIMING_DUMP")) {
+      unsigned long long hb[8];
+      (void)hipMemcpy(hb, dbg, 64, hipMemcpyDeviceToHost);
+      if (hb[4]) fprintf(stderr, "[chain timing, thread 0 cycles per block] phase 1 %llu  phase 2 (both passes) %llu  phase 3 %llu  total %llu  (blocks %llu)\n",
+                         hb[0] / hb[4], hb[1] / hb[4], hb[2] / hb[4], hb[3] / hb[4], hb[4]);
+      (void)hipMemset(dbg, 0, 64);
+    }
+  }
+#endif
+  if ((a.Cin != 64 && a.Cin != 256) || (a.K3 != 64 && a.K3 != 128) || a.n_img < 1 || a.x_cs % 4 || a.x_coff % 4 || a.y_cs % 4 || a.y_coff % 4 ||
+      (a.res && (a.res_cs % 4 || a.res_coff % 4)) || (a.K3 == 128 && (a.Cin != 64 || a.res))) {
+    *why = "chain14: need Cin in {64, 256}, K3 in {64, 128 (with Cin 64)}, 16-byte aligned channel slices";
+    return hipErrorInvalidValue;
+  }
+  if (!a.x_bytes) { *why = "chain14: input beyond 31-bit byte offsets"; return hipErrorInvalidValue; }
+  const int blocks = (a.n_img + 7) / 8 * 16;
+#define OFFK_CHAIN_LAUNCH(NKT, MRG)                                                                                   \
+  {                                                                                                                   \
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(chain14_kernel<NKT, MRG>), kChainLds);                 \
+    if (e != hipSuccess) return e;                                                                                    \
+    hipLaunchKernelGGL((chain14_kernel<NKT, MRG>), dim3(blocks), dim3(256), kChainLds, st, a);                        \
+  }
+  if (a.Cin == 64 && a.K3 == 128) OFFK_CHAIN_LAUNCH(4, true)
+  else if (a.Cin == 64) OFFK_CHAIN_LAUNCH(4, false)
+  else OFFK_CHAIN_LAUNCH(16, false)
+#undef OFFK_CHAIN_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace offk

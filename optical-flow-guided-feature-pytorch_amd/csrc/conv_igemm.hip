@@ -1205,10 +1205,26 @@ static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t
 // small tiles win (more resident waves hide the gather latency, finer work quantisation):
 // 64x64 for short K, 64x128 for long K with wide outputs; then split K until the grid has
 // >= 1536 blocks (6 per CU) while every slice keeps >= 16 K-tiles.
-void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out) {
+// Exact fp32 (round 3, tools/tune_forward.py --wide at B = 42 / P = 252: the rule above lost 5.8 % to the in-situ optimum,
+// almost all of it in the split of the three big convs): the 64x64 tile everywhere and a split that brings the grid to
+// >= 3500 blocks (2.7 rounds of the 1280 resident blocks: the tuned plans at P = 240 / 252 / 384 all sit at 3500-7000)
+// while a slice keeps >= 24 K-tiles.
+void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out, int precision) {
+  static const int cand[] = {1, 2, 3, 4, 6, 8, 12};
+  if (precision == 0) {
+    const long long blocks = ((M + 63) / 64) * (Co / 64);
+    int sk = 1;
+    for (int c : cand) {
+      if (c > 1 && nkt / c < 24) break;
+      sk = c;
+      if (blocks * c >= 3500) break;
+    }
+    *cfg_out = 3;
+    *splitk_out = sk;
+    return;
+  }
   int cfg = (nkt >= 36 && Co % 128 == 0) ? 4 : 3;
   long long blocks = ((M + kTileBM[cfg] - 1) / kTileBM[cfg]) * (Co / kTileBN[cfg]);
-  static const int cand[] = {1, 2, 3, 4, 6, 8, 12};
   int sk = 1;
   for (int c : cand) {
     if (nkt / c < 16) break;
@@ -1259,7 +1275,7 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.M = (int)M;
   const int nkt = d.KH * d.KW * (d.Ci / 32);
   int cfg = d.tile_cfg, sk = d.splitk;
-  if (cfg < 0 || sk < 1) conv2d_auto_plan(d.plan_n_img > 0 ? (long long)d.plan_n_img * a.Ho * a.Wo : M, d.Co, nkt, &cfg, &sk);
+  if (cfg < 0 || sk < 1) conv2d_auto_plan(d.plan_n_img > 0 ? (long long)d.plan_n_img * a.Ho * a.Wo : M, d.Co, nkt, &cfg, &sk, d.precision);
   if (sk > nkt) sk = nkt;
   if (narrow) sk = 1;
   a.co_limit = narrow ? d.co_limit : d.Co;

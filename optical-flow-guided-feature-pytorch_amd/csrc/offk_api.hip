@@ -149,6 +149,7 @@ struct offk_handle {
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
+  bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
   bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
@@ -696,6 +697,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   // inference: K1 fused with the temporal difference (pw_tdiff.hip) unless OFFK_FUSED_UNITS=0 at offk_create
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_PW_DMA"); h->pw_dma = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&
@@ -1078,6 +1080,31 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     float *F28_ = at(F28, 28, 320), *F14_ = at(F14, 14, 1056), *F7_ = at(F7, 7, 832);
     TRY(conv(h, s, C_T28, n, 28, View{F28_, 320, 0}, nullptr, 0, 0, 0, xt_, 128, 64));             // :657 x0, pre-ReLU kept for the branch
     if (after_first) HIP_TRY(h, hipEventRecord(after_first, s));
+    // 1x1 -> 3x3 -> 1x1 (+ residual) as ONE launch per chain (exact fp32; a block owns half an image, t1 / t2 stay in LDS)
+    auto chain = [&](const char* name, const float* x, int x_cs, int x_coff, int Cin, int relu_in, ConvId c1, ConvId c2,
+                     const float* w3, const float* b3, int K3, const float* res, float* y, int y_cs, int y_coff) -> int {
+      ChainArgs a;
+      a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in;
+      a.w1 = h->conv_w[c1]; a.b1 = h->conv_b[c1]; a.w2 = h->conv_w[c2]; a.b2 = h->conv_b[c2];
+      a.w3 = w3; a.b3 = b3; a.K3 = K3;
+      a.res = res; a.res_cs = 256; a.res_coff = 0;
+      a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
+      a.n_img = n; a.relu_out = 1;
+      const unsigned long long xb = ((unsigned long long)n * 196 * x_cs - x_coff) * 4ull;
+      a.x_bytes = xb < 0x7fffffffull ? (unsigned)xb : 0u;
+      { int rc = trace_mark(h, s, name); if (rc != OFFK_OK) return rc; }
+      const char* why = nullptr;
+      hipError_t e = chain14_launch(a, s, &why);
+      if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
+      return OFFK_OK;
+    };
+    const bool chained = h->chain && h->cfg.precision == OFFK_PRECISION_FP32 && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
+    if (chained) {
+      TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt_, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
+                nullptr, sa_, 256, 0));                                                              // :658-667
+      TRY(chain("chain_28b = motion_conv1_trans_28b + motion_conv2_trans_28b + motion_conv3_trans_28b", sa_, 256, 0, 256, 0, C1_28B, C2_28B, h->conv_w[C3_28B], h->conv_b[C3_28B], 64, sa_, sb_, 256, 0));   // :670-676
+      TRY(chain("chain_28c = motion_conv1_trans_28c + motion_conv2_trans_28c + motion_conv3_trans_28c", sb_, 256, 0, 256, 0, C1_28C, C2_28C, h->conv_w[C3_28C], h->conv_b[C3_28C], 64, sb_, F14_, 1056, 800)); // :679-685 -> cat at :760
+    } else {
     TRY(conv(h, s, C1_28A, n, 14, View{xt_, 128, 64}, nullptr, 0, 0, RI | RP, t1_, 64, 0));        // :658-660
     TRY(conv(h, s, C2_28A, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :661-662 t2
     TRY(conv_merged(h, s, 0, n, 14, View{xt_, 128, 0}, RO, sa_, 256, 0));                           // :663-667
@@ -1087,6 +1114,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     TRY(conv(h, s, C1_28C, n, 14, View{sb_, 256, 0}, nullptr, 0, 0, RP, t1_, 64, 0));              // :679-680
     TRY(conv(h, s, C2_28C, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :681-682
     TRY(conv(h, s, C3_28C, n, 14, View{xt_, 128, 0}, sb_, 256, 0, RO, F14_, 1056, 800));            // :683-685 -> cat at :760
+    }
     if (sev) HIP_TRY(h, hipEventRecord(sev[3], s));
     if (out28) {   // 28-head (:782-787) beside fusion@14: only reads sum_28c
       if (side_heads && forked) {

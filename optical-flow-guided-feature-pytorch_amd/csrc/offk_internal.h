@@ -32,10 +32,29 @@ struct ConvDesc {
   int plan_n_img = 0;                     // > 0: the automatic plan is the one of this many images (a call on part of a batch
                                           // then splits K exactly as the whole-batch call: same bits)
 };
-void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out);
+void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out, int precision);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
 hipError_t split_bf16_launch(const float* src, size_t n, void* dst, hipStream_t st);   // fp32 -> bf16 hi plane | lo plane
 hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st);
+
+// ---- K4c: one 1x1 -> 3x3 -> 1x1 (+ residual) bottleneck chain at 14x14 per launch (chain_fused.hip, exact fp32) ----
+struct ChainArgs {
+  const float* x; int x_cs, x_coff;       // chain input, channels-last [n_img * 196][x_cs], Cin channels at x_coff
+  int Cin;                                // 64 or 256
+  int relu_in;                            // c1 reads relu(x) (28a: x is the pre-ReLU 7x7 output)
+  const float* w1; const float* b1;       // c1 [64][Cin], [64]
+  const float* w2; const float* b2;       // c2 3x3 64 -> 64 in the library's packed K order [64][2][9][32], [64]
+  const float* w3; const float* b3;       // c3 [256][K3], [256]
+  int K3;                                 // 64, or 128: c3 contracts [t2 | x] (the branch 1x1 on the chain input merged in)
+  const float* res; int res_cs, res_coff; // residual (256 channels) or nullptr
+  float* y; int y_cs, y_coff;             // output, 256 channels at y_coff
+  int n_img, relu_out;
+  unsigned x_bytes;                       // bytes behind x + x_coff (< 2^31, else 0: not launchable)
+#ifdef OFFK_CHAIN_TIMING
+  unsigned long long* dbg;                // cycle sums per phase (tools only)
+#endif
+};
+hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
 
 // ---- K1 ------------------------------------------------------------------------
 struct PwSite {
