@@ -52,10 +52,10 @@ const ConvSpec kConvs[kNumConvs] = {
 // (BASELINE config 2: B = 64, L = 7) on MI355X; other sizes use conv2d_auto_plan.
 // (round 2: re-tuned in situ, tools/tune_forward.py --precision fp32, after the fp32 K loop went lean -- with the addressing
 // VALU gone the 64x64 tile wins almost everywhere: 6.13 -> 5.89 ms; profiles/r02/tune_fp32_lean.txt)
-const int kTunedP384[kNumConvs][2] = {
-    {3, 3}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},   // fusion @28
-    {3, 6}, {3, 1}, {3, 2}, {3, 1}, {3, 1}, {3, 2}, {0, 3}, {3, 1},                           // fusion @14
-    {3, 6}, {3, 1}, {3, 3}, {3, 1}, {3, 1}};                                                   // fusion @7
+// (round 3: after the K loops changed again -- LDS-DMA tiles, fused bottleneck chains at 28 -- the conv2d_auto_plan rule
+// re-derived from the B = 42 sweep beats this table at P = 384 (5.221 vs 5.253 ms, same box) and an in-situ sweep started
+// from it finds nothing better (profiles/r03/tune_b64_fp32_from_heuristic.txt): exact fp32 has no P = 384 table any more;
+// {-1, 0} = automatic)
 // same sweep with --precision 1 (bf16x3 core)
 const int kTunedP384B3[kNumConvs][2] = {
     {1, 6}, {1, 1}, {7, 1}, {3, 1}, {3, 1}, {1, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {1, 1},   // fusion @28
@@ -74,10 +74,10 @@ const MergedSpec kMerged[3] = {{"merged_28a", C3_28A, CB_28A}, {"merged_14a", C3
 // (round 2: both tables re-tuned in situ with the buffer-addressed loaders, tools/tune_forward.py --batch 10 --length 25 --wide:
 // fp32 3.64 -> 3.54 ms, bf16x3 1.77 -> 1.68 ms; profiles/r02/tune_p240_*.txt; splits the sweep reports beyond the slab space of
 // the workspace run unsplit and are written as 1 here)
-const int kTunedP240[kNumConvs][2] = {
-    {3, 8}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1},
-    {3, 8}, {1, 1}, {3, 2}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1},
-    {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}};
+const int kTunedP240[kNumConvs][2] = {   // round 3: the two entries an in-situ sweep from the automatic plans still moves (3.427 -> 3.359 ms)
+    {3, 2}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0},
+    {4, 4}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0},
+    {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}};
 const int kTunedP240B3[kNumConvs][2] = {
     {1, 2}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1},
     {0, 12}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 2}, {3, 1}, {3, 1},
@@ -626,9 +626,11 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
   { const char* e = getenv("OFFK_PW_PRESPLIT"); if (e && *e == '0') h->pw_presplit = false; }
+  const char* tab_env = getenv("OFFK_PLAN_TABLES");          // "0": the heuristic plans at every size (A/B of the tables)
+  const bool use_tables = !(tab_env && *tab_env == '0');
   for (int c = 0; c < kNumConvs; ++c) {
     const bool b3 = cfg->precision == OFFK_PRECISION_BF16X3;
-    const int (*tab)[2] = h->P == 384 ? (b3 ? kTunedP384B3 : kTunedP384) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
+    const int (*tab)[2] = !use_tables ? nullptr : h->P == 384 ? (b3 ? kTunedP384B3 : nullptr) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
