@@ -37,6 +37,8 @@ struct ConvArgs {
   int flags, M;
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
+  float* pool_part;    // != nullptr: per 32-row slab and output channel, the sums of the stored values over the slab's rows of its
+  int pool_hw;         // first / second image (pool_hw rows per image, >= 32): [slab][2][Co] -- the average pool of a head folded in
   float* partial;      // [splitk][M][Co] when splitk > 1
   int no_dma;                  // tools: keep the register-staged loader (OFFK_CONV_DMA=0 in the tuning build)
   unsigned x_bytes, w_bytes;   // PREC 2 (fp32, buffer addressing): bytes behind p.x + p.x_coff / behind p.w, both < 2^31
@@ -555,6 +557,26 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + wm * 32 * TM + tm * 32 + acc_row(reg, h);
         if (m < p.M && co < p.co_limit) p.y[(size_t)m * p.y_cs + p.y_coff + co] = ov[reg];
+      }
+      if (p.pool_part) {
+        // column sums of this accumulator tile, split at the image boundary inside the slab (an image has >= 32 rows, so
+        // a slab touches at most two); fixed order: registers ascending, then the lower half-wave + the upper one
+        const int slab = (m0 + wm * 32 * TM + tm * 32) >> 5;
+        const int b1 = ((slab * 32) / p.pool_hw + 1) * p.pool_hw;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = slab * 32 + acc_row(reg, h);
+          const float v = m < p.M ? ov[reg] : 0.f;
+          s0 += m < b1 ? v : 0.f;
+          s1 += m < b1 ? 0.f : v;
+        }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (h == 0 && co < p.co_limit) {
+          p.pool_part[((size_t)slab * 2) * p.Co + co] = s0;
+          p.pool_part[((size_t)slab * 2 + 1) * p.Co + co] = s1;
+        }
       }
     }
   }
@@ -1279,6 +1301,11 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   if (sk > nkt) sk = nkt;
   if (narrow) sk = 1;
   a.co_limit = narrow ? d.co_limit : d.Co;
+  a.pool_part = d.pool_part; a.pool_hw = d.pool_hw;
+  if (d.pool_part) {
+    if (d.pool_hw < 32 || cfg == 6 || cfg == 7 || cfg == 10) { *why = "conv2d: pooled partial sums need >= 32 rows per image and a generic tile"; return hipErrorInvalidValue; }
+    sk = 1;                               // the sums are taken in the epilogue of an unsplit conv
+  }
   if (sk > 1 && (!d.partial || d.partial_floats < (size_t)sk * (size_t)M * d.Co)) sk = 1;   // no slab space: unsplit
   a.splitk = sk; a.partial = d.partial; a.gm = a.gn = 0;
 #ifdef OFFK_TUNING_KNOBS

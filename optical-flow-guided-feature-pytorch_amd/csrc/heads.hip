@@ -205,6 +205,82 @@ hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, con
   return hipGetLastError();
 }
 
+// FC of a head whose average pool was folded into the producing conv's epilogue (conv_igemm.hip, ConvArgs.pool_part):
+//   pooled[img][c] = (1 / hw) * sum over the 32-row slabs the image touches of part[slab][first or second image][c]
+//   out[img][cls]  = fb[cls] + sum_c fw[cls][c] * pooled[img][c]                  (RGB_OFF.py:789-793, :843-847)
+// as a small fp32-MFMA GEMM: v_mfma_f32_16x16x4_f32, A = 16 weight rows (classes), B = 16 images; a block = 16 images x 32
+// classes, its four waves split K and meet in LDS (fixed order).  Replaces a pooling launch that re-read the 77 MB map
+// plus a per-image VALU GEMV on a (images, 13) grid.
+typedef float fcx4 __attribute__((ext_vector_type(4)));
+constexpr int kFcWaves = 8;       // K is split over the block's waves: C / 8 channels each, in batches of four 16-channel steps
+__global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* __restrict__ part, int hw, int n_img, int C,
+                                                                  const float* __restrict__ fw, const float* __restrict__ fb, int ncls,
+                                                                  float* __restrict__ out) {
+  __shared__ fcx4 red[kFcWaves][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+  const int img = min((int)blockIdx.x * 16 + li, n_img - 1);
+  const int cls0 = blockIdx.y * 32;
+  // the image's rows [img * hw, img * hw + hw) touch slabs s_lo .. s_lo + 2 at most (hw >= 32); a slab the image does not
+  // reach is read with weight 0 from the image's last slab (no branch: every load of a batch goes out before the first use)
+  const int r0 = img * hw, s_lo = r0 >> 5, s_hi = (r0 + hw - 1) >> 5;
+  const float* ps[3];
+  float pw[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int sl = min(s_lo + j, s_hi);
+    const int slot = (sl * 32) / hw == img ? 0 : 1;          // is this image the slab's first or its second?
+    ps[j] = part + ((size_t)sl * 2 + slot) * C + 4 * kq;
+    pw[j] = s_lo + j <= s_hi ? 1.f : 0.f;
+  }
+  const int kbeg = wave * (C / kFcWaves), kend = kbeg + C / kFcWaves;
+  const float* w0 = fw + (size_t)min(cls0 + li, ncls - 1) * C + 4 * kq;
+  const float* w1 = fw + (size_t)min(cls0 + 16 + li, ncls - 1) * C + 4 * kq;
+  fcx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = kbeg; kb < kend; kb += 64) {
+    fcx4 xr[4][3], a0[4], a1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xr[u][j] = *reinterpret_cast<const fcx4*>(ps[j] + kb + 16 * u);
+      a0[u] = *reinterpret_cast<const fcx4*>(w0 + kb + 16 * u);
+      a1[u] = *reinterpret_cast<const fcx4*>(w1 + kb + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const fcx4 x = (xr[u][0] * pw[0] + xr[u][1] * pw[1]) + xr[u][2] * pw[2];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].x, x.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].x, x.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].y, x.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].y, x.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].z, x.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].z, x.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].w, x.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].w, x.w, acc1, 0, 0, 0);
+    }
+  }
+  red[wave][0][lane] = acc0;
+  red[wave][1][lane] = acc1;
+  __syncthreads();
+  if (wave < 2) {          // wave t finishes class tile t: lane = (image li, classes cls0 + 16 t + 4 kq .. + 3), K slices in order
+    fcx4 v = red[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < kFcWaves; ++w) v += red[w][wave][lane];
+    const int gi = blockIdx.x * 16 + li, c = cls0 + 16 * wave + 4 * kq;
+    const float inv = 1.f / (float)hw;
+    if (gi < n_img) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < ncls) out[(size_t)gi * ncls + c + j] = v[j] * inv + fb[c + j];
+    }
+  }
+}
+hipError_t fc_pooled_launch(const float* part, int hw, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
+                            hipStream_t st) {
+  if (C % (64 * kFcWaves) || hw < 32 || n_img <= 0 || ncls <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fc_pooled_kernel, dim3((n_img + 15) / 16, (ncls + 31) / 32), dim3(64 * kFcWaves), 0, st, part, hw, n_img, C, fw, fb, ncls, out);
+  return hipGetLastError();
+}
+
 __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] + b[i];

@@ -160,6 +160,8 @@ struct offk_handle {
   int conv_splitk[kNumConvs];    // K-split per fusion conv (0 = automatic)
   size_t splitk_floats = 0;      // size of the "splitk" workspace region
   float* cur_splitk = nullptr;   // that region inside the workspace of the forward being enqueued
+  float* cur_pool_part = nullptr;   // set around the one conv launch whose epilogue also emits pooled partial sums (heads)
+  bool fold_pool = true;         // 7- / 14-head: average pool in the producing conv's epilogue + MFMA FC (OFFK_FOLD_POOL=0: pool + fc kernels)
   std::vector<void*> allocs;
   // workspace plan
   std::map<std::string, std::pair<size_t, size_t>> regions;
@@ -276,6 +278,9 @@ void plan_workspace(offk_handle* h) {
   add_region(h, "pooled_7", P * 1024);
   add_region(h, "pooled_14", P * 512);
   add_region(h, "pooled_28", P * 256);
+  // average pools of the 7- and 14-heads folded into the producing conv: per 32-row slab, two partial column sums
+  add_region(h, "poolpart_7", ((P * 49 + 31) / 32) * 2 * 1024);
+  add_region(h, "poolpart_14", ((P * 49 + 31) / 32) * 2 * 512);
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64],
   // 3x3 @7: [P*49, 256]); a conv whose plan needs more falls back to fewer slices
   h->splitk_floats = 8 * P * 196 * 64;
@@ -548,6 +553,7 @@ int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, i
   d.partial = h->cur_splitk; d.partial_floats = h->splitk_floats;
   d.precision = h->cfg.precision;
   d.plan_n_img = h->P;                    // the two-half pipeline calls with half the pairs: same plan, same bits
+  d.pool_part = h->cur_pool_part; d.pool_hw = h->cur_pool_part ? H * H / (stride * stride) : 0;
   const char* why = nullptr;
   { int rc = trace_mark(h, st, name); if (rc != OFFK_OK) return rc; }
   hipError_t e = conv2d_launch(d, st, &why);
@@ -700,6 +706,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_PW_DMA"); h->pw_dma = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&
@@ -1133,24 +1140,46 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     TRY(conv_merged(h, s, 1, n, 7, View{xu_, 256, 0}, RO, s14_, 512, 0));                           // :768-771
     TRY(conv(h, s, C1_14B, n, 7, View{s14_, 512, 0}, nullptr, 0, 0, RP, u1_, 128, 0));             // :773-774
     TRY(conv(h, s, C2_14B, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :775-776
-    TRY(conv(h, s, C3_14B, n, 7, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320));         // :777-780 -> cat at :832
+    // (fold: the conv's epilogue also leaves per-slab column sums of sum_14b: the 14-head's average pool.  Slabs are 32
+    // rows of the whole pair range, so only a call on all pairs -- i0 = 0 -- can fold)
+    auto generic = [](int cfg) { return cfg != 6 && cfg != 7 && cfg != 10; };      // the LDS-patch kernels have no pooling epilogue
+    const bool fold = h->fold_pool && i0 == 0 && n == P && generic(h->conv_cfg[C3_14B]) && generic(h->merged_cfg[2]);
+    float* pp14 = region(h, ws, "poolpart_14");
+    float* pp7 = region(h, ws, "poolpart_7");
+    h->cur_pool_part = fold ? pp14 : nullptr;
+    { int rc_ = conv(h, s, C3_14B, n, 7, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320);   // :777-780 -> cat at :832
+      h->cur_pool_part = nullptr;
+      if (rc_ != OFFK_OK) return rc_; }
     if (sev) HIP_TRY(h, hipEventRecord(sev[4], s));
     {              // 14-head (:789-793) beside fusion@7: only reads sum_14b
       if (side_heads && forked) {
         HIP_TRY(h, hipEventRecord(h->ev_fork[1], s));
         HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[1], 0));
       }
-      TRY(run_head(hs, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14, i0, n));
+      if (fold) {
+        TRY(trace_mark(h, hs, "head_14 (fc on folded pool)"));
+        HIP_TRY(h, fc_pooled_launch(pp14, 49, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, hs));
+      } else {
+        TRY(run_head(hs, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14, i0, n));
+      }
     }
     // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
     float *xv_ = at(xv, 7, 512), *v1_ = at(v1, 7, 256), *s7_ = at(s7, 7, 1024);
     TRY(conv(h, s, C_T7, n, 7, View{F7_, 832, 0}, nullptr, 0, 0, RP, xv_, 512, 256));              // :833-834 x2
     TRY(conv(h, s, C1_7, n, 7, View{xv_, 512, 256}, nullptr, 0, 0, RP, v1_, 256, 0));              // :835-836
     TRY(conv(h, s, C2_7, n, 7, View{v1_, 256, 0}, nullptr, 0, 0, RP, xv_, 512, 0));                // :837-838 v2
-    TRY(conv_merged(h, s, 2, n, 7, View{xv_, 512, 0}, 0, s7_, 1024, 0));                            // :839-841 (no ReLU)
+    h->cur_pool_part = fold ? pp7 : nullptr;
+    { int rc_ = conv_merged(h, s, 2, n, 7, View{xv_, 512, 0}, 0, s7_, 1024, 0);                     // :839-841 (no ReLU)
+      h->cur_pool_part = nullptr;
+      if (rc_ != OFFK_OK) return rc_; }
     if (sev) HIP_TRY(h, hipEventRecord(sev[5], s));
     // ---- 7-head on the chain's stream (:843-847)
-    TRY(run_head(s, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7, i0, n));
+    if (fold) {
+      TRY(trace_mark(h, s, "head_7 (fc on folded pool)"));
+      HIP_TRY(h, fc_pooled_launch(pp7, 49, n, 1024, h->fc_w[0], h->fc_b[0], ncls, l7, s));
+    } else {
+      TRY(run_head(s, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7, i0, n));
+    }
     return OFFK_OK;
   };
   // Two-half pipeline (opt-in: OFFK_PIPELINE=1 at offk_create): the bottleneck chains between the big convs are small,

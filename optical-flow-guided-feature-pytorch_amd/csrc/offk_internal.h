@@ -29,6 +29,8 @@ struct ConvDesc {
   size_t partial_floats = 0;
   int precision = 0;                      // 0 = exact fp32 MFMA, 1 = bf16x3
   int co_limit = 0;                       // > 0: store only output channels < co_limit (weights padded to Co); needs splitk == 1
+  float* pool_part = nullptr;             // != nullptr: [ceil(M / 32)][2][Co] partial column sums of the stored output (heads.hip: fc_pooled)
+  int pool_hw = 0;                        //   rows per image (>= 32); forces splitk = 1
   int plan_n_img = 0;                     // > 0: the automatic plan is the one of this many images (a call on part of a batch
                                           // then splits K exactly as the whole-batch call: same bits)
 };
@@ -229,6 +231,9 @@ hipError_t head_launch(const float* x, int x_cs, int x_coff, int n_img, int H, i
 hipError_t pool_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, int maxpool, float* pooled,
                        hipStream_t st);
 hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, const float* fb, int ncls, float* out, hipStream_t st);
+// FC of a head whose average pool was folded into the producing conv: part = [ceil(n_img * hw / 32)][2][C] (ConvDesc.pool_part)
+hipError_t fc_pooled_launch(const float* part, int hw, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
+                            hipStream_t st);
 hipError_t vec_add_launch(const float* a, const float* b, float* o, int n, hipStream_t st);
 hipError_t score_fusion_launch(const float* const* scores, const float* weights, int n, int videos, int crops, int classes,
                                float* fused, int* pred, hipStream_t st);
