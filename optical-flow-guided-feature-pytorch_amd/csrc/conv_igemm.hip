@@ -37,6 +37,8 @@ struct ConvArgs {
   int flags, M;
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
+  int batch;           // gridDim.y (1: a single problem)
+  long long x_bs, w_bs, y_bs;   // batched launch (gridDim.y problems of the same shape): element strides between problems
   float* pool_part;    // != nullptr: per 32-row slab and output channel, the sums of the stored values over the slab's rows of its
   int pool_hw;         // first / second image (pool_hw rows per image, >= 32): [slab][2][Co] -- the average pool of a head folded in
   float* partial;      // [splitk][M][Co] when splitk > 1
@@ -79,6 +81,7 @@ template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 // (the 128x128 tile compiled to 131 and ran one block per CU)
 __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr bool F32 = !(PREC & 1), LEAN = PREC >= 2;      // PREC 3: the bf16x3 core with the same buffer-addressed loader
+  if (gridDim.y > 1) { p.x += blockIdx.y * p.x_bs; p.w += blockIdx.y * p.w_bs; p.y += blockIdx.y * p.y_bs; }   // batched GEMMs (winograd.hip)
   constexpr bool DMA = PREC == 4;                          // fp32 core, tiles DMA'd into swizzled 128-byte LDS rows
   constexpr int DST = kDmaStages;                          // DMA: LDS stages (tiles run DST - 1 ahead of the MFMAs)
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -1186,7 +1189,7 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   }
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;
-  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(!(PREC & 1) ? 256 : 512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk, a.batch), dim3(!(PREC & 1) ? 256 : 512), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.splitk == 1) return e;
   size_t n4 = (size_t)a.M * (a.Co / 4);
@@ -1302,6 +1305,11 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   if (narrow) sk = 1;
   a.co_limit = narrow ? d.co_limit : d.Co;
   a.pool_part = d.pool_part; a.pool_hw = d.pool_hw;
+  a.batch = d.batch > 1 ? d.batch : 1; a.x_bs = d.x_bstride; a.w_bs = d.w_bstride; a.y_bs = d.y_bstride;
+  if (a.batch > 1) {
+    if (d.KH != 1 || d.KW != 1 || d.res || d.pool_part || cfg == 6 || cfg == 7 || cfg == 10 || a.batch > 65535) { *why = "conv2d: batched launches are plain 1x1 GEMMs on a generic tile"; return hipErrorInvalidValue; }
+    sk = 1;
+  }
   if (d.pool_part) {
     if (d.pool_hw < 32 || cfg == 6 || cfg == 7 || cfg == 10) { *why = "conv2d: pooled partial sums need >= 32 rows per image and a generic tile"; return hipErrorInvalidValue; }
     sk = 1;                               // the sums are taken in the epilogue of an unsplit conv

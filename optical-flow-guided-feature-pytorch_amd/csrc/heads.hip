@@ -213,7 +213,8 @@ hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, con
 // plus a per-image VALU GEMV on a (images, 13) grid.
 typedef float fcx4 __attribute__((ext_vector_type(4)));
 constexpr int kFcWaves = 8;       // K is split over the block's waves: C / 8 channels each, in batches of four 16-channel steps
-__global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* __restrict__ part, int hw, int n_img, int C,
+// tiles != 0: part = [n_img * 4][C], one row per 4x4 output tile of the Winograd path (winograd.hip): an image = 4 rows
+__global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* __restrict__ part, int hw, int tiles, int n_img, int C,
                                                                   const float* __restrict__ fw, const float* __restrict__ fb, int ncls,
                                                                   float* __restrict__ out) {
   __shared__ fcx4 red[kFcWaves][2][64];
@@ -223,31 +224,31 @@ __global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* _
   // the image's rows [img * hw, img * hw + hw) touch slabs s_lo .. s_lo + 2 at most (hw >= 32); a slab the image does not
   // reach is read with weight 0 from the image's last slab (no branch: every load of a batch goes out before the first use)
   const int r0 = img * hw, s_lo = r0 >> 5, s_hi = (r0 + hw - 1) >> 5;
-  const float* ps[3];
-  float pw[3];
+  const float* ps[4];
+  float pw[4];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < 4; ++j) {
     const int sl = min(s_lo + j, s_hi);
     const int slot = (sl * 32) / hw == img ? 0 : 1;          // is this image the slab's first or its second?
-    ps[j] = part + ((size_t)sl * 2 + slot) * C + 4 * kq;
-    pw[j] = s_lo + j <= s_hi ? 1.f : 0.f;
+    ps[j] = tiles ? part + ((size_t)img * 4 + j) * C + 4 * kq : part + ((size_t)sl * 2 + slot) * C + 4 * kq;
+    pw[j] = tiles || s_lo + j <= s_hi ? 1.f : 0.f;
   }
   const int kbeg = wave * (C / kFcWaves), kend = kbeg + C / kFcWaves;
   const float* w0 = fw + (size_t)min(cls0 + li, ncls - 1) * C + 4 * kq;
   const float* w1 = fw + (size_t)min(cls0 + 16 + li, ncls - 1) * C + 4 * kq;
   fcx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int kb = kbeg; kb < kend; kb += 64) {
-    fcx4 xr[4][3], a0[4], a1[4];
+    fcx4 xr[4][4], a0[4], a1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) xr[u][j] = *reinterpret_cast<const fcx4*>(ps[j] + kb + 16 * u);
+      for (int j = 0; j < 4; ++j) xr[u][j] = *reinterpret_cast<const fcx4*>(ps[j] + kb + 16 * u);
       a0[u] = *reinterpret_cast<const fcx4*>(w0 + kb + 16 * u);
       a1[u] = *reinterpret_cast<const fcx4*>(w1 + kb + 16 * u);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const fcx4 x = (xr[u][0] * pw[0] + xr[u][1] * pw[1]) + xr[u][2] * pw[2];
+      const fcx4 x = ((xr[u][0] * pw[0] + xr[u][1] * pw[1]) + xr[u][2] * pw[2]) + xr[u][3] * pw[3];
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].x, x.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].x, x.x, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].y, x.y, acc0, 0, 0, 0);
@@ -274,10 +275,10 @@ __global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* _
     }
   }
 }
-hipError_t fc_pooled_launch(const float* part, int hw, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
+hipError_t fc_pooled_launch(const float* part, int hw, int tiles, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
                             hipStream_t st) {
   if (C % (64 * kFcWaves) || hw < 32 || n_img <= 0 || ncls <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fc_pooled_kernel, dim3((n_img + 15) / 16, (ncls + 31) / 32), dim3(64 * kFcWaves), 0, st, part, hw, n_img, C, fw, fb, ncls, out);
+  hipLaunchKernelGGL(fc_pooled_kernel, dim3((n_img + 15) / 16, (ncls + 31) / 32), dim3(64 * kFcWaves), 0, st, part, hw, tiles, n_img, C, fw, fb, ncls, out);
   return hipGetLastError();
 }
 

@@ -149,6 +149,9 @@ struct offk_handle {
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
+  bool winograd = true;          // fp32: Winograd F(4x4, 3x3) for the three 3x3 / stride 1 convs on 7x7 maps (winograd.hip); OFFK_WINOGRAD=0: direct
+  float* wino_u[3] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7
+  bool wino_dirty = true;
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
   bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
   size_t train_ws_bytes = 0;
@@ -281,6 +284,13 @@ void plan_workspace(offk_handle* h) {
   // average pools of the 7- and 14-heads folded into the producing conv: per 32-row slab, two partial column sums
   add_region(h, "poolpart_7", ((P * 49 + 31) / 32) * 2 * 1024);
   add_region(h, "poolpart_14", ((P * 49 + 31) / 32) * 2 * 512);
+  // Winograd path of the 3x3 convs at 7x7 (fp32): transformed input [36][4 P][Ci <= 832], GEMM output [36][4 P][Co <= 512],
+  // per-tile sums of sum_14b for the 14-head
+  if (h->cfg.precision == OFFK_PRECISION_FP32) {
+    add_region(h, "wino_v", (size_t)36 * 4 * P * 832);
+    add_region(h, "wino_m", (size_t)36 * 4 * P * 512);
+    add_region(h, "poolpart_14t", (size_t)4 * P * 512);
+  }
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64],
   // 3x3 @7: [P*49, 256]); a conv whose plan needs more falls back to fewer slices
   h->splitk_floats = 8 * P * 196 * 64;
@@ -595,6 +605,14 @@ int finalize_merged(offk_handle* h, hipStream_t st) {
   h->merged_dirty = false;
   return OFFK_OK;
 }
+int finalize_wino(offk_handle* h, hipStream_t st) {
+  if (!h->winograd || !h->wino_dirty) return OFFK_OK;
+  const ConvId wid[3] = {C3_14B, C_T7, C2_7};
+  for (int k = 0; k < 3; ++k)
+    HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, h->wino_u[k], st));
+  h->wino_dirty = false;
+  return OFFK_OK;
+}
 #define TRY(expr)            \
   do {                       \
     int rc__ = (expr);       \
@@ -707,6 +725,12 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_PW_DMA"); h->pw_dma = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
+  if (h->winograd) {
+    const ConvId wid[3] = {C3_14B, C_T7, C2_7};
+    for (int k = 0; k < 3; ++k)
+      if (dev_alloc(h, &h->wino_u[k], (size_t)36 * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+  }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
   if (!(side_env && *side_env == '0') &&
@@ -829,6 +853,7 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
     }
   }
   if (s.kind == SK_CONV_W || s.kind == SK_CONV_B) h->merged_dirty = true;
+  if (s.kind == SK_CONV_W) h->wino_dirty = true;
   if (s.kind == SK_GEN_W || s.kind == SK_DOWN_W) h->pw_dirty = true;
   return rc;
 }
@@ -1056,6 +1081,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   const int RI = OFFK_CONV_RELU_IN_, RP = OFFK_CONV_RELU_PRE_, RO = OFFK_CONV_RELU_POST_;
 
   TRY(finalize_merged(h, st));
+  TRY(finalize_wino(h, st));
   const bool forked = h->side != nullptr && h->profiling != 2;   // per-launch trace: everything in line on the caller's stream
   hipStream_t side = forked ? h->side : st;
   const bool cons = h->cfg.consensus == OFFK_CONSENSUS_AVG;
@@ -1083,6 +1109,32 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   auto fusion = [&](hipStream_t s, int i0, int n, bool side_heads, hipEvent_t after_first, hipEvent_t* sev) -> int {
     auto at = [&](float* base, int Hh, int cs) { return base + (size_t)i0 * Hh * Hh * cs; };
     hipStream_t hs = side_heads ? side : s;
+    // 3x3 / stride 1 conv on 7x7 maps as Winograd F(4x4, 3x3): input transform, 36 batched GEMMs on the 1x1 kernel, output
+    // transform with the conv's epilogue (winograd.hip).  Every buffer is indexed from this call's first pair.
+    const bool wino = h->winograd && h->cfg.precision == OFFK_PRECISION_FP32;
+    auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
+                         int y_coff, float* pool_t) -> int {
+      const ConvSpec& c = kConvs[id];
+      const int T = 4 * n;
+      float* V = region(h, ws, "wino_v") + (size_t)36 * 4 * i0 * 832;       // (a split call gets its own part of the regions)
+      float* M = region(h, ws, "wino_m") + (size_t)36 * 4 * i0 * 512;
+      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()); if (rc != OFFK_OK) return rc; }
+      HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, V, s));
+      ConvDesc d;
+      d.x = V; d.x_cs = c.Ci; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = c.Ci;
+      d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+      d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+      d.y = M; d.y_cs = c.Co; d.y_coff = 0;
+      d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+      d.batch = 36; d.x_bstride = (long long)T * c.Ci; d.w_bstride = (long long)c.Co * c.Ci; d.y_bstride = (long long)T * c.Co;
+      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 36 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
+      const char* why = nullptr;
+      hipError_t e = conv2d_launch(d, s, &why);
+      if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
+      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()); if (rc != OFFK_OK) return rc; }
+      HIP_TRY(h, wino_output_launch(M, n, c.Co, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
+      return OFFK_OK;
+    };
     // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
     // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
     float *xt_ = at(xt, 14, 128), *t1_ = at(t1, 14, 64), *sa_ = at(sa, 14, 256), *sb_ = at(sb, 14, 256);
@@ -1146,27 +1198,40 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     const bool fold = h->fold_pool && i0 == 0 && n == P && generic(h->conv_cfg[C3_14B]) && generic(h->merged_cfg[2]);
     float* pp14 = region(h, ws, "poolpart_14");
     float* pp7 = region(h, ws, "poolpart_7");
-    h->cur_pool_part = fold ? pp14 : nullptr;
-    { int rc_ = conv(h, s, C3_14B, n, 7, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320);   // :777-780 -> cat at :832
+    float* pp14t = wino ? region(h, ws, "poolpart_14t") + (size_t)4 * i0 * 512 : nullptr;
+    const bool fold14t = wino && h->fold_pool;
+    if (wino) {
+      TRY(wino_conv(C3_14B, 0, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320, fold14t ? pp14t : nullptr));   // :777-780 -> cat at :832
+    } else {
+      h->cur_pool_part = fold ? pp14 : nullptr;
+      int rc_ = conv(h, s, C3_14B, n, 7, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320);   // :777-780 -> cat at :832
       h->cur_pool_part = nullptr;
-      if (rc_ != OFFK_OK) return rc_; }
+      if (rc_ != OFFK_OK) return rc_;
+    }
     if (sev) HIP_TRY(h, hipEventRecord(sev[4], s));
     {              // 14-head (:789-793) beside fusion@7: only reads sum_14b
       if (side_heads && forked) {
         HIP_TRY(h, hipEventRecord(h->ev_fork[1], s));
         HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[1], 0));
       }
-      if (fold) {
+      if (fold14t) {
         TRY(trace_mark(h, hs, "head_14 (fc on folded pool)"));
-        HIP_TRY(h, fc_pooled_launch(pp14, 49, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, hs));
+        HIP_TRY(h, fc_pooled_launch(pp14t, 49, 1, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14 + (size_t)i0 * ncls, hs));
+      } else if (fold && !wino) {
+        TRY(trace_mark(h, hs, "head_14 (fc on folded pool)"));
+        HIP_TRY(h, fc_pooled_launch(pp14, 49, 0, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, hs));
       } else {
         TRY(run_head(hs, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14, i0, n));
       }
     }
     // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
     float *xv_ = at(xv, 7, 512), *v1_ = at(v1, 7, 256), *s7_ = at(s7, 7, 1024);
+    if (wino) TRY(wino_conv(C_T7, 1, View{F7_, 832, 0}, nullptr, 0, 0, RP, xv_, 512, 256, nullptr));  // :833-834 x2
+    else
     TRY(conv(h, s, C_T7, n, 7, View{F7_, 832, 0}, nullptr, 0, 0, RP, xv_, 512, 256));              // :833-834 x2
     TRY(conv(h, s, C1_7, n, 7, View{xv_, 512, 256}, nullptr, 0, 0, RP, v1_, 256, 0));              // :835-836
+    if (wino) TRY(wino_conv(C2_7, 2, View{v1_, 256, 0}, nullptr, 0, 0, RP, xv_, 512, 0, nullptr));     // :837-838 v2
+    else
     TRY(conv(h, s, C2_7, n, 7, View{v1_, 256, 0}, nullptr, 0, 0, RP, xv_, 512, 0));                // :837-838 v2
     h->cur_pool_part = fold ? pp7 : nullptr;
     { int rc_ = conv_merged(h, s, 2, n, 7, View{xv_, 512, 0}, 0, s7_, 1024, 0);                     // :839-841 (no ReLU)
@@ -1176,7 +1241,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     // ---- 7-head on the chain's stream (:843-847)
     if (fold) {
       TRY(trace_mark(h, s, "head_7 (fc on folded pool)"));
-      HIP_TRY(h, fc_pooled_launch(pp7, 49, n, 1024, h->fc_w[0], h->fc_b[0], ncls, l7, s));
+      HIP_TRY(h, fc_pooled_launch(pp7, 49, 0, n, 1024, h->fc_w[0], h->fc_b[0], ncls, l7, s));
     } else {
       TRY(run_head(s, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7, i0, n));
     }

@@ -29,6 +29,8 @@ struct ConvDesc {
   size_t partial_floats = 0;
   int precision = 0;                      // 0 = exact fp32 MFMA, 1 = bf16x3
   int co_limit = 0;                       // > 0: store only output channels < co_limit (weights padded to Co); needs splitk == 1
+  int batch = 1;                          // > 1: that many independent problems of this shape in one launch (1x1 only): problem b
+  long long x_bstride = 0, w_bstride = 0, y_bstride = 0;   //   reads x + b * x_bstride, w + b * w_bstride, writes y + b * y_bstride (floats)
   float* pool_part = nullptr;             // != nullptr: [ceil(M / 32)][2][Co] partial column sums of the stored output (heads.hip: fc_pooled)
   int pool_hw = 0;                        //   rows per image (>= 32); forces splitk = 1
   int plan_n_img = 0;                     // > 0: the automatic plan is the one of this many images (a call on part of a batch
@@ -57,6 +59,12 @@ struct ChainArgs {
 #endif
 };
 hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
+
+// ---- K4w: Winograd F(4x4, 3x3) for the 3x3 / stride 1 convs on 7x7 maps (winograd.hip) ----
+hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, float* U, hipStream_t st);           // U [36][Co][Ci]
+hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, float* V, hipStream_t st);   // V [36][4 n_img][Ci]
+hipError_t wino_output_launch(const float* M, int n_img, int Co, const float* bias, const float* res, int res_cs, int res_coff,
+                              int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st);
 
 // ---- K1 ------------------------------------------------------------------------
 struct PwSite {
@@ -232,7 +240,8 @@ hipError_t pool_launch(const float* x, int x_cs, int x_coff, int n_img, int H, i
                        hipStream_t st);
 hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, const float* fb, int ncls, float* out, hipStream_t st);
 // FC of a head whose average pool was folded into the producing conv: part = [ceil(n_img * hw / 32)][2][C] (ConvDesc.pool_part)
-hipError_t fc_pooled_launch(const float* part, int hw, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
+// or, tiles != 0, [n_img * 4][C] (the Winograd output transform's per-tile sums)
+hipError_t fc_pooled_launch(const float* part, int hw, int tiles, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
                             hipStream_t st);
 hipError_t vec_add_launch(const float* a, const float* b, float* o, int n, hipStream_t st);
 hipError_t score_fusion_launch(const float* const* scores, const float* weights, int n, int videos, int crops, int classes,

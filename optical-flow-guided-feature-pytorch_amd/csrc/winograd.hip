@@ -1,0 +1,186 @@
+// K4w: Winograd F(4x4, 3x3) for the 3x3 / stride 1 / pad 1 fusion convolutions on 7x7 maps (fp32 arithmetic throughout).
+//
+// Stands for motion_conv3_trans_14b (128 -> 512, RGB_OFF.py:777-780), motion_conv_trans (832 -> 256, :833-834) and
+// motion_conv2_trans (256 -> 256, :837-838): 0.95 ms of the 5.2 ms forward as direct implicit GEMMs at 74-80 % of the fp32
+// matrix peak.  Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 4x4 output tile (Lavin & Gray, arXiv:1509.09308): 36 multiplies
+// per 16 outputs instead of 144.  A 7x7 map is 2 x 2 tiles (8x8 outputs computed, 49 kept: 64 / 49 of the work), so the
+// contraction shrinks 3.06x; it becomes 36 independent GEMMs [tiles][Ci] x [Ci][Co] that run on the existing 1x1
+// implicit-GEMM kernel with a batch index (conv_igemm.hip), between two bandwidth-bound transform kernels:
+//   wino_input_kernel    V[p][tile][ci] = (B^T d B)[p]   one thread per (tile, channel), lanes along channels
+//   (36 batched GEMMs)   M[p][tile][co] = sum_ci V[p][tile][ci] * U[p][co][ci]
+//   wino_output_kernel   Y = A^T M A + bias, the conv epilogue (ReLU / residual / ReLU), the valid 7x7 pixels stored; optional
+//                        per-tile column sums of the stored values (the 14-head's average pool, heads.hip fc_pooled)
+//   wino_weight_kernel   U[p][co][ci] = (G g G^T)[p], once per weight change
+// Same arithmetic type as the reference (fp32), different summation: the transforms' constants (up to 8 and 1/24) cost a few
+// ulps -- measured against the oracle in tests/test_gpu_parity.py (stage tensors and logits), well inside the 1e-3 budget;
+// OFFK_WINOGRAD=0 at offk_create keeps the direct kernels.
+#include "offk_common.h"
+#include "offk_internal.h"
+
+namespace offk {
+
+namespace {
+// 1-D input transform B^T (6 -> 6)
+__device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
+  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// 1-D output transform A^T (6 -> 4)
+__device__ __forceinline__ void at4(const float (&m)[6], float (&s)[4]) {
+  const float a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
+  s[0] = m[0] + a + c;
+  s[1] = b + 2.f * e;
+  s[2] = a + 4.f * c;
+  s[3] = b + 8.f * e + m[5];
+}
+// 1-D weight transform G (3 -> 6)
+__device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
+  u[0] = g[0] * 0.25f;
+  u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
+  u[2] = (-g[0] + g[1] - g[2]) * (1.f / 6.f);
+  u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+  u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+  u[5] = g[2];
+}
+}  // namespace
+
+// x: channels-last [n_img * 49][x_cs], Ci channels at x_coff.  V: [36][n_img * 4][Ci].
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_cs, int x_coff, int n_img, int Ci,
+                                                         float* __restrict__ V) {
+  const int T = n_img * 4;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)T * Ci) return;
+  const int tile = (int)(gid / Ci), c = (int)(gid - (long long)tile * Ci);
+  const int img = tile >> 2, oy = (tile & 2) * 2, ox = (tile & 1) * 4;      // output tile origin (0 / 4)
+  const float* xi = x + (size_t)img * 49 * x_cs + x_coff + c;
+  float t[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {            // column j of the 6x6 input tile: rows oy - 1 .. oy + 4, column ox - 1 + j
+    const int col = ox - 1 + j;
+    float d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = oy - 1 + i;
+      const bool ok = (unsigned)row < 7u && (unsigned)col < 7u;
+      d[i] = ok ? xi[(size_t)(row * 7 + col) * x_cs] : 0.f;
+    }
+    float tc[6];
+    bt6(d, tc);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = tc[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float v[6];
+    bt6(t[i], v);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * T + tile) * Ci + c] = v[j];
+  }
+}
+
+struct WinoOutArgs {
+  const float* M;                // [36][T][Co]
+  const float* bias;             // [Co]
+  const float* res; int res_cs, res_coff;
+  float* y; int y_cs, y_coff;
+  float* pool_part;              // != nullptr: [T][Co] sums of the stored values of each tile (4 tiles = one image)
+  int n_img, Co, flags;
+};
+__global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
+  const int T = a.n_img * 4;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)T * a.Co) return;
+  const int tile = (int)(gid / a.Co), c = (int)(gid - (long long)tile * a.Co);
+  const int img = tile >> 2, oy = (tile & 2) * 2, ox = (tile & 1) * 4;
+  const float* mp = a.M + (size_t)tile * a.Co + c;
+  const size_t pstride = (size_t)T * a.Co;
+  float s[4][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float m[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = mp[(size_t)(i * 6 + j) * pstride];
+    float sc[4];
+    at4(m, sc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i][j] = sc[i];
+  }
+  const float bv = a.bias ? a.bias[c] : 0.f;
+  const bool relu_pre = a.flags & OFFK_CONV_RELU_PRE_, relu_post = a.flags & OFFK_CONV_RELU_POST_;
+  float psum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float yv[4];
+    at4(s[i], yv);
+    const int row = oy + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = ox + j;
+      if (row < 7 && col < 7) {
+        const size_t pix = (size_t)img * 49 + row * 7 + col;
+        float v = yv[j] + bv;
+        if (relu_pre) v = fmaxf(v, 0.f);
+        if (a.res) v += a.res[pix * a.res_cs + a.res_coff + c];
+        if (relu_post) v = fmaxf(v, 0.f);
+        a.y[pix * a.y_cs + a.y_coff + c] = v;
+        psum += v;
+      }
+    }
+  }
+  if (a.pool_part) a.pool_part[(size_t)tile * a.Co + c] = psum;
+}
+
+// w: the library's packed 3x3 weight [Co][Ci / 32][9][32] (pack_conv_weight_launch).  U: [36][Co][Ci].
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Co, int Ci, float* __restrict__ U) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)Co * Ci) return;
+  const int co = (int)(gid / Ci), ci = (int)(gid - (long long)co * Ci);
+  const float* wp = w + ((size_t)(co * (Ci / 32) + ci / 32) * 9) * 32 + (ci & 31);
+  float t[6][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {            // column j of g (3x3, tap = kh * 3 + kw)
+    float g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = wp[(size_t)(i * 3 + j) * 32];
+    float u[6];
+    g6(g, u);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = u[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float u[6];
+    g6(t[i], u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) U[((size_t)(i * 6 + j) * Co + co) * Ci + ci] = u[j];
+  }
+}
+
+hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, float* U, hipStream_t st) {
+  const long long n = (long long)Co * Ci;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_packed, Co, Ci, U);
+  return hipGetLastError();
+}
+
+hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, float* V, hipStream_t st) {
+  const long long n = (long long)n_img * 4 * Ci;
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x_cs, x_coff, n_img, Ci, V);
+  return hipGetLastError();
+}
+
+hipError_t wino_output_launch(const float* M, int n_img, int Co, const float* bias, const float* res, int res_cs, int res_coff,
+                              int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st) {
+  WinoOutArgs a;
+  a.M = M; a.bias = bias; a.res = res; a.res_cs = res_cs; a.res_coff = res_coff;
+  a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.pool_part = pool_part;
+  a.n_img = n_img; a.Co = Co; a.flags = flags;
+  const long long n = (long long)n_img * 4 * Co;
+  hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace offk
