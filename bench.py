@@ -210,6 +210,22 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             nbytes = spec.algorithmic_bytes_sobel_tdiff(B, L)
             rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6,
                        frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
+        elif "[winograd:" in name:
+            # Winograd F(4x4, 3x3) of a 3x3 conv on 7x7 maps: the 36 batched GEMMs against the fp32-MFMA peak with THEIR
+            # FLOPs (2 * 36 * 4P * Ci * Co = 1 / 3.06 of the direct conv's), the two transforms against HBM with the bytes
+            # they move (V written / M read; the 7x7 map side is a fraction of that)
+            key = name.split(" ")[0]
+            co, ci = next((c, i) for k_, c, i, _k, _s, _p in spec.FUSION_CONVS if k_ == key)
+            T = 4 * P
+            if "GEMMs" in name:
+                fl = 2.0 * 36 * T * ci * co
+                rec.update(bound="mfma", flops=fl, direct_conv_flops=work[key], achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
+                small_ms += avg
+                small_fl += work[key] if key != "motion_conv_trans" else 0.0
+            else:
+                nbytes = (36 * T * ci + P * 49 * ci) * 4 if "input" in name else (36 * T * co + P * 49 * co) * 4
+                rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
+                small_ms += avg
         elif name in work or name.split(" ")[0] in work or name.startswith("chain_"):
             fl = work.get(name, work.get(name.split(" ")[0]))
             if fl is None:      # a fused bottleneck chain: "chain_<tag> = convA + convB + ..." (offk_api.hip)

@@ -150,8 +150,9 @@ struct offk_handle {
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
   bool winograd = true;          // fp32: Winograd F(4x4, 3x3) for the three 3x3 / stride 1 convs on 7x7 maps (winograd.hip); OFFK_WINOGRAD=0: direct
-  float* wino_u[3] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7
+  float* wino_u[5] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B
   bool wino_dirty = true;
+  int wino_cfg = 3;              // tile of the 36 batched GEMMs (OFFK_WINO_CFG at offk_create: tools)
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
   bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
   size_t train_ws_bytes = 0;
@@ -607,8 +608,8 @@ int finalize_merged(offk_handle* h, hipStream_t st) {
 }
 int finalize_wino(offk_handle* h, hipStream_t st) {
   if (!h->winograd || !h->wino_dirty) return OFFK_OK;
-  const ConvId wid[3] = {C3_14B, C_T7, C2_7};
-  for (int k = 0; k < 3; ++k)
+  const ConvId wid[5] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B};
+  for (int k = 0; k < 5; ++k)
     HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, h->wino_u[k], st));
   h->wino_dirty = false;
   return OFFK_OK;
@@ -726,9 +727,10 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
+  { const char* e = getenv("OFFK_WINO_CFG"); if (e && *e >= '0' && *e <= '5') h->wino_cfg = *e - '0'; }
   if (h->winograd) {
-    const ConvId wid[3] = {C3_14B, C_T7, C2_7};
-    for (int k = 0; k < 3; ++k)
+    const ConvId wid[5] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B};
+    for (int k = 0; k < 5; ++k)
       if (dev_alloc(h, &h->wino_u[k], (size_t)36 * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
   }
   plan_workspace(h);
@@ -1125,7 +1127,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
       d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
       d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
       d.y = M; d.y_cs = c.Co; d.y_coff = 0;
-      d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+      d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
       d.batch = 36; d.x_bstride = (long long)T * c.Ci; d.w_bstride = (long long)c.Co * c.Ci; d.y_bstride = (long long)T * c.Co;
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 36 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
       const char* why = nullptr;
@@ -1188,9 +1190,13 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);
     TRY(conv(h, s, C_T14, n, 14, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128));          // :762-763 x1
     TRY(conv(h, s, C1_14A, n, 7, View{xu_, 256, 128}, nullptr, 0, 0, RP, u1_, 128, 0));            // :764-765
+    if (wino) TRY(wino_conv(C2_14A, 3, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0, nullptr));   // :766-767 u2
+    else
     TRY(conv(h, s, C2_14A, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :766-767 u2
     TRY(conv_merged(h, s, 1, n, 7, View{xu_, 256, 0}, RO, s14_, 512, 0));                           // :768-771
     TRY(conv(h, s, C1_14B, n, 7, View{s14_, 512, 0}, nullptr, 0, 0, RP, u1_, 128, 0));             // :773-774
+    if (wino) TRY(wino_conv(C2_14B, 4, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0, nullptr));   // :775-776
+    else
     TRY(conv(h, s, C2_14B, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :775-776
     // (fold: the conv's epilogue also leaves per-slab column sums of sum_14b: the 14-head's average pool.  Slabs are 32
     // rows of the whole pair range, so only a call on all pairs -- i0 = 0 -- can fold)
