@@ -1201,11 +1201,11 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     // (fold: the conv's epilogue also leaves per-slab column sums of sum_14b: the 14-head's average pool.  Slabs are 32
     // rows of the whole pair range, so only a call on all pairs -- i0 = 0 -- can fold)
     auto generic = [](int cfg) { return cfg != 6 && cfg != 7 && cfg != 10; };      // the LDS-patch kernels have no pooling epilogue
-    const bool fold = h->fold_pool && i0 == 0 && n == P && generic(h->conv_cfg[C3_14B]) && generic(h->merged_cfg[2]);
+    const bool fold = h->fold_pool && !h->pipe && i0 == 0 && n == P && generic(h->conv_cfg[C3_14B]) && generic(h->merged_cfg[2]);
     float* pp14 = region(h, ws, "poolpart_14");
     float* pp7 = region(h, ws, "poolpart_7");
     float* pp14t = wino ? region(h, ws, "poolpart_14t") + (size_t)4 * i0 * 512 : nullptr;
-    const bool fold14t = wino && h->fold_pool;
+    const bool fold14t = wino && h->fold_pool && !h->pipe;
     if (wino) {
       TRY(wino_conv(C3_14B, 0, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320, fold14t ? pp14t : nullptr));   // :777-780 -> cat at :832
     } else {

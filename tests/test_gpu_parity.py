@@ -513,10 +513,15 @@ def test_two_half_pipeline_bit_identical(rt, variant, B, L, prec, monkeypatch):
     logits are the single-stream bits, with an odd pair count (17 * 6 = 102 -> 51 + 51; 16 * 7 = 112) and with the
     consensus of the Flow variant behind the join."""
     feats = [dev(f) for f in synth.make_features(B, L, 3)]
+    # the single-stream handle with the heads' average pools NOT folded into the conv epilogues: the folded sums are taken
+    # per 32-row slab of the call's pair range, so a call on half the pairs groups them differently (same values to ~1e-7,
+    # not the same bits); the pipelined handle never folds
+    monkeypatch.setenv("OFFK_FOLD_POOL", "0")
     h0, _ = make_handle(rt, B, L, variant, precision=prec)
     monkeypatch.setenv("OFFK_PIPELINE", "1")
     h1, _ = make_handle(rt, B, L, variant, precision=prec)
     monkeypatch.delenv("OFFK_PIPELINE")
+    monkeypatch.delenv("OFFK_FOLD_POOL")
     ref = h0.forward(feats)
     for _ in range(2):                       # twice: the second run re-uses the events / the split-K slabs
         got = h1.forward(feats)
