@@ -175,6 +175,18 @@ def launch_work(P):
     return d
 
 
+WINOGRAD_CONVS = ("motion_conv2_trans_14a", "motion_conv2_trans_14b", "motion_conv3_trans_14b", "motion_conv_trans",
+                  "motion_conv2_trans")
+
+
+def winograd_saved_flops(P):
+    """Direct-conv FLOPs minus the FLOPs of the 36 batched GEMMs (4 tiles of 4x4 outputs per 7x7 map) for the convs the fp32
+    path runs as Winograd F(4x4, 3x3) (csrc/winograd.hip)."""
+    w = launch_work(P)
+    dims = {k: (co, ci) for k, co, ci, _k, _s, _p in spec.FUSION_CONVS}
+    return sum(w[k] - 2.0 * 36 * 4 * P * dims[k][1] * dims[k][0] for k in WINOGRAD_CONVS)
+
+
 def roofline_in_path(h, arr, out, B, L, precision, steps):
     """What bounds the kernels the DEFAULT forward launches: a third loop with the library's per-launch trace on (one HIP
     event in front of every launch group, heads folded back onto the main stream).  HBM-bound: the S-blocks of K2 (the only
@@ -551,8 +563,14 @@ def main():
                      "peak_tflops": MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0,
                      "whole_forward_frac_of_peak": (unit_f + fus_f) * B / (ms_step * 1e-3) / 1e12 /
                                                    (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0) / world,
-                     "note": "algorithmic fp32 FLOPs / summed stage time; whole_forward_frac_of_peak = the same FLOPs / the "
-                             "wall-clock ms_per_step / peak; bf16x3 peak = dense bf16 MFMA peak / 3 products"},
+                     "executed_flops_per_step": ((unit_f + fus_f) * B - winograd_saved_flops(B * (L - 1))
+                                                 if args.precision == "fp32" and os.environ.get("OFFK_WINOGRAD", "1") != "0"
+                                                 else (unit_f + fus_f) * B),
+                     "note": "algorithmic (direct-convolution) fp32 FLOPs / summed stage time; whole_forward_frac_of_peak = "
+                             "the same FLOPs / the wall-clock ms_per_step / peak; bf16x3 peak = dense bf16 MFMA peak / 3 "
+                             "products.  In fp32 the five 3x3 / stride 1 convs on 7x7 maps run as Winograd F(4x4, 3x3) "
+                             "(fp32 arithmetic, 1 / 3.06 of their multiplies): executed_flops_per_step is what the matrix "
+                             "pipe is asked to do, so the algorithmic fraction can exceed any kernel's MFMA-busy share"},
         }
         if in_path is not None:
             res["roofline_in_path"] = in_path
