@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 5
+#define OFFK_ABI_VERSION 6
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -226,6 +226,26 @@ int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int
 /* Override the plan offk_forward uses for one fusion conv (key = its state_dict name without
  * ".weight", e.g. "motion_conv_trans_28"); tile_cfg < 0 / splitk < 1 restore the automatic choice. */
 int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int splitk);
+
+/* K4c. One bottleneck chain of fusion@28 at 14x14 in one launch (exact fp32): t1 = relu(c1(in(x))), t2 = relu(c2_3x3(t1)),
+ * y = relu(c3([t2 | x]) + b3 + res) -- RGB_OFF.py:658-667 (28a: K3 = 128, c3's weight = [motion_conv3_trans_28a |
+ * motion_conv_branch_28a] over [t2 | pre-ReLU x], relu_in = 1, no residual) and :670-676 / :679-685 (28b / 28c: Cin = 256, K3 = 64,
+ * res = x).  x: [n_img * 196][x_cstride] channels-last, Cin in {64, 256} channels at x_coff; w1 [64][Cin], w2 the packed
+ * 3x3 weight [64][2][9][32] (offk_pack_conv_weight), w3 [256][K3]; res / y: 256 channels at res_coff / y_coff.  t1 and t2
+ * never leave the chip (csrc/chain_fused.hip). */
+int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Cin, int relu_in,
+                            const float* w1, const float* b1, const float* w2_packed, const float* b2,
+                            const float* w3, const float* b3, int K3,
+                            const float* res, int res_cstride, int res_coff, float* y, int y_cstride, int y_coff);
+/* K4w. 3x3 / stride 1 / pad 1 convolution on 7x7 maps as Winograd F(4x4, 3x3), fp32 arithmetic (csrc/winograd.hip): the five such
+ * convs of fusion@14 / @7 (RGB_OFF.py:766-767, 775-780, 833-834, 837-838).  Same epilogue and views as offk_conv2d (flags without
+ * OFFK_CONV_RELU_IN); w_packed as for offk_conv2d.  scratch: 36 * (Co * Ci + 4 * n_img * (Ci + Co)) floats of device memory
+ * (transformed weights, transformed input, GEMM output).  pool_part != NULL: [4 * n_img][Co] sums of the stored values of each
+ * 4x4 output tile (an image = 4 consecutive rows): the average pool of a head that follows. */
+int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
+                          const float* w_packed, const float* bias, int Co,
+                          const float* res, int res_cstride, int res_coff, int flags,
+                          float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part);
 
 /* K5. Replaces motion_pool_trans_28 / global_pool / squeeze / fc_action_motion*
  * (RGB_OFF.py:782-787, 789-793, 843-847): optional MaxPool(3,2,ceil) then global

@@ -1450,6 +1450,54 @@ int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int 
   return OFFK_OK;
 }
 
+int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Cin, int relu_in,
+                            const float* w1, const float* b1, const float* w2_packed, const float* b2, const float* w3,
+                            const float* b3, int K3, const float* res, int res_cstride, int res_coff, float* y, int y_cstride,
+                            int y_coff) {
+  if (!x || !w1 || !b1 || !w2_packed || !b2 || !w3 || !b3 || !y || n_img < 1)
+    return fail(nullptr, OFFK_ERR_INVALID, "offk_bottleneck_chain14: bad argument");
+  ChainArgs a;
+  a.x = x; a.x_cs = x_cstride; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in ? 1 : 0;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2_packed; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.K3 = K3;
+  a.res = res; a.res_cs = res_cstride; a.res_coff = res_coff; a.y = y; a.y_cs = y_cstride; a.y_coff = y_coff;
+  a.n_img = n_img; a.relu_out = 1;
+  const unsigned long long xb = ((unsigned long long)n_img * 196 * x_cstride - x_coff) * 4ull;
+  a.x_bytes = xb < 0x7fffffffull ? (unsigned)xb : 0u;
+  const char* why = nullptr;
+  hipError_t e = chain14_launch(a, static_cast<hipStream_t>(stream), &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  return OFFK_OK;
+}
+
+int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, const float* w_packed,
+                          const float* bias, int Co, const float* res, int res_cstride, int res_coff, int flags, float* y,
+                          int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part) {
+  if (!x || !w_packed || !y || !scratch || n_img < 1 || Ci < 32 || (Ci & 31) || Co < 64 || (Co & 63) || (flags & OFFK_CONV_RELU_IN_))
+    return fail(nullptr, OFFK_ERR_INVALID, "offk_winograd_conv3x3: bad argument (Ci % 32 == 0, Co % 64 == 0, no RELU_IN)");
+  const size_t T = 4 * (size_t)n_img, need = 36 * ((size_t)Co * Ci + T * ((size_t)Ci + Co));
+  if (scratch_floats < need) return fail(nullptr, OFFK_ERR_INVALID, "offk_winograd_conv3x3: scratch too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* U = scratch;
+  float* V = U + (size_t)36 * Co * Ci;
+  float* M = V + 36 * T * Ci;
+  hipError_t e = wino_weight_launch(w_packed, Co, Ci, U, st);
+  if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, V, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_winograd_conv3x3");
+  ConvDesc d;
+  d.x = V; d.x_cs = Ci; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = Ci;
+  d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+  d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+  d.y = M; d.y_cs = Co; d.y_coff = 0;
+  d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+  d.batch = 36; d.x_bstride = (long long)T * Ci; d.w_bstride = (long long)Co * Ci; d.y_bstride = (long long)T * Co;
+  const char* why = nullptr;
+  e = conv2d_launch(d, st, &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  e = wino_output_launch(M, n_img, Co, bias, res, res_cstride, res_coff, flags, y, y_cstride, y_coff, pool_part, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_winograd_conv3x3");
+  return OFFK_OK;
+}
+
 int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int splitk) {
   if (!h || !conv_key) return fail(h, OFFK_ERR_INVALID, "offk_set_conv_plan: null argument");
   for (int c = 0; c < kNumConvs; ++c)

@@ -325,6 +325,50 @@ def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=No
     return y
 
 
+def pack_conv_weight(w_oihw):
+    """[Co][Ci][KH][KW] -> the library's K order [Co][Ci/32][KH*KW][32] (device tensor)."""
+    lib = _lib.load()
+    Co, Ci, KH, KW = w_oihw.shape
+    wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=w_oihw.device)
+    _lib.check(lib.offk_pack_conv_weight(_stream(w_oihw.device), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
+    return wp
+
+
+def bottleneck_chain14(x, w1, b1, w2_oihw, b2, w3, b3, res=None, relu_in=False, x_coff=0, y=None, y_coff=0):
+    """One 1x1 -> 3x3 -> 1x1 (+ residual) chain of fusion@28 in one launch (offk_bottleneck_chain14).  x: [n, 14, 14, Cs] fp32 CUDA,
+    the chain reads channels [x_coff, x_coff + Cin); w1 [64, Cin], w2_oihw [64, 64, 3, 3], w3 [256, K3] (K3 = 128: contracts
+    [t2 | x]); res: [n, 14, 14, 256] or None.  Returns y [n, 14, 14, 256] (or writes channels [y_coff, y_coff + 256) of y)."""
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    assert H == 14 and W == 14
+    Cin, K3 = w1.shape[1], w3.shape[1]
+    if y is None:
+        y = torch.empty(n, 14, 14, 256, dtype=torch.float32, device=x.device)
+    w2p = pack_conv_weight(w2_oihw)
+    _lib.check(lib.offk_bottleneck_chain14(_stream(x.device), _ptr(x), cs, x_coff, n, Cin, int(relu_in), _ptr(w1.contiguous()),
+                                           _ptr(b1), _ptr(w2p), _ptr(b2), _ptr(w3.contiguous()), _ptr(b3), K3, _ptr(res),
+                                           res.shape[-1] if res is not None else 0, 0, _ptr(y), y.shape[-1], y_coff))
+    return y
+
+
+def winograd_conv3x3(x, w_oihw, bias, res=None, flags=0, x_coff=0, y=None, y_coff=0, want_pool=False):
+    """3x3 / stride 1 / pad 1 conv on 7x7 maps as Winograd F(4x4, 3x3) (offk_winograd_conv3x3).  x: [n, 7, 7, Cs]; returns y
+    [n, 7, 7, Co] (and, want_pool, the per-tile sums [4 n, Co])."""
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    assert H == 7 and W == 7
+    Co, Ci = w_oihw.shape[:2]
+    if y is None:
+        y = torch.empty(n, 7, 7, Co, dtype=torch.float32, device=x.device)
+    nfl = 36 * (Co * Ci + 4 * n * (Ci + Co))
+    scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    pool = torch.empty(4 * n, Co, dtype=torch.float32, device=x.device) if want_pool else None
+    _lib.check(lib.offk_winograd_conv3x3(_stream(x.device), _ptr(x), cs, x_coff, n, Ci, _ptr(pack_conv_weight(w_oihw)), _ptr(bias), Co,
+                                         _ptr(res), res.shape[-1] if res is not None else 0, 0, flags, _ptr(y), y.shape[-1], y_coff,
+                                         _ptr(scratch), nfl, _ptr(pool)))
+    return (y, pool) if want_pool else y
+
+
 def head(x, fc_w, fc_b, maxpool, x_coff=0, c=None):
     lib = _lib.load()
     n, H, W, cs = x.shape

@@ -791,3 +791,73 @@ def test_two_stream_b64_vs_oracle(rt, prec):
     top2 = ref.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()       # ties within the tolerance may flip
     assert torch.equal(pred.cpu().long()[clear], ref.argmax(dim=1)[clear])
+
+
+# ---- round 3: fused bottleneck chain (chain_fused.hip) and Winograd conv (winograd.hip) through their C-ABI entry points ----
+@pytest.mark.parametrize("case", ["28a_merged", "28b_residual", "28c_into_slice"])
+@pytest.mark.parametrize("n", [1, 5, 11])
+def test_bottleneck_chain14_vs_torch(rt, case, n):
+    """offk_bottleneck_chain14 against torch CPU fp32 convolutions (RGB_OFF.py:658-667 / :670-685): the merged form of block 28a
+    (pre-ReLU input, branch conv folded into c3's K), the residual form, and output into a channel slice of a wider buffer.
+    Odd image counts exercise the grid rounding (blocks of 8 images x 2 halves)."""
+    g = torch.Generator().manual_seed(100 + n)
+    merged = case == "28a_merged"
+    Cin = 64 if merged else 256
+    x = torch.randn(n, 14, 14, Cin + (64 if merged else 0), generator=g) * (1.0 if merged else 0.5)
+    if not merged:
+        x = x.clamp_min(0)                               # sa / sb are post-ReLU
+    x_coff = 64 if merged else 0
+    k1 = 1.0 / Cin ** 0.5
+    w1 = (torch.rand(64, Cin, generator=g) * 2 - 1) * k1
+    b1 = (torch.rand(64, generator=g) * 2 - 1) * k1
+    w2 = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    b2 = (torch.rand(64, generator=g) * 2 - 1) / 24.0
+    K3 = 128 if merged else 64
+    w3 = (torch.rand(256, K3, generator=g) * 2 - 1) / K3 ** 0.5
+    b3 = (torch.rand(256, generator=g) * 2 - 1) / 8.0
+    xin = x[..., x_coff:x_coff + Cin].permute(0, 3, 1, 2).contiguous()
+    t1 = F.relu(F.conv2d(F.relu(xin) if merged else xin, w1[:, :, None, None], b1))
+    t2 = F.relu(F.conv2d(t1, w2, b2, padding=1))
+    cat = torch.cat([t2, xin], 1) if merged else t2
+    want = F.conv2d(cat, w3[:, :, None, None], b3)
+    if not merged:
+        want = want + xin
+    want = F.relu(want).permute(0, 2, 3, 1)
+    res = None if merged else dev(x)
+    if case == "28c_into_slice":
+        ybuf = torch.full((n, 14, 14, 352), -3.0, device="cuda")
+        rt.bottleneck_chain14(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), res=res, y=ybuf, y_coff=64)
+        got = ybuf[..., 64:320]
+        assert torch.all(ybuf[..., :64] == -3.0) and torch.all(ybuf[..., 320:] == -3.0)
+    else:
+        got = rt.bottleneck_chain14(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), res=res, relu_in=merged, x_coff=x_coff)
+    torch.cuda.synchronize()
+    assert rel_err(got, want) < RTOL
+
+
+@pytest.mark.parametrize("ci,co", [(128, 128), (128, 512), (256, 256), (832, 256)])
+@pytest.mark.parametrize("n", [1, 7])
+def test_winograd_conv3x3_vs_torch(rt, ci, co, n):
+    """offk_winograd_conv3x3 (F(4x4, 3x3), fp32) against torch CPU fp32 F.conv2d for the five shapes it serves (RGB_OFF.py:766-767,
+    775-780, 833-834, 837-838), with the epilogue of motion_conv3_trans_14b (ReLU, residual, ReLU) and the per-tile sums the 14-head
+    takes its average pool from.  Tolerance as for the direct kernels; the measured error is printed."""
+    g = torch.Generator().manual_seed(7 * ci + co + n)
+    x = torch.randn(n, 7, 7, ci + 32, generator=g).clamp_min(0)
+    w = (torch.rand(co, ci, 3, 3, generator=g) * 2 - 1) / (9 * ci) ** 0.5
+    b = (torch.rand(co, generator=g) * 2 - 1) / (9 * ci) ** 0.5
+    res = torch.randn(n, 7, 7, co, generator=g).clamp_min(0) * 0.3
+    xin = x[..., 32:].permute(0, 3, 1, 2).contiguous()
+    want = F.relu(F.relu(F.conv2d(xin, w, b, padding=1)) + res.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    got, pool = rt.winograd_conv3x3(dev(x), dev(w), dev(b), res=dev(res), flags=2 | 4, x_coff=32, want_pool=True)
+    torch.cuda.synchronize()
+    err = rel_err(got, want)
+    print("winograd %d -> %d n=%d: max error / max |ref| = %.2e" % (ci, co, n, err))
+    assert err < RTOL
+    pooled = pool.view(n, 4, co).sum(1) / 49.0
+    assert rel_err(pooled, want.mean(dim=(1, 2))) < RTOL
+    # plain conv (no epilogue), output into a channel slice
+    ybuf = torch.full((n, 7, 7, co + 64), -3.0, device="cuda")
+    rt.winograd_conv3x3(dev(x), dev(w), None, x_coff=32, y=ybuf, y_coff=64)
+    torch.cuda.synchronize()
+    assert rel_err(ybuf[..., 64:], F.conv2d(xin, w, None, padding=1).permute(0, 2, 3, 1)) < RTOL
+    assert torch.all(ybuf[..., :64] == -3.0)
