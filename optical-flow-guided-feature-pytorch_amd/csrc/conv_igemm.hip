@@ -185,21 +185,33 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
   };
-  auto dma_tile = [&](int kt, const int stage) {
+  // dma_prep: scalar offsets of tile kt; dma_piece(i): row visit i of the tile (A rows first) into LDS stage `stage`.  In the K
+  // loop the pieces go out one behind each k-group's MFMAs (round 3: issued in a bunch at the top of the step they cost the
+  // wave 60-180 cycles each with nothing of its own multiplying behind them; pw_tdiff.hip measured the same)
+  int dm_soff_a = 0, dm_soff_b = 0, dm_kh = 0, dm_kw = 0;
+  auto dma_prep = [&](int kt) {
     if constexpr (DMA) {
       int chunk = kt / TAPS, tap = kt - chunk * TAPS, c0 = chunk * BK;
-      int kh = tap / KW, kw = tap - kh * KW;
-      const int soff_a = ((kh * p.W + kw) * p.x_cs + c0) * 4, soff_b = kt * BK * 4;     // scalar
-      const unsigned la = lds_base + stage * (BM * 128), lb = lds_base + DST * (BM * 128) + stage * (BN * 128);
-#pragma unroll
-      for (int r = 0; r < NRA; ++r) {
-        int voff = rowoff[r];
-        if constexpr (TAPS > 1) voff |= (int)(((inv[r] << (31 - kh)) | (inv[r] << (15 - kw))) & 0x80000000u);
-        dma16(xdesc, la + r * 32 * 128, voff, soff_a);
-      }
-#pragma unroll
-      for (int r = 0; r < NRB; ++r) dma16(wdesc, lb + r * 32 * 128, woff[r], soff_b);
+      dm_kh = tap / KW; dm_kw = tap - dm_kh * KW;
+      dm_soff_a = ((dm_kh * p.W + dm_kw) * p.x_cs + c0) * 4; dm_soff_b = kt * BK * 4;     // scalar
     }
+  };
+  auto dma_piece = [&](const int i, const int stage) {
+    if constexpr (DMA) {
+      const unsigned la = lds_base + stage * (BM * 128), lb = lds_base + DST * (BM * 128) + stage * (BN * 128);
+      if (i < NRA) {
+        int voff = rowoff[i];
+        if constexpr (TAPS > 1) voff |= (int)(((inv[i] << (31 - dm_kh)) | (inv[i] << (15 - dm_kw))) & 0x80000000u);
+        dma16(xdesc, la + i * 32 * 128, voff, dm_soff_a);
+      } else {
+        dma16(wdesc, lb + (i - NRA) * 32 * 128, woff[i - NRA], dm_soff_b);
+      }
+    }
+  };
+  auto dma_tile = [&](int kt, const int stage) {
+    dma_prep(kt);
+#pragma unroll
+    for (int i = 0; i < NRA + NRB; ++i) dma_piece(i, stage);
   };
   constexpr int NRG = NRA * VA + NRB * VB;
   // prefetch registers: A rows then B rows (one array per set: separate A / B arrays end up in scratch).
@@ -348,7 +360,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       boff[g] = DST * (BM * 128) + (wn * (32 * TN) + r32) * 128 + ((sw ^ (2 * g)) << 4);
     }
     const char* const lds_c8 = reinterpret_cast<const char*>(smem);
-    auto mma = [&](const int st) {
+    auto mma = [&](const int st, const int st_next) {
       float4 a[2][TM], b[2][TN];
       auto rd = [&](const int g, float4 (&aa)[TM], float4 (&bb)[TN]) {
 #pragma unroll
@@ -371,6 +383,11 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
             acc.acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][tm].w, b[g & 1][tn].w, acc.acc[tm][tn], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if (st_next >= 0) {
+#pragma unroll
+          for (int i = g; i < NRA + NRB; i += BK / 8) dma_piece(i, st_next);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     };
     // s_waitcnt vmcnt(n): all but this thread's newest n DMA loads have landed (gfx9 encoding: vmcnt = bits 3:0 and 15:14)
@@ -383,9 +400,14 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     // one K-tile: the load unit fills the stage every wave left at the last barrier with tile kt + DST - 1 while the MFMAs
     // read stage st (a literal: the loop is unrolled by DST)
     auto step = [&](int kt, const int st) {
-      dma_tile(min(kt + DST - 1, kt_end - 1), (st + DST - 1) % DST);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(st);
+      if constexpr (DST == 2) {
+        dma_prep(min(kt + 1, kt_end - 1));
+        mma(st, st ^ 1);                       // the pieces of tile kt + 1 go out between the k-groups
+      } else {
+        dma_tile(min(kt + DST - 1, kt_end - 1), (st + DST - 1) % DST);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(st, -1);
+      }
       __builtin_amdgcn_s_waitcnt(kWaitTile);   // tile kt + 1 has landed
       __syncthreads();
     };
