@@ -176,15 +176,21 @@ def launch_work(P):
 
 
 WINOGRAD_CONVS = ("motion_conv2_trans_14a", "motion_conv2_trans_14b", "motion_conv3_trans_14b", "motion_conv_trans",
-                  "motion_conv2_trans")
+                  "motion_conv2_trans", "motion_conv_trans_14")
+
+
+def winograd_gemm_flops(P, key):
+    """FLOPs of the 36 batched GEMMs [4P tiles][K] x [K][Co] of a conv on the Winograd path: K = Ci for a 3x3 / stride 1
+    conv on 7x7 maps, 4 Ci for the polyphase form of the 5x5 / stride 2 conv (four 7x7 phase images concatenated along K)."""
+    co, ci, k = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
+    return 2.0 * 36 * 4 * P * (4 * ci if k == 5 else ci) * co
 
 
 def winograd_saved_flops(P):
     """Direct-conv FLOPs minus the FLOPs of the 36 batched GEMMs (4 tiles of 4x4 outputs per 7x7 map) for the convs the fp32
     path runs as Winograd F(4x4, 3x3) (csrc/winograd.hip)."""
     w = launch_work(P)
-    dims = {k: (co, ci) for k, co, ci, _k, _s, _p in spec.FUSION_CONVS}
-    return sum(w[k] - 2.0 * 36 * 4 * P * dims[k][1] * dims[k][0] for k in WINOGRAD_CONVS)
+    return sum(w[k] - winograd_gemm_flops(P, k) for k in WINOGRAD_CONVS)
 
 
 def roofline_in_path(h, arr, out, B, L, precision, steps):
@@ -227,17 +233,19 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             # FLOPs (2 * 36 * 4P * Ci * Co = 1 / 3.06 of the direct conv's), the two transforms against HBM with the bytes
             # they move (V written / M read; the 7x7 map side is a fraction of that)
             key = name.split(" ")[0]
-            co, ci = next((c, i) for k_, c, i, _k, _s, _p in spec.FUSION_CONVS if k_ == key)
+            co, ci, ksz = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
             T = 4 * P
+            if ksz == 5:
+                ci *= 4           # polyphase: four 7x7 phase images along K
             if "GEMMs" in name:
-                fl = 2.0 * 36 * T * ci * co
+                fl = winograd_gemm_flops(P, key)
                 rec.update(bound="mfma", flops=fl, direct_conv_flops=work[key], achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
-                small_ms += avg
-                small_fl += work[key] if key != "motion_conv_trans" else 0.0
+                small_ms += avg if key not in big else 0.0
+                small_fl += work[key] if key not in big else 0.0
             else:
                 nbytes = (36 * T * ci + P * 49 * ci) * 4 if "input" in name else (36 * T * co + P * 49 * co) * 4
                 rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
-                small_ms += avg
+                small_ms += avg if key not in big else 0.0
         elif name in work or name.split(" ")[0] in work or name.startswith("chain_"):
             fl = work.get(name, work.get(name.split(" ")[0]))
             if fl is None:      # a fused bottleneck chain: "chain_<tag> = convA + convB + ..." (offk_api.hip)

@@ -150,8 +150,9 @@ struct offk_handle {
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
   bool winograd = true;          // fp32: Winograd F(4x4, 3x3) for the three 3x3 / stride 1 convs on 7x7 maps (winograd.hip); OFFK_WINOGRAD=0: direct
-  float* wino_u[5] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B
+  float* wino_u[6] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; [36][Co][4 Ci] of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
+  bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
   int wino_cfg = 3;              // tile of the 36 batched GEMMs (OFFK_WINO_CFG at offk_create: tools)
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
   bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
@@ -288,7 +289,7 @@ void plan_workspace(offk_handle* h) {
   // Winograd path of the 3x3 convs at 7x7 (fp32): transformed input [36][4 P][Ci <= 832], GEMM output [36][4 P][Co <= 512],
   // per-tile sums of sum_14b for the 14-head
   if (h->cfg.precision == OFFK_PRECISION_FP32) {
-    add_region(h, "wino_v", (size_t)36 * 4 * P * 832);
+    add_region(h, "wino_v", (size_t)36 * 4 * P * 4224);      // widest: the polyphase 5x5 / 2 conv, K = 4 x 1056
     add_region(h, "wino_m", (size_t)36 * 4 * P * 512);
     add_region(h, "poolpart_14t", (size_t)4 * P * 512);
   }
@@ -608,9 +609,9 @@ int finalize_merged(offk_handle* h, hipStream_t st) {
 }
 int finalize_wino(offk_handle* h, hipStream_t st) {
   if (!h->winograd || !h->wino_dirty) return OFFK_OK;
-  const ConvId wid[5] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B};
-  for (int k = 0; k < 5; ++k)
-    HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, h->wino_u[k], st));
+  const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
+  for (int k = 0; k < 6; ++k)
+    HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, k == 5 ? 4 : 1, h->wino_u[k], st));
   h->wino_dirty = false;
   return OFFK_OK;
 }
@@ -727,11 +728,12 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
+  { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINO_CFG"); if (e && *e >= '0' && *e <= '5') h->wino_cfg = *e - '0'; }
   if (h->winograd) {
-    const ConvId wid[5] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B};
-    for (int k = 0; k < 5; ++k)
-      if (dev_alloc(h, &h->wino_u[k], (size_t)36 * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
+    for (int k = 0; k < 6; ++k)
+      if (dev_alloc(h, &h->wino_u[k], (size_t)36 * kConvs[wid[k]].Co * kConvs[wid[k]].Ci * (k == 5 ? 4 : 1)) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
   }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
@@ -1117,18 +1119,18 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
                          int y_coff, float* pool_t) -> int {
       const ConvSpec& c = kConvs[id];
-      const int T = 4 * n;
-      float* V = region(h, ws, "wino_v") + (size_t)36 * 4 * i0 * 832;       // (a split call gets its own part of the regions)
+      const int T = 4 * n, phases = c.K == 5 ? 4 : 1, Kg = phases * c.Ci;
+      float* V = region(h, ws, "wino_v") + (size_t)36 * 4 * i0 * 4224;      // (a split call gets its own part of the regions)
       float* M = region(h, ws, "wino_m") + (size_t)36 * 4 * i0 * 512;
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()); if (rc != OFFK_OK) return rc; }
-      HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, V, s));
+      HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, phases, V, s));
       ConvDesc d;
-      d.x = V; d.x_cs = c.Ci; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = c.Ci;
+      d.x = V; d.x_cs = Kg; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = Kg;
       d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
       d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
       d.y = M; d.y_cs = c.Co; d.y_coff = 0;
       d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
-      d.batch = 36; d.x_bstride = (long long)T * c.Ci; d.w_bstride = (long long)c.Co * c.Ci; d.y_bstride = (long long)T * c.Co;
+      d.batch = 36; d.x_bstride = (long long)T * Kg; d.w_bstride = (long long)c.Co * Kg; d.y_bstride = (long long)T * c.Co;
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 36 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
       const char* why = nullptr;
       hipError_t e = conv2d_launch(d, s, &why);
@@ -1188,6 +1190,8 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     }
     // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
     float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);
+    if (wino && h->wino_5x5) TRY(wino_conv(C_T14, 5, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128, nullptr));   // :762-763 x1 (polyphase)
+    else
     TRY(conv(h, s, C_T14, n, 14, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128));          // :762-763 x1
     TRY(conv(h, s, C1_14A, n, 7, View{xu_, 256, 128}, nullptr, 0, 0, RP, u1_, 128, 0));            // :764-765
     if (wino) TRY(wino_conv(C2_14A, 3, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0, nullptr));   // :766-767 u2
@@ -1480,8 +1484,8 @@ int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_cof
   float* U = scratch;
   float* V = U + (size_t)36 * Co * Ci;
   float* M = V + 36 * T * Ci;
-  hipError_t e = wino_weight_launch(w_packed, Co, Ci, U, st);
-  if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, V, st);
+  hipError_t e = wino_weight_launch(w_packed, Co, Ci, 1, U, st);
+  if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, 1, V, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, "offk_winograd_conv3x3");
   ConvDesc d;
   d.x = V; d.x_cs = Ci; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = Ci;

@@ -61,8 +61,9 @@ struct ChainArgs {
 hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
 
 // ---- K4w: Winograd F(4x4, 3x3) for the 3x3 / stride 1 convs on 7x7 maps (winograd.hip) ----
-hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, float* U, hipStream_t st);           // U [36][Co][Ci]
-hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, float* V, hipStream_t st);   // V [36][4 n_img][Ci]
+// phases = 1: 3x3 / stride 1 on 7x7 maps; phases = 4: the polyphase form of a 5x5 / stride 2 / pad 2 conv on 14x14 maps (K = 4 Ci)
+hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, int phases, float* U, hipStream_t st);           // U [36][Co][phases Ci]
+hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, int phases, float* V, hipStream_t st);   // V [36][4 n_img][phases Ci]
 hipError_t wino_output_launch(const float* M, int n_img, int Co, const float* bias, const float* res, int res_cs, int res_coff,
                               int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st);
 

@@ -11,6 +11,9 @@
 //   wino_output_kernel   Y = A^T M A + bias, the conv epilogue (ReLU / residual / ReLU), the valid 7x7 pixels stored; optional
 //                        per-tile column sums of the stored values (the 14-head's average pool, heads.hip fc_pooled)
 //   wino_weight_kernel   U[p][co][ci] = (G g G^T)[p], once per weight change
+// The 5x5 / stride 2 / pad 2 conv motion_conv_trans_14 (1056 -> 128 on 14x14, :762-763; 0.96 ms direct) goes the same way in
+// polyphase form: its four phase images are 7x7, its four phase kernels at most 3x3, and their contractions concatenate along
+// K (4 x 1056 = 4224), so the 36 GEMMs, the output transform and this file's transform matrices serve it unchanged (NPH = 4).
 // Same arithmetic type as the reference (fp32), different summation: the transforms' constants (up to 8 and 1/24) cost a few
 // ulps -- measured against the oracle in tests/test_gpu_parity.py (stage tensors and logits), well inside the 1e-3 budget;
 // OFFK_WINOGRAD=0 at offk_create keeps the direct kernels.
@@ -48,25 +51,32 @@ __device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
 }
 }  // namespace
 
-// x: channels-last [n_img * 49][x_cs], Ci channels at x_coff.  V: [36][n_img * 4][Ci].
+// x: channels-last [n_img * W * W][x_cs], Ci channels at x_coff.  V: [36][n_img * 4][NPH * Ci].
+// NPH = 1: W = 7, the 3x3 / stride 1 conv.  NPH = 4: W = 14, the polyphase form of a 5x5 / stride 2 / pad 2 conv
+//   y[o] = sum_{a, b in {0, 1}} conv3x3_pad1(X_ab, G_ab)[o],   X_ab[i][j] = x[2i + a][2j + b] (7x7),   G_ab[u][v] = w[2u + a][2v + b]
+// (taps with 2u + a > 4 are zero): four 3x3 / stride 1 convs on 7x7 phase images whose contraction is concatenated along K
+// (phase ph = 2a + b occupies K range [ph * Ci, ph * Ci + Ci)), so the SAME 36 GEMMs and the same output transform serve it.
+template <int NPH>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_cs, int x_coff, int n_img, int Ci,
                                                          float* __restrict__ V) {
-  const int T = n_img * 4;
+  constexpr int W = NPH == 1 ? 7 : 14, STEP = NPH == 1 ? 1 : 2;
+  const int T = n_img * 4, K = NPH * Ci;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)T * Ci) return;
-  const int tile = (int)(gid / Ci), c = (int)(gid - (long long)tile * Ci);
+  if (gid >= (long long)T * K) return;
+  const int tile = (int)(gid / K), kk = (int)(gid - (long long)tile * K);
+  const int ph = kk / Ci, c = kk - ph * Ci, pa = ph >> 1, pb = ph & 1;
   const int img = tile >> 2, oy = (tile & 2) * 2, ox = (tile & 1) * 4;      // output tile origin (0 / 4)
-  const float* xi = x + (size_t)img * 49 * x_cs + x_coff + c;
+  const float* xi = x + (size_t)img * W * W * x_cs + x_coff + c;
   float t[6][6];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {            // column j of the 6x6 input tile: rows oy - 1 .. oy + 4, column ox - 1 + j
+  for (int j = 0; j < 6; ++j) {            // column j of the 6x6 input tile: rows oy - 1 .. oy + 4, column ox - 1 + j (of the phase image)
     const int col = ox - 1 + j;
     float d[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int row = oy - 1 + i;
       const bool ok = (unsigned)row < 7u && (unsigned)col < 7u;
-      d[i] = ok ? xi[(size_t)(row * 7 + col) * x_cs] : 0.f;
+      d[i] = ok ? xi[(size_t)((STEP * row + pa) * W + STEP * col + pb) * x_cs] : 0.f;
     }
     float tc[6];
     bt6(d, tc);
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     float v[6];
     bt6(t[i], v);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * T + tile) * Ci + c] = v[j];
+    for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * T + tile) * K + kk] = v[j];
   }
 }
 
@@ -134,18 +144,26 @@ __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
   if (a.pool_part) a.pool_part[(size_t)tile * a.Co + c] = psum;
 }
 
-// w: the library's packed 3x3 weight [Co][Ci / 32][9][32] (pack_conv_weight_launch).  U: [36][Co][Ci].
+// w: the library's packed weight [Co][Ci / 32][KS * KS][32] (pack_conv_weight_launch).  U: [36][Co][NPH * Ci].
+// NPH = 1: KS = 3.  NPH = 4: KS = 5, phase (a, b) takes the taps (2u + a, 2v + b), u, v in 0..2 (zero beyond tap 4).
+template <int NPH>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int Co, int Ci, float* __restrict__ U) {
+  constexpr int KS = NPH == 1 ? 3 : 5, STEP = NPH == 1 ? 1 : 2;
+  const int K = NPH * Ci;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)Co * Ci) return;
-  const int co = (int)(gid / Ci), ci = (int)(gid - (long long)co * Ci);
-  const float* wp = w + ((size_t)(co * (Ci / 32) + ci / 32) * 9) * 32 + (ci & 31);
+  if (gid >= (long long)Co * K) return;
+  const int co = (int)(gid / K), kk = (int)(gid - (long long)co * K);
+  const int ph = kk / Ci, ci = kk - ph * Ci, pa = ph >> 1, pb = ph & 1;
+  const float* wp = w + ((size_t)(co * (Ci / 32) + ci / 32) * (KS * KS)) * 32 + (ci & 31);
   float t[6][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {            // column j of g (3x3, tap = kh * 3 + kw)
+  for (int j = 0; j < 3; ++j) {            // column j of the phase's 3x3 kernel
     float g[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g[i] = wp[(size_t)(i * 3 + j) * 32];
+    for (int i = 0; i < 3; ++i) {
+      const int kh = STEP * i + pa, kw = STEP * j + pb;
+      g[i] = kh < KS && kw < KS ? wp[(size_t)(kh * KS + kw) * 32] : 0.f;
+    }
     float u[6];
     g6(g, u);
 #pragma unroll
@@ -156,19 +174,21 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     float u[6];
     g6(t[i], u);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) U[((size_t)(i * 6 + j) * Co + co) * Ci + ci] = u[j];
+    for (int j = 0; j < 6; ++j) U[((size_t)(i * 6 + j) * Co + co) * K + kk] = u[j];
   }
 }
 
-hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, float* U, hipStream_t st) {
-  const long long n = (long long)Co * Ci;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_packed, Co, Ci, U);
+hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, int phases, float* U, hipStream_t st) {
+  const long long n = (long long)Co * Ci * phases;
+  if (phases == 4) hipLaunchKernelGGL(wino_weight_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_packed, Co, Ci, U);
+  else hipLaunchKernelGGL(wino_weight_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w_packed, Co, Ci, U);
   return hipGetLastError();
 }
 
-hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, float* V, hipStream_t st) {
-  const long long n = (long long)n_img * 4 * Ci;
-  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x_cs, x_coff, n_img, Ci, V);
+hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, int phases, float* V, hipStream_t st) {
+  const long long n = (long long)n_img * 4 * Ci * phases;
+  if (phases == 4) hipLaunchKernelGGL(wino_input_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x_cs, x_coff, n_img, Ci, V);
+  else hipLaunchKernelGGL(wino_input_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, x_cs, x_coff, n_img, Ci, V);
   return hipGetLastError();
 }
 
