@@ -247,6 +247,14 @@ int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_cof
                           const float* res, int res_cstride, int res_coff, int flags,
                           float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part);
 
+/* The 5x5 / stride 2 / pad 2 conv on 14x14 maps (motion_conv_trans_14, RGB_OFF.py:762-763) through the same machinery in polyphase
+ * form: four 7x7 phase images x 3x3 phase kernels concatenated along K.  x: [n_img * 196][x_cstride]; y: [n_img * 49][y_cstride];
+ * w_packed: the packed 5x5 weight [Co][Ci/32][25][32]; scratch: 36 * (4 * Co * Ci + 4 * n_img * (4 * Ci + Co)) floats. */
+int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
+                            const float* w_packed, const float* bias, int Co,
+                            const float* res, int res_cstride, int res_coff, int flags,
+                            float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats);
+
 /* K5. Replaces motion_pool_trans_28 / global_pool / squeeze / fc_action_motion*
  * (RGB_OFF.py:782-787, 789-793, 843-847): optional MaxPool(3,2,ceil) then global
  * average over the (pooled) map then Linear.  x: channel slice [x_coff, x_coff+C) of a

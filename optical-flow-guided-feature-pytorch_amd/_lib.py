@@ -63,6 +63,7 @@ SIGNATURES = {
                             _I, _I, _F, _c.c_size_t, _I]),
     "offk_bottleneck_chain14": (_I, [_P, _F, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _F, _I, _I, _F, _I, _I]),
     "offk_winograd_conv3x3": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t, _F]),
+    "offk_winograd_conv5x5s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_split_bf16x3": (_I, [_P, _F, _c.c_size_t, _F]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),

@@ -1473,33 +1473,50 @@ int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_c
   return OFFK_OK;
 }
 
-int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, const float* w_packed,
-                          const float* bias, int Co, const float* res, int res_cstride, int res_coff, int flags, float* y,
-                          int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part) {
+namespace {
+// shared body of the two Winograd entry points: phases = 1 (3x3 / stride 1 on 7x7) or 4 (polyphase 5x5 / stride 2 on 14x14)
+int winograd_entry(const char* who, void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, int phases,
+                   const float* w_packed, const float* bias, int Co, const float* res, int res_cstride, int res_coff, int flags,
+                   float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part) {
   if (!x || !w_packed || !y || !scratch || n_img < 1 || Ci < 32 || (Ci & 31) || Co < 64 || (Co & 63) || (flags & OFFK_CONV_RELU_IN_))
-    return fail(nullptr, OFFK_ERR_INVALID, "offk_winograd_conv3x3: bad argument (Ci % 32 == 0, Co % 64 == 0, no RELU_IN)");
-  const size_t T = 4 * (size_t)n_img, need = 36 * ((size_t)Co * Ci + T * ((size_t)Ci + Co));
-  if (scratch_floats < need) return fail(nullptr, OFFK_ERR_INVALID, "offk_winograd_conv3x3: scratch too small");
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument (Ci % 32 == 0, Co % 64 == 0, no RELU_IN)");
+  const size_t T = 4 * (size_t)n_img, K = (size_t)phases * Ci, need = 36 * ((size_t)Co * K + T * (K + Co));
+  if (scratch_floats < need) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* U = scratch;
-  float* V = U + (size_t)36 * Co * Ci;
-  float* M = V + 36 * T * Ci;
-  hipError_t e = wino_weight_launch(w_packed, Co, Ci, 1, U, st);
-  if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, 1, V, st);
-  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_winograd_conv3x3");
+  float* V = U + (size_t)36 * Co * K;
+  float* M = V + 36 * T * K;
+  hipError_t e = wino_weight_launch(w_packed, Co, Ci, phases, U, st);
+  if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, phases, V, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
   ConvDesc d;
-  d.x = V; d.x_cs = Ci; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = Ci;
+  d.x = V; d.x_cs = (int)K; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = (int)K;
   d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
   d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
   d.y = M; d.y_cs = Co; d.y_coff = 0;
   d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
-  d.batch = 36; d.x_bstride = (long long)T * Ci; d.w_bstride = (long long)Co * Ci; d.y_bstride = (long long)T * Co;
+  d.batch = 36; d.x_bstride = (long long)T * K; d.w_bstride = (long long)Co * K; d.y_bstride = (long long)T * Co;
   const char* why = nullptr;
   e = conv2d_launch(d, st, &why);
   if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
   e = wino_output_launch(M, n_img, Co, bias, res, res_cstride, res_coff, flags, y, y_cstride, y_coff, pool_part, st);
-  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_winograd_conv3x3");
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
   return OFFK_OK;
+}
+}  // namespace
+
+int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, const float* w_packed,
+                          const float* bias, int Co, const float* res, int res_cstride, int res_coff, int flags, float* y,
+                          int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part) {
+  return winograd_entry("offk_winograd_conv3x3", stream, x, x_cstride, x_coff, n_img, Ci, 1, w_packed, bias, Co, res, res_cstride,
+                        res_coff, flags, y, y_cstride, y_coff, scratch, scratch_floats, pool_part);
+}
+
+int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, const float* w_packed,
+                            const float* bias, int Co, const float* res, int res_cstride, int res_coff, int flags, float* y,
+                            int y_cstride, int y_coff, float* scratch, size_t scratch_floats) {
+  return winograd_entry("offk_winograd_conv5x5s2", stream, x, x_cstride, x_coff, n_img, Ci, 4, w_packed, bias, Co, res, res_cstride,
+                        res_coff, flags, y, y_cstride, y_coff, scratch, scratch_floats, nullptr);
 }
 
 int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int splitk) {

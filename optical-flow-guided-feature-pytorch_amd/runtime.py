@@ -369,6 +369,22 @@ def winograd_conv3x3(x, w_oihw, bias, res=None, flags=0, x_coff=0, y=None, y_cof
     return (y, pool) if want_pool else y
 
 
+def winograd_conv5x5s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0):
+    """5x5 / stride 2 / pad 2 conv on 14x14 maps in polyphase Winograd form (offk_winograd_conv5x5s2).  x: [n, 14, 14, Cs]; returns
+    y [n, 7, 7, Co]."""
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    assert H == 14 and W == 14
+    Co, Ci = w_oihw.shape[:2]
+    if y is None:
+        y = torch.empty(n, 7, 7, Co, dtype=torch.float32, device=x.device)
+    nfl = 36 * (4 * Co * Ci + 4 * n * (4 * Ci + Co))
+    scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    _lib.check(lib.offk_winograd_conv5x5s2(_stream(x.device), _ptr(x), cs, x_coff, n, Ci, _ptr(pack_conv_weight(w_oihw)), _ptr(bias), Co,
+                                           None, 0, 0, flags, _ptr(y), y.shape[-1], y_coff, _ptr(scratch), nfl))
+    return y
+
+
 def head(x, fc_w, fc_b, maxpool, x_coff=0, c=None):
     lib = _lib.load()
     n, H, W, cs = x.shape

@@ -861,3 +861,23 @@ def test_winograd_conv3x3_vs_torch(rt, ci, co, n):
     torch.cuda.synchronize()
     assert rel_err(ybuf[..., 64:], F.conv2d(xin, w, None, padding=1).permute(0, 2, 3, 1)) < RTOL
     assert torch.all(ybuf[..., :64] == -3.0)
+
+
+@pytest.mark.parametrize("ci,co,n", [(64, 64, 1), (1056, 128, 3)])
+def test_winograd_conv5x5s2_vs_torch(rt, ci, co, n):
+    """offk_winograd_conv5x5s2 -- the polyphase form of motion_conv_trans_14 (RGB_OFF.py:762-763: 5x5, stride 2, pad 2, 14x14 ->
+    7x7): four 7x7 phase images x 3x3 phase kernels concatenated along K -- against torch CPU fp32 F.conv2d, with the ReLU of
+    :763 and output into a channel slice (the [u2 | x1] buffer)."""
+    g = torch.Generator().manual_seed(11 * ci + co)
+    x = torch.randn(n, 14, 14, ci + 32, generator=g).clamp_min(0)
+    w = (torch.rand(co, ci, 5, 5, generator=g) * 2 - 1) / (25 * ci) ** 0.5
+    b = (torch.rand(co, generator=g) * 2 - 1) / (25 * ci) ** 0.5
+    xin = x[..., 32:].permute(0, 3, 1, 2).contiguous()
+    want = F.relu(F.conv2d(xin, w, b, stride=2, padding=2)).permute(0, 2, 3, 1)
+    ybuf = torch.full((n, 7, 7, co + 96), -3.0, device="cuda")
+    rt.winograd_conv5x5s2(dev(x), dev(w), dev(b), flags=2, x_coff=32, y=ybuf, y_coff=96)
+    torch.cuda.synchronize()
+    err = rel_err(ybuf[..., 96:], want)
+    print("polyphase winograd 5x5/2 %d -> %d n=%d: max error / max |ref| = %.2e" % (ci, co, n, err))
+    assert err < RTOL
+    assert torch.all(ybuf[..., :96] == -3.0)
