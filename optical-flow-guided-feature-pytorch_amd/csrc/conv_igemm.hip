@@ -39,6 +39,10 @@ struct ConvArgs {
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   int batch;           // gridDim.y (1: a single problem)
   long long x_bs, w_bs, y_bs;   // batched launch (gridDim.y problems of the same shape): element strides between problems
+  // grouped batch (ngroups > 0; winograd.hip's polyphase form): gridDim.y = sum of g_batch; the problems of group g are dense
+  // 1x1 GEMMs [M][g_Ci] x [Co][g_Ci] -> [M][Co] packed one behind the other from x + g_x / w + g_w / y + g_y
+  int ngroups, g_batch[4], g_Ci[4];
+  long long g_x[4], g_w[4], g_y[4];
   float* pool_part;    // != nullptr: per 32-row slab and output channel, the sums of the stored values over the slab's rows of its
   int pool_hw;         // first / second image (pool_hw rows per image, >= 32): [slab][2][Co] -- the average pool of a head folded in
   float* partial;      // [splitk][M][Co] when splitk > 1
@@ -81,7 +85,17 @@ template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 // (the 128x128 tile compiled to 131 and ran one block per CU)
 __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr bool F32 = !(PREC & 1), LEAN = PREC >= 2;      // PREC 3: the bf16x3 core with the same buffer-addressed loader
-  if (gridDim.y > 1) { p.x += blockIdx.y * p.x_bs; p.w += blockIdx.y * p.w_bs; p.y += blockIdx.y * p.y_bs; }   // batched GEMMs (winograd.hip)
+  if (p.ngroups > 0) {          // grouped batch: this block's group and its problem inside the group (static indices: scalar code)
+    int b = blockIdx.y, ci = p.g_Ci[0], first = 0;
+    long long gx = p.g_x[0], gw = p.g_w[0], gy = p.g_y[0];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+      first += p.g_batch[g - 1];
+      if (g < p.ngroups && (int)blockIdx.y >= first) { b = blockIdx.y - first; ci = p.g_Ci[g]; gx = p.g_x[g]; gw = p.g_w[g]; gy = p.g_y[g]; }
+    }
+    p.x += gx + (long long)b * p.M * ci; p.w += gw + (long long)b * p.Co * ci; p.y += gy + (long long)b * p.M * p.Co;
+    p.Ci = ci; p.x_cs = ci; p.x_bytes = (unsigned)p.M * (unsigned)ci * 4u; p.w_bytes = (unsigned)p.Co * (unsigned)ci * 4u;
+  } else if (gridDim.y > 1) { p.x += blockIdx.y * p.x_bs; p.w += blockIdx.y * p.w_bs; p.y += blockIdx.y * p.y_bs; }   // batched GEMMs (winograd.hip)
   constexpr bool DMA = PREC == 4;                          // fp32 core, tiles DMA'd into swizzled 128-byte LDS rows
   constexpr int DST = kDmaStages;                          // DMA: LDS stages (tiles run DST - 1 ahead of the MFMAs)
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -1328,6 +1342,17 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.co_limit = narrow ? d.co_limit : d.Co;
   a.pool_part = d.pool_part; a.pool_hw = d.pool_hw;
   a.batch = d.batch > 1 ? d.batch : 1; a.x_bs = d.x_bstride; a.w_bs = d.w_bstride; a.y_bs = d.y_bstride;
+  a.ngroups = d.ngroups;
+  for (int g = 0; g < 4; ++g) { a.g_batch[g] = d.g_batch[g]; a.g_Ci[g] = d.g_Ci[g]; a.g_x[g] = d.g_x[g]; a.g_w[g] = d.g_w[g]; a.g_y[g] = d.g_y[g]; }
+  if (d.ngroups > 0) {
+    if (d.ngroups > 4 || d.x_coff || d.y_coff || d.y_cs != d.Co) { *why = "conv2d: grouped batches are dense [M][Ci] x [Co][Ci] -> [M][Co] problems"; return hipErrorInvalidValue; }
+    int nb = 0;
+    for (int g = 0; g < d.ngroups; ++g) {
+      if (d.g_Ci[g] < 32 || d.g_Ci[g] % 32 || d.g_batch[g] < 1) { *why = "conv2d: bad batch group"; return hipErrorInvalidValue; }
+      nb += d.g_batch[g];
+    }
+    a.batch = nb;
+  }
   if (a.batch > 1) {
     if (d.KH != 1 || d.KW != 1 || d.res || d.pool_part || cfg == 6 || cfg == 7 || cfg == 10 || a.batch > 65535) { *why = "conv2d: batched launches are plain 1x1 GEMMs on a generic tile"; return hipErrorInvalidValue; }
     sk = 1;

@@ -1119,24 +1119,36 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
                          int y_coff, float* pool_t) -> int {
       const ConvSpec& c = kConvs[id];
-      const int T = 4 * n, phases = c.K == 5 ? 4 : 1, Kg = phases * c.Ci;
+      const int T = 4 * n, phases = c.K == 5 ? 4 : 1;
       float* V = region(h, ws, "wino_v") + (size_t)36 * 4 * i0 * 4224;      // (a split call gets its own part of the regions)
       float* M = region(h, ws, "wino_m") + (size_t)36 * 4 * i0 * 512;
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()); if (rc != OFFK_OK) return rc; }
       HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, phases, V, s));
-      ConvDesc d;
-      d.x = V; d.x_cs = Kg; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = Kg;
-      d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-      d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-      d.y = M; d.y_cs = c.Co; d.y_coff = 0;
-      d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
-      d.batch = 36; d.x_bstride = (long long)T * Kg; d.w_bstride = (long long)c.Co * Kg; d.y_bstride = (long long)T * c.Co;
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 36 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
-      const char* why = nullptr;
-      hipError_t e = conv2d_launch(d, s, &why);
-      if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
+      WinoGroup grp[4];
+      const int ngrp = wino_groups(phases, T, c.Ci, c.Co, grp);
+      {       // ONE launch: the groups ride on gridDim.y (four launches left the short groups alone on the chip: slower than no skipping)
+        const int K0 = grp[0].kmul * c.Ci;
+        ConvDesc d;
+        d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = K0;
+        d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+        d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+        d.y = M; d.y_cs = c.Co; d.y_coff = 0;
+        d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
+        d.batch = 36; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
+        if (ngrp > 1) {
+          d.ngroups = ngrp;
+          for (int gi = 0; gi < ngrp; ++gi) {
+            d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * c.Ci;
+            d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
+          }
+        }
+        const char* why = nullptr;
+        hipError_t e = conv2d_launch(d, s, &why);
+        if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
+      }
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()); if (rc != OFFK_OK) return rc; }
-      HIP_TRY(h, wino_output_launch(M, n, c.Co, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
+      HIP_TRY(h, wino_output_launch(M, n, c.Co, phases, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
       return OFFK_OK;
     };
     // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
@@ -1489,17 +1501,29 @@ int winograd_entry(const char* who, void* stream, const float* x, int x_cstride,
   hipError_t e = wino_weight_launch(w_packed, Co, Ci, phases, U, st);
   if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, phases, V, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
-  ConvDesc d;
-  d.x = V; d.x_cs = (int)K; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = (int)K;
-  d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-  d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-  d.y = M; d.y_cs = Co; d.y_coff = 0;
-  d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
-  d.batch = 36; d.x_bstride = (long long)T * K; d.w_bstride = (long long)Co * K; d.y_bstride = (long long)T * Co;
-  const char* why = nullptr;
-  e = conv2d_launch(d, st, &why);
-  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
-  e = wino_output_launch(M, n_img, Co, bias, res, res_cstride, res_coff, flags, y, y_cstride, y_coff, pool_part, st);
+  WinoGroup grp[4];
+  const int ngrp = wino_groups(phases, (long long)T, Ci, Co, grp);
+  {
+    const int K0 = grp[0].kmul * Ci;
+    ConvDesc d;
+    d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = K0;
+    d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+    d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+    d.y = M; d.y_cs = Co; d.y_coff = 0;
+    d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+    d.batch = 36; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)T * Co;
+    if (ngrp > 1) {
+      d.ngroups = ngrp;
+      for (int gi = 0; gi < ngrp; ++gi) {
+        d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
+        d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
+      }
+    }
+    const char* why = nullptr;
+    e = conv2d_launch(d, st, &why);
+    if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  }
+  e = wino_output_launch(M, n_img, Co, phases, bias, res, res_cstride, res_coff, flags, y, y_cstride, y_coff, pool_part, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
   return OFFK_OK;
 }

@@ -31,6 +31,9 @@ struct ConvDesc {
   int co_limit = 0;                       // > 0: store only output channels < co_limit (weights padded to Co); needs splitk == 1
   int batch = 1;                          // > 1: that many independent problems of this shape in one launch (1x1 only): problem b
   long long x_bstride = 0, w_bstride = 0, y_bstride = 0;   //   reads x + b * x_bstride, w + b * w_bstride, writes y + b * y_bstride (floats)
+  int ngroups = 0;                        // > 0: grouped batch -- g_batch[g] dense 1x1 problems [M][g_Ci[g]] x [Co][g_Ci[g]] -> [M][Co] per group,
+  int g_batch[4] = {0, 0, 0, 0}, g_Ci[4] = {0, 0, 0, 0};   //   packed from x + g_x[g], w + g_w[g], y + g_y[g] (floats); Ci / x_cs = the largest
+  long long g_x[4] = {0, 0, 0, 0}, g_w[4] = {0, 0, 0, 0}, g_y[4] = {0, 0, 0, 0};
   float* pool_part = nullptr;             // != nullptr: [ceil(M / 32)][2][Co] partial column sums of the stored output (heads.hip: fc_pooled)
   int pool_hw = 0;                        //   rows per image (>= 32); forces splitk = 1
   int plan_n_img = 0;                     // > 0: the automatic plan is the one of this many images (a call on part of a batch
@@ -64,8 +67,12 @@ hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
 // phases = 1: 3x3 / stride 1 on 7x7 maps; phases = 4: the polyphase form of a 5x5 / stride 2 / pad 2 conv on 14x14 maps (K = 4 Ci)
 hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, int phases, float* U, hipStream_t st);           // U [36][Co][phases Ci]
 hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, int phases, float* V, hipStream_t st);   // V [36][4 n_img][phases Ci]
-hipError_t wino_output_launch(const float* M, int n_img, int Co, const float* bias, const float* res, int res_cs, int res_coff,
-                              int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st);
+hipError_t wino_output_launch(const float* M, int n_img, int Co, int phases, const float* bias, const float* res, int res_cs,
+                              int res_coff, int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st);
+// the GEMM launches of a conv on the Winograd path: phases == 1: one group of 36 points with K = Ci; phases == 4: four groups
+// (25 points K = 4 Ci, 5 + 5 points K = 2 Ci, 1 point K = Ci; winograd.hip).  Offsets in floats for T tiles / Co output channels.
+struct WinoGroup { int batch, kmul; long long v_off, u_off, m_off; };
+int wino_groups(int phases, long long T, int Ci, int Co, WinoGroup out[4]);
 
 // ---- K1 ------------------------------------------------------------------------
 struct PwSite {

@@ -49,6 +49,26 @@ __device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
   u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
   u[5] = g[2];
 }
+// Polyphase form (NPH = 4): a phase kernel with a == 1 (b == 1) has two taps, its transform is zero at the point "infinity"
+// (row / column 5 of the 6x6 point grid).  Those (point, phase) products are skipped: the 25 points with i, j < 5 contract all
+// four phases (K = 4 Ci), the five points of row 5 only the phases with a == 0, the five of column 5 those with b == 0 (K = 2 Ci),
+// point (5, 5) phase 0 alone (K = Ci): 121 instead of 144 phase-points of GEMM work and of transformed-input traffic.  Points are
+// stored group by group -- A: i * 5 + j, B (i == 5): 25 + j, C (j == 5): 30 + i, D: 35 -- each group with its own K.
+// place(): for point (i, j) and phase (pa, pb), the group's first float (in units of rows * Ci), the point's index inside the
+// group, the group's K in units of Ci and the phase's slot in it; false if the product is identically zero.
+struct WinoPlace { int base_ci, idx, kmul, slot; };
+__device__ __forceinline__ bool wino_place4(int i, int j, int pa, int pb, WinoPlace& o) {
+  if (i < 5 && j < 5) { o = WinoPlace{0, i * 5 + j, 4, 2 * pa + pb}; return true; }
+  if (i == 5 && j < 5) { o = WinoPlace{100, j, 2, pb}; return pa == 0; }             // group A holds 25 * 4 = 100 row-Ci units
+  if (j == 5 && i < 5) { o = WinoPlace{110, i, 2, pa}; return pb == 0; }             // + 5 * 2
+  o = WinoPlace{120, 0, 1, 0};                                                         // + 5 * 2
+  return pa == 0 && pb == 0;
+}
+// index of point (i, j) in the GEMM-output array M [36][T][Co]
+__device__ __forceinline__ int wino_mindex(int nph, int i, int j) {
+  if (nph == 1) return i * 6 + j;
+  return i < 5 && j < 5 ? i * 5 + j : (i == 5 && j < 5 ? 25 + j : (j == 5 && i < 5 ? 30 + i : 35));
+}
 }  // namespace
 
 // x: channels-last [n_img * W * W][x_cs], Ci channels at x_coff.  V: [36][n_img * 4][NPH * Ci].
@@ -88,7 +108,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     float v[6];
     bt6(t[i], v);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * T + tile) * K + kk] = v[j];
+    for (int j = 0; j < 6; ++j) {
+      if constexpr (NPH == 1) {
+        V[((size_t)(i * 6 + j) * T + tile) * K + kk] = v[j];
+      } else {
+        WinoPlace pl;
+        if (wino_place4(i, j, pa, pb, pl))
+          V[((size_t)pl.base_ci * T + ((size_t)pl.idx * T + tile) * pl.kmul + pl.slot) * Ci + c] = v[j];
+      }
+    }
   }
 }
 
@@ -99,6 +127,7 @@ struct WinoOutArgs {
   float* y; int y_cs, y_coff;
   float* pool_part;              // != nullptr: [T][Co] sums of the stored values of each tile (4 tiles = one image)
   int n_img, Co, flags;
+  int nph;                       // 1: M indexed i * 6 + j; 4: the polyphase point order (wino_mindex)
 };
 __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
   const int T = a.n_img * 4;
@@ -113,7 +142,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(WinoOutArgs a) {
   for (int j = 0; j < 6; ++j) {
     float m[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m[i] = mp[(size_t)(i * 6 + j) * pstride];
+    for (int i = 0; i < 6; ++i) m[i] = mp[(size_t)wino_mindex(a.nph, i, j) * pstride];
     float sc[4];
     at4(m, sc);
 #pragma unroll
@@ -174,8 +203,24 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     float u[6];
     g6(t[i], u);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) U[((size_t)(i * 6 + j) * Co + co) * K + kk] = u[j];
+    for (int j = 0; j < 6; ++j) {
+      if constexpr (NPH == 1) {
+        U[((size_t)(i * 6 + j) * Co + co) * K + kk] = u[j];
+      } else {
+        WinoPlace pl;
+        if (wino_place4(i, j, pa, pb, pl))
+          U[((size_t)pl.base_ci * Co + ((size_t)pl.idx * Co + co) * pl.kmul + pl.slot) * Ci + ci] = u[j];
+      }
+    }
   }
+}
+
+int wino_groups(int phases, long long T, int Ci, int Co, WinoGroup out[4]) {
+  if (phases == 1) { out[0] = WinoGroup{36, 1, 0, 0, 0}; return 1; }
+  const int batch[4] = {25, 5, 5, 1}, kmul[4] = {4, 2, 2, 1}, base[4] = {0, 100, 110, 120}, first[4] = {0, 25, 30, 35};
+  for (int g = 0; g < 4; ++g)
+    out[g] = WinoGroup{batch[g], kmul[g], (long long)base[g] * T * Ci, (long long)base[g] * Co * Ci, (long long)first[g] * T * Co};
+  return 4;
 }
 
 hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, int phases, float* U, hipStream_t st) {
@@ -192,9 +237,10 @@ hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, in
   return hipGetLastError();
 }
 
-hipError_t wino_output_launch(const float* M, int n_img, int Co, const float* bias, const float* res, int res_cs, int res_coff,
-                              int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st) {
+hipError_t wino_output_launch(const float* M, int n_img, int Co, int phases, const float* bias, const float* res, int res_cs,
+                              int res_coff, int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st) {
   WinoOutArgs a;
+  a.nph = phases;
   a.M = M; a.bias = bias; a.res = res; a.res_cs = res_cs; a.res_coff = res_coff;
   a.y = y; a.y_cs = y_cs; a.y_coff = y_coff; a.pool_part = pool_part;
   a.n_img = n_img; a.Co = Co; a.flags = flags;
