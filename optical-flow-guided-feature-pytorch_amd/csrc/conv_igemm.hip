@@ -38,6 +38,9 @@ struct ConvArgs {
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   int batch;           // gridDim.y (1: a single problem)
+  int spread;          // LDS-DMA form: issue the next tile's DMA pieces between the k-groups (grids that fill the chip several times
+                       // over: +0.5 % at B = 64) instead of in a bunch at the top of the step (small grids: with one block per CU
+                       // the later issue is exposed latency -- B = 1: 0.81 vs 0.98 ms)
   long long x_bs, w_bs, y_bs;   // batched launch (gridDim.y problems of the same shape): element strides between problems
   // grouped batch (ngroups > 0; winograd.hip's polyphase form): gridDim.y = sum of g_batch; the problems of group g are dense
   // 1x1 GEMMs [M][g_Ci] x [Co][g_Ci] -> [M][Co] packed one behind the other from x + g_x / w + g_w / y + g_y
@@ -414,7 +417,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     // one K-tile: the load unit fills the stage every wave left at the last barrier with tile kt + DST - 1 while the MFMAs
     // read stage st (a literal: the loop is unrolled by DST)
     auto step = [&](int kt, const int st) {
-      if constexpr (DST == 2) {
+      if (DST == 2 && p.spread) {
         dma_prep(min(kt + 1, kt_end - 1));
         mma(st, st ^ 1);                       // the pieces of tile kt + 1 go out between the k-groups
       } else {
@@ -1225,6 +1228,7 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   }
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;
+  a.spread = (long long)a.gm * a.gn * a.splitk * a.batch >= 2560 ? 1 : 0;      // >= two rounds of five blocks per CU
   hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk, a.batch), dim3(!(PREC & 1) ? 256 : 512), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.splitk == 1) return e;

@@ -1202,7 +1202,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     }
     // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
     float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);
-    if (wino && h->wino_5x5) TRY(wino_conv(C_T14, 5, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128, nullptr));   // :762-763 x1 (polyphase)
+    // (from P = 96 pairs: below, its 132-K-tile GEMMs have too few row tiles to fill the chip and the split-K direct conv wins --
+    // B = 1: 0.81 vs 1.04 ms, B = 8: 1.15 vs 1.37 ms, B = 16: equal; profiles/r03/batch_table_fp32_*.txt)
+    if (wino && h->wino_5x5 && h->P >= 96) TRY(wino_conv(C_T14, 5, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128, nullptr));   // :762-763 x1 (polyphase)
     else
     TRY(conv(h, s, C_T14, n, 14, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128));          // :762-763 x1
     TRY(conv(h, s, C1_14A, n, 7, View{xu_, 256, 128}, nullptr, 0, 0, RP, u1_, 128, 0));            // :764-765
