@@ -183,7 +183,8 @@ def winograd_gemm_flops(P, key):
     """FLOPs of the 36 batched GEMMs [4P tiles][K] x [K][Co] of a conv on the Winograd path: K = Ci for a 3x3 / stride 1
     conv on 7x7 maps, 4 Ci for the polyphase form of the 5x5 / stride 2 conv (four 7x7 phase images concatenated along K)."""
     co, ci, k = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
-    return 2.0 * 36 * 4 * P * (4 * ci if k == 5 else ci) * co
+    # polyphase: 121 of the 144 (point, phase) products -- the others have an identically zero transformed kernel and are skipped
+    return 2.0 * 4 * P * (121 * ci if k == 5 else 36 * ci) * co
 
 
 def winograd_saved_flops(P):
@@ -243,7 +244,8 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
                 small_ms += avg if key not in big else 0.0
                 small_fl += work[key] if key not in big else 0.0
             else:
-                nbytes = (36 * T * ci + P * 49 * ci) * 4 if "input" in name else (36 * T * co + P * 49 * co) * 4
+                vpts = 121 * ci / 4 if ksz == 5 else 36 * ci          # transformed-input floats per tile (polyphase: 121 phase-points)
+                nbytes = (T * vpts + P * 49 * ci) * 4 if "input" in name else (36 * T * co + P * 49 * co) * 4
                 rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
                 small_ms += avg if key not in big else 0.0
         elif name in work or name.split(" ")[0] in work or name.startswith("chain_"):
