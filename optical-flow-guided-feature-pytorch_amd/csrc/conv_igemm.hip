@@ -38,7 +38,7 @@ struct ConvArgs {
   int gm, gn, splitk;  // m-tiles, n-tiles, k-splits (grid = gm*gn*splitk blocks)
   int co_limit;        // output channels >= co_limit are not stored (Co padded for the tiling)
   int batch;           // gridDim.y (1: a single problem)
-  int spread;          // LDS-DMA form: issue the next tile's DMA pieces between the k-groups (grids that fill the chip several times
+  int spread;          // LDS-DMA form: issue the next tile's DMA pieces between the k-groups (grids of >= 1024 blocks, four per CU
                        // over: +0.5 % at B = 64) instead of in a bunch at the top of the step (small grids: with one block per CU
                        // the later issue is exposed latency -- B = 1: 0.81 vs 0.98 ms)
   long long x_bs, w_bs, y_bs;   // batched launch (gridDim.y problems of the same shape): element strides between problems
@@ -1228,7 +1228,7 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   }
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;
-  a.spread = (long long)a.gm * a.gn * a.splitk * a.batch >= 2560 ? 1 : 0;      // >= two rounds of five blocks per CU
+  a.spread = (long long)a.gm * a.gn * a.splitk * a.batch >= 1024 ? 1 : 0;      // >= four blocks per CU
   hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk, a.batch), dim3(!(PREC & 1) ? 256 : 512), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.splitk == 1) return e;

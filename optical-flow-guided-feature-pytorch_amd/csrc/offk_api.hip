@@ -154,6 +154,7 @@ struct offk_handle {
   bool wino_dirty = true;
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
   int wino_cfg = 3;              // tile of the 36 batched GEMMs (OFFK_WINO_CFG at offk_create: tools)
+  int wino_cfg_small = 3;        // the same for the short-K ones (K <= 256; OFFK_WINO_CFG_SMALL)
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
   bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
   size_t train_ws_bytes = 0;
@@ -729,6 +730,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
   { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_WINO_CFG_SMALL"); if (e && *e >= '0' && *e <= '5') h->wino_cfg_small = *e - '0'; }
   { const char* e = getenv("OFFK_WINO_CFG"); if (e && *e >= '0' && *e <= '5') h->wino_cfg = *e - '0'; }
   if (h->winograd) {
     const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
@@ -1134,7 +1136,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
         d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
         d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
         d.y = M; d.y_cs = c.Co; d.y_coff = 0;
-        d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
+        d.tile_cfg = K0 <= 256 ? h->wino_cfg_small : h->wino_cfg; d.splitk = 1; d.precision = 0;
         d.batch = 36; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
         if (ngrp > 1) {
           d.ngroups = ngrp;
