@@ -114,6 +114,7 @@ struct offk_handle {
   float* pw_w[kNumSites] = {};   // [160][C]
   float* pw_wb3[kNumSites] = {}; // bf16x3 mode: the same matrix pre-split per K-tile (hi 32 | lo 32)
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
+  float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
   bool pw_dirty = true;
   bool pw_presplit = true;
   float* pw_b[kNumSites] = {};   // [160]
@@ -156,7 +157,7 @@ struct offk_handle {
   int wino_cfg = 3;              // tile of the 36 batched GEMMs (OFFK_WINO_CFG at offk_create: tools)
   int wino_cfg_small = 3;        // the same for the short-K ones (K <= 256; OFFK_WINO_CFG_SMALL)
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
-  bool pw_dma = true;            // fp32 fused units: feature-map tiles by LDS-DMA (OFFK_PW_DMA=0 at offk_create: register-staged form)
+  int pw_dma = 2;                // fp32 fused units: 2 = 16-pixel LDS-DMA form, 1 = 32-pixel LDS-DMA form, 0 = register-staged (OFFK_PW_DMA at offk_create)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
   std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
@@ -477,6 +478,8 @@ int finalize_pw(offk_handle* h, hipStream_t st) {
       HIP_TRY(h, split_bf16_launch(h->pw_w[s], (size_t)kUnitCh * kSites[s].C, h->pw_wb3[s], st));
   for (int s = 0; s < kNumSites; ++s)
     HIP_TRY(h, pw_pack_direct_launch(h->pw_w[s], kSites[s].C, h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0, h->pw_wt[s], st));
+  if (h->cfg.precision == OFFK_PRECISION_FP32)
+    for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16[s], st));
   h->pw_dirty = false;
   return OFFK_OK;
 }
@@ -525,7 +528,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   pt.bdirect = 1;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
-  pt.dma = h->pw_dma ? 1 : 0;
+  pt.dma = h->pw_dma;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
@@ -536,6 +539,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
     o.nparts = fp.n_parts;
     pw_weight_ptrs(h, s, pt.presplit, &o.w, &o.w_down, &o.bias, &o.bias_down);
     o.wt = h->pw_wt[s];
+    o.wt16 = h->pw_wt16[s];
     o.D = region(h, ws, (std::string("D_") + kSites[s].name).c_str());
     o.M = region(h, ws, fus[kSiteFusion[s]]);
     o.m_cs = kFusionC[kSiteFusion[s]]; o.m_coff = kSiteCoff[s];
@@ -678,6 +682,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     rc = dev_alloc(h, &h->pw_w[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wb3[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_wt[s], (size_t)kUnitCh * C);
+    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_FP32) rc = dev_alloc(h, &h->pw_wt16[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
     if (cfg->variant == OFFK_VARIANT_RGB_LEARNED_DW && rc == OFFK_OK) {
       add_slot(h, "motion_spatial_grad_" + n + ".weight", {kDownCh, 1, 3, 3}, SK_DW_W, s);
@@ -725,7 +730,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   }
   // inference: K1 fused with the temporal difference (pw_tdiff.hip) unless OFFK_FUSED_UNITS=0 at offk_create
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
-  { const char* e = getenv("OFFK_PW_DMA"); h->pw_dma = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_PW_DMA"); if (e && *e >= '0' && *e <= '2') h->pw_dma = *e - '0'; }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }

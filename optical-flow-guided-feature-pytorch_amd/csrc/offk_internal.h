@@ -113,6 +113,7 @@ struct PtSite {
   const float* w;       // gen rows [128][C] fp32, or pre-split for bf16x3 (as PwSite)
   const float* w_down;  // down rows [32][C]
   const float* wt;      // PtParams.bdirect: all 160 rows packed in MFMA-operand order (pw_pack_direct_launch), read straight into registers
+  const float* wt16;    // the same rows in the operand order of the 16-pixel form (pw_pack_direct16_launch)
   const float* bias;    // [128]
   const float* bias_down;   // [32]
   float* D;             // [P*HW][32]
@@ -134,7 +135,8 @@ struct PtParams {
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
   int bdirect;               // every site carries wt: the weight operand bypasses LDS (two LDS stages for the feature-map tile)
-  int dma;                   // fp32 + bdirect: the LDS-DMA form (pw_tdiff_dma_kernel); 0 with OFFK_PW_DMA=0 at offk_create
+  int dma;                   // fp32 + bdirect: 2 = the 16-pixel LDS-DMA form (pw_tdiff16_kernel), 1 = the 32-pixel one (pw_tdiff_dma_kernel),
+                             // 0 = register-staged (OFFK_PW_DMA at offk_create)
   const float* zeros;
 #ifdef OFFK_PT_TIMING
   unsigned long long* dbg;   // cycle-counter sums (tools only)
@@ -144,6 +146,7 @@ int pt_tgroups(int L);
 hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);
 // w160: [160][C] fp32 (gen rows, then down rows) -> out (160 * C floats), the operand-order image pw_tdiff reads with bdirect
 hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float* out, hipStream_t st);
+hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStream_t st);
 
 // ---- K2 ------------------------------------------------------------------------
 struct StSite {

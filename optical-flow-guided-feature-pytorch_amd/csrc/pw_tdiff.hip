@@ -762,6 +762,290 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16-pixel form of the LDS-DMA kernel (round 3): v_mfma_f32_16x16x4_f32 tiles, a block owns (clip, 16-pixel chunk) x all
+// frames.  Why: pw_tdiff_dma_kernel keeps 9 accumulator tiles of 32x32 per wave (144 registers, 202 in all), so two blocks per
+// CU is all that fits, and a block alone on its CU -- its partner in a prologue, an epilogue or at a barrier -- runs at 83 % of
+// the matrix pipe (profiles/r03/k1t_experiments.txt).  With 16x16 tiles a wave holds 14 gen tiles + up to 4 down tiles of FOUR
+// registers each (72), the kernel fits three waves per SIMD and 29 KB of LDS per block: three blocks per CU cover each other.
+// Same MFMA cycles per pixel (2048 FLOP per 32 cycles), twice the weight bytes per pixel from L2 (a block streams the whole
+// [160][32] weight tile per K-tile for 16 pixels instead of 32) and 64-byte feature-map runs instead of 128.
+//   wave w: gen channels [32w, 32w + 32) = channel tiles 2w, 2w + 1, all seven frames; down tiles (both channel tiles) of
+//   frames w and w + 4.  MFMA (weights = A, pixels = B): D rows = channels, lanes = pixels -> a lane holds four consecutive
+//   channels of one pixel (16-byte stores).  x operand: lane (pixel li, kq) of step s reads X[k = 4s + kq][pixel] -- one dword,
+//   conflict-free -- two units ahead; unit = (k half, frame): 8 MFMAs (16 with the frame's down tiles), alternating between
+//   the two channel tiles so that consecutive MFMAs never share an accumulator.
+//   queue (per wave, as pw_tdiff_dma_kernel): 4 DMA instructions per step -- the 14 of a tile (7 frames x two 16-row halves)
+//   over four waves, the two missing ones land in a dummy KB -- behind the first four units; the 4 weight loads of a k half
+//   behind that half's last unit.  Waits: half 0: all but the 4 newest; half 1: all but 8; end of step (DMAs): all but 8.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
+  constexpr int FRAME_B = 32 * 64;               // one frame's K-tile image [32 k][16 pixels] fp32
+  constexpr int STAGE_B = PT_FT * FRAME_B;       // 14 KB; two stages, then 1 KB that the surplus DMA slots write
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+  PtSite S;
+  int nblk_site;
+#define OFFK_PT_PICK(i)                                                                                \
+  S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;                           \
+  S.bias_down = p.s[i].bias_down; S.wt = p.s[i].wt16;                                                  \
+  S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
+  S.nrem = p.s[i].nrem; S.rsh = p.s[i].rsh;                                                            \
+  S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
+  nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;          \
+  S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
+  S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
+  OFFK_PT_PICK(0)
+#pragma unroll
+  for (int i = 1; i < kNumSites; ++i)
+    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PT_PICK(i) }
+#undef OFFK_PT_PICK
+  const int C = S.C, HW = S.HW, L = p.L;
+  int local = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site);
+  const int tg = local % p.tgroups; local /= p.tgroups;
+  // (clip, 16-pixel chunk) blocks first, then the leftover blocks: HW % 16 pixels of 16 >> rsh clips each (rsh = 4: one clip)
+  const int nfull = p.B * S.chunks;
+  const bool leftover = local >= nfull;
+  const int rsh = leftover ? S.rsh : 4, rmask = (1 << rsh) - 1;
+  const int b = leftover ? (local - nfull) << (4 - rsh) : local / S.chunks;
+  const int q0 = (leftover ? S.chunks : local - b * S.chunks) * 16;
+  const int t0 = tg * (PT_FT - 1);
+  const int nf = min(PT_FT, L - t0);
+  const bool last_group = tg == p.tgroups - 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int li = lane & 15, kq = lane >> 4;
+
+  // ---- DMA: instruction slot q = wave + 4 i (i = 0..3) lands frame q >> 1, k rows 16 (q & 1) + (lane >> 2), pixel quad lane & 3;
+  //      slots 14, 15 (waves 2, 3, i = 3) go to the dummy KB with an out-of-range source ----
+  const int pq = lane & 3;
+  const int cq = (4 * pq) >> rsh;                                  // clip of the quad within the block (0 unless packed)
+  const int k0px = q0 + ((4 * pq) & rmask);
+  const bool px_ok = k0px < HW && b + cq < p.B;
+  int vrow[4];                                                     // per slot: byte offset of (k row, pixel quad) inside a frame
+  int dframe[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave + 4 * i;
+    dframe[i] = q >> 1;
+    vrow[i] = px_ok && q < 2 * PT_FT ? ((16 * (q & 1) + (lane >> 2)) * HW + k0px) * 4 : (int)0x80000000;
+  }
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
+  };
+  i32x4 dm_desc = {0, 0, 0, 0};
+  int dm_fstride = 0, dm_s0 = 0, dm_clip = 0;
+  auto dma_prep = [&](int kt) {
+    const float* xb = S.xp[0]; int cpart = S.cp[0], kl = kt * BK;
+    if (S.nparts > 1 && kl >= S.cp[0]) {
+      kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
+      if (S.nparts > 2 && kl >= S.cp[1]) {
+        kl -= S.cp[1]; xb = S.xp[2]; cpart = S.cp[2];
+        if (S.nparts > 3 && kl >= S.cp[2]) { kl -= S.cp[2]; xb = S.xp[3]; cpart = S.cp[3]; }
+      }
+    }
+    const unsigned long long xa = reinterpret_cast<unsigned long long>(xb);
+    dm_desc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
+    dm_fstride = cpart * HW * 4;
+    dm_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;
+    dm_clip = cq * L * dm_fstride;
+  };
+  auto dma_issue = [&](const int i, const int stage) {
+    const int q = wave + 4 * i;                                     // scalar
+    const int voff = dframe[i] < nf ? vrow[i] + dm_clip + dframe[i] * dm_fstride : (int)0x80000000;   // (an invalid vrow stays >= 2^31)
+    const unsigned dst = q < 2 * PT_FT ? lds_base + stage * STAGE_B + dframe[i] * FRAME_B + (q & 1) * 1024 : lds_base + 2 * STAGE_B;
+    dma16(dm_desc, dst, voff, dm_s0);
+  };
+
+  // ---- weight operand: asm loads (hand-counted waits).  wg[2 ct + hf]: gen channel tile ct of this wave, k half hf (the
+  //      lane's W[ch][kt * 32 + 16 hf + 4 e + kq], e = 0..3); wd likewise for the two down channel tiles ----
+  f32x4 wg[4], wd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { wg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; wd[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  i32x4 wdesc;
+  {
+    const unsigned long long wa = reinterpret_cast<unsigned long long>(S.wt);
+    wdesc = i32x4{(int)(unsigned)wa, (int)(unsigned)(wa >> 32) & 0xffff, kUnitCh * C * 4, 0x00020000};
+  }
+  const int wlane = lane * 16;
+  // image: [kt][slab (4 gen + 1 down)][ct][hf][lane] float4 (pw_pack_direct16_kernel)
+  auto load_w = [&](const int hf, int kt) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int so_g = (((kt * 5 + wave) * 2 + ct) * 2 + hf) * 1024, so_d = (((kt * 5 + 4) * 2 + ct) * 2 + hf) * 1024;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wg[2 * ct + hf]) : "v"(wlane), "s"(wdesc), "s"(so_g));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wd[2 * ct + hf]) : "v"(wlane), "s"(wdesc), "s"(so_d));
+    }
+  };
+#define OFFK_WAIT16(N, hf) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[hf]), "+v"(wg[2 + (hf)]), "+v"(wd[hf]), "+v"(wd[2 + (hf)]))
+
+  f32x4 ag[PT_FT][2], ad[2][2];          // gen tiles [frame][ct]; down tiles [frame wave / wave + 4][ct]
+#pragma unroll
+  for (int j = 0; j < PT_FT; ++j) { ag[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ad[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ad[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nkt = C / BK;
+  // nine frame slots per k half: slots 0..6 = the gen tiles of frame s, slot 7 / 8 = the down tiles of frames `wave` / wave + 4
+  // (wave 3 has no second down frame: it multiplies frame 6 again and never stores the result -- no branch in the MFMA stream:
+  // per-unit tests of a runtime wave index made hipcc copy accumulators at every merge).  Units of two slots = four accumulator
+  // tiles in rotation; x reads one unit ahead.
+  const char* const xl = lds + kq * 64 + li * 4;         // + frame * 2048 + step * 256
+  const int xoffA = wave * FRAME_B, xoffB = min(wave + 4, PT_FT - 1) * FRAME_B;
+  auto rdx = [&](float (&x)[4], const int st, const int hf, const int slot) {
+    const char* q = xl + st * STAGE_B + hf * 1024 + (slot < PT_FT ? slot * FRAME_B : (slot == PT_FT ? xoffA : xoffB));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = *reinterpret_cast<const float*>(q + e * 256);
+  };
+  auto mf = [&](f32x4& c, float a, float b) { c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); };
+  auto mma = [&](const int st, int ktn) {
+    constexpr int NS = PT_FT + 2, NU = (NS + 1) / 2;          // slots, units per k half
+    float x[2][2][4];
+    rdx(x[0][0], st, 0, 0);
+    rdx(x[0][1], st, 0, 1);
+#pragma unroll
+    for (int u = 0; u < 2 * NU; ++u) {
+      const int hf = u / NU, uu = u % NU, s0 = 2 * uu, s1 = s0 + 1;
+      if (u + 1 < 2 * NU) {
+        const int hn = (u + 1) / NU, un = (u + 1) % NU;
+        rdx(x[(u + 1) & 1][0], st, hn, 2 * un);
+        if (2 * un + 1 < NS) rdx(x[(u + 1) & 1][1], st, hn, 2 * un + 1);
+      }
+      if (uu == 0) { if (hf == 0) OFFK_WAIT16(4, 0); else OFFK_WAIT16(8, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      const float (&xa)[4] = x[u & 1][0];
+      const float (&xb)[4] = x[u & 1][1];
+      // accumulators and weights of the two slots (literals: s0 / s1 are compile-time)
+      f32x4 &a00 = s0 < PT_FT ? ag[s0][0] : ad[s0 - PT_FT][0], &a01 = s0 < PT_FT ? ag[s0][1] : ad[s0 - PT_FT][1];
+      const f32x4 &w00 = s0 < PT_FT ? wg[hf] : wd[hf], &w01 = s0 < PT_FT ? wg[2 + hf] : wd[2 + hf];
+      if (s1 < NS) {
+        f32x4 &a10 = s1 < PT_FT ? ag[s1][0] : ad[s1 - PT_FT][0], &a11 = s1 < PT_FT ? ag[s1][1] : ad[s1 - PT_FT][1];
+        const f32x4 &w10 = s1 < PT_FT ? wg[hf] : wd[hf], &w11 = s1 < PT_FT ? wg[2 + hf] : wd[2 + hf];
+        mf(a00, w00.x, xa[0]); mf(a01, w01.x, xa[0]); mf(a10, w10.x, xb[0]); mf(a11, w11.x, xb[0]);
+        mf(a00, w00.y, xa[1]); mf(a01, w01.y, xa[1]); mf(a10, w10.y, xb[1]); mf(a11, w11.y, xb[1]);
+        mf(a00, w00.z, xa[2]); mf(a01, w01.z, xa[2]); mf(a10, w10.z, xb[2]); mf(a11, w11.z, xb[2]);
+        mf(a00, w00.w, xa[3]); mf(a01, w01.w, xa[3]); mf(a10, w10.w, xb[3]); mf(a11, w11.w, xb[3]);
+      } else {
+        mf(a00, w00.x, xa[0]); mf(a01, w01.x, xa[0]);
+        mf(a00, w00.y, xa[1]); mf(a01, w01.y, xa[1]);
+        mf(a00, w00.z, xa[2]); mf(a01, w01.z, xa[2]);
+        mf(a00, w00.w, xa[3]); mf(a01, w01.w, xa[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef OFFK_K16_NO_DMA
+      if (u < 4) dma_issue(u, st ^ 1);              // every wave has left stage st ^ 1 at the last barrier
+#else
+      if (u < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(wg[0]) : "v"(wlane), "s"(wdesc));   // timing only: keeps the counts
+#endif
+#ifndef OFFK_K16_NO_W
+      if (uu == NU - 1) load_w(hf, ktn);
+#else
+      if (uu == NU - 1) load_w(hf, 0);              // timing only: the same (cached) tile every time
+#endif
+    }
+  };
+#ifdef OFFK_PT_TIMING
+  unsigned long long tm_mma = 0, tm_wait = 0, tm_bar = 0;
+  const unsigned long long tm_begin = __builtin_readcyclecounter();
+#define OFFK_STAMP(var, stmt) { const unsigned long long q0_ = __builtin_readcyclecounter(); stmt; var += __builtin_readcyclecounter() - q0_; }
+#else
+#define OFFK_STAMP(var, stmt) stmt;
+#endif
+  auto step = [&](int kt, const int st) {
+    OFFK_STAMP(tm_mma, dma_prep(min(kt + 1, nkt - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(st, min(kt + 1, nkt - 1)))
+    OFFK_STAMP(tm_wait, asm volatile("s_waitcnt vmcnt(8)" ::: "memory"))   // this wave's DMAs of the step have landed
+    OFFK_STAMP(tm_bar, __syncthreads())
+  };
+  dma_prep(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_issue(i, 0);
+  load_w(0, 0);
+  load_w(1, 0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+#ifdef OFFK_PT_TIMING
+  const unsigned long long tm_loop = __builtin_readcyclecounter();
+#endif
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    step(kt, 0);
+    step(kt + 1, 1);
+  }
+  if (kt < nkt) step(kt, 0);
+#ifdef OFFK_PT_TIMING
+  const unsigned long long tm_epi = __builtin_readcyclecounter();
+#endif
+#undef OFFK_STAMP
+  // nothing may still be landing when the LDS is handed on; the weight registers stay allocated until their last load returned
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0]), "+v"(wg[1]), "+v"(wg[2]), "+v"(wg[3]), "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]) :: "memory");
+#undef OFFK_WAIT16
+
+  // ---- epilogue: lane = (pixel li, channels 4 kq .. + 3 of a channel tile): G = relu(acc + bias), T = G[j + 1] - G[j]; D ----
+  const int bl = b + (li >> rsh), pixl = q0 + (li & rmask);
+  const size_t pair0 = (size_t)bl * (L - 1) + t0;
+  const bool pix_ok = pixl < HW && bl < p.B;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const f32x4 bg = *reinterpret_cast<const f32x4*>(S.bias + wave * 32 + 16 * ct + 4 * kq);
+    f32x4 g[PT_FT];
+#pragma unroll
+    for (int j = 0; j < PT_FT; ++j) {
+      const f32x4 v = ag[j][ct] + bg;
+      g[j] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < PT_FT; ++j)
+      if (j + 1 < nf && pix_ok)
+        *reinterpret_cast<f32x4*>(S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 16 * ct + 4 * kq) = g[j + 1] - g[j];
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int j = wave + 4 * half;                 // (wave 3, half 1: j = 7 >= nf -- its duplicate tile is dropped here)
+    if (j < nf && (last_group || j < PT_FT - 1) && pix_ok) {
+      const int dr = pt_down_row(bl, t0 + j, L, p.P, p.slice_mode);
+      if (dr >= 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 bd = *reinterpret_cast<const f32x4*>(S.bias_down + 16 * ct + 4 * kq);
+          *reinterpret_cast<f32x4*>(S.D + ((size_t)dr * HW + pixl) * kDownCh + 16 * ct + 4 * kq) = ad[half][ct] + bd;
+        }
+      }
+    }
+  }
+#ifdef OFFK_PT_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.dbg && threadIdx.x == 0) {
+    const unsigned long long tm_end = __builtin_readcyclecounter();
+    atomicAdd(p.dbg + 0, tm_loop - tm_begin); atomicAdd(p.dbg + 1, tm_epi - tm_loop); atomicAdd(p.dbg + 2, tm_end - tm_epi);
+    atomicAdd(p.dbg + 3, tm_mma); atomicAdd(p.dbg + 4, tm_wait); atomicAdd(p.dbg + 5, tm_bar);
+    atomicAdd(p.dbg + 6, (unsigned long long)nkt); atomicAdd(p.dbg + 7, 1ull);
+  }
+#endif
+}
+
+// Operand-order image for pw_tdiff16_kernel: one 16-byte item per (K-tile, slab of 32 rows, channel tile ct, k half hf, lane):
+//   W[slab * 32 + 16 ct + li][kt * 32 + 16 hf + 4 e + kq], e = 0..3   (li = lane & 15, kq = lane >> 4)
+__global__ void pw_pack_direct16_kernel(const float* __restrict__ w, int C, float4* __restrict__ out) {
+  const int item = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nitems = (C / BK) * 5 * 2 * 2 * 64;
+  if (item >= nitems) return;
+  const int lane = item & 63, hf = (item >> 6) & 1, ct = (item >> 7) & 1, slab = (item >> 8) % 5, kt = (item >> 8) / 5;
+  const int li = lane & 15, kq = lane >> 4;
+  const float* row = w + (size_t)(slab * 32 + 16 * ct + li) * C + kt * BK + 16 * hf + kq;
+  out[item] = make_float4(row[0], row[4], row[8], row[12]);
+}
+hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStream_t st) {
+  const int nitems = (C / BK) * 5 * 2 * 2 * 64;
+  hipLaunchKernelGGL(pw_pack_direct16_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, w160, C, reinterpret_cast<float4*>(out));
+  return hipGetLastError();
+}
+
 // Operand-order image of a site's 160 weight rows for the BD form.  One 16-byte item per (K-tile, slab, i, lane):
 //   fp32  : i = k-group g          -> W[slab*32 + r32][kt*32 + 8g + 4h + 0..3]
 //   bf16x3: i = plane*2 + s2       -> bf16 hi (plane 0) / lo (plane 1) of W[slab*32 + r32][kt*32 + 16 s2 + 8h + 0..7]
@@ -815,7 +1099,12 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
   constexpr size_t kStageA32 = (size_t)PT_BM * LDS_K * 4, kStageAB3 = 2 * (size_t)PT_BM * B3_ROW;   // BD: feature-map tile only, two stages
 #define OFFK_PT_LAUNCH_BD(P)                                                                                         \
-  if (P == 0 && p.dma) {                                                                                      \
+  if (P == 0 && form16) {                                                                                            \
+    constexpr int k16Lds = 2 * PT_FT * 32 * 64 + 1024;                                                               \
+    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff16_kernel), k16Lds);                         \
+    if (er != hipSuccess) return er;                                                                                 \
+    hipLaunchKernelGGL(pw_tdiff16_kernel, dim3(p.total_blocks), dim3(256), k16Lds, st, p);                           \
+  } else if (P == 0 && p.dma) {                                                                                      \
     constexpr int kDmaLds = 2 * PT_FT * 32 * 128;                                                                    \
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_dma_kernel), kDmaLds);                      \
     if (er != hipSuccess) return er;                                                                                 \
@@ -843,7 +1132,23 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   const bool pc_form = p.precision == 1 && pce && *pce == '1';
   if (pc_form) lean = bd = pack = false;
 #endif
+  const bool form16 = p.precision == 0 && p.dma == 2 && bd;      // the 16-pixel form (pw_tdiff16_kernel)
   auto layout = [&]() {      // block layout of every site (PtSite)
+    if (form16) {
+      int blk = 0;
+      for (int i = 0; i < p.nsites; ++i) {
+        PtSite& o = p.s[i];
+        const int rem = o.HW % 16;
+        const bool packed = rem == 4 || rem == 8;        // 14x14: four clips' four leftover pixels per block
+        o.chunks = packed ? o.HW / 16 : (o.HW + 15) / 16;
+        o.rsh = packed ? (rem == 4 ? 2 : 3) : 4;
+        o.nrem = packed ? (p.B + (16 >> o.rsh) - 1) / (16 >> o.rsh) : 0;
+        o.blk_begin = blk;
+        blk += (p.B * o.chunks + o.nrem) * p.tgroups;
+      }
+      p.total_blocks = blk;
+      return;
+    }
     int blk = 0;
     for (int i = 0; i < p.nsites; ++i) {
       PtSite& o = p.s[i];

@@ -15,7 +15,8 @@ SITE_FUS = [("fusion_28", 320, 0), ("fusion_28", 320, 160), ("fusion_14", 1056, 
             ("fusion_14", 1056, 480), ("fusion_14", 1056, 640), ("fusion_7", 832, 0), ("fusion_7", 832, 160)]
 for B, L in shapes:
     res = {}
-    for dma in ("0", "1"):
+    MODE = os.environ.get("DMA_MODE", "2")
+    for dma in ("0", MODE):
         os.environ["OFFK_PW_DMA"] = dma
         h = runtime.OffForward(B, L, spec.VARIANT_RGB, precision="fp32")
         h.load_state_dict(synth.make_weights(spec.VARIANT_RGB))
@@ -26,8 +27,8 @@ for B, L in shapes:
         res[dma] = ([h.region(n, cs)[:, off:off + 160].clone() for n, cs, off in SITE_FUS],
                     [h.region("D_" + s, 32).clone() for s in spec.SITE_NAMES], [o.clone() for o in out])
     for si in range(9):
-        a, b = res["0"][0][si], res["1"][0][si]
-        da, db = res["0"][1][si], res["1"][1][si]
+        a, b = res["0"][0][si], res[MODE][0][si]
+        da, db = res["0"][1][si], res[MODE][1][si]
         bad = (a != b).any(dim=1).nonzero().flatten()
         badd = (da != db).any(dim=1).nonzero().flatten()
         print("B=%d L=%d site %d: M rows differing %d / %d (first %s), max |diff| %.3g ; D rows differing %d / %d (first %s)"
@@ -39,4 +40,5 @@ for B, L in shapes:
             chans = d.any(dim=0).nonzero().flatten().tolist()
             px = sorted(set((bad % HW).tolist()))
             print("   pairs", pairs, "channels", chans[:8], "..", chans[-4:], "n", len(chans), "pixels", px[:8], "..", px[-4:], "n", len(px))
-    print("logits identical:", [bool(torch.equal(x, y)) for x, y in zip(res["0"][2], res["1"][2])], flush=True)
+    print("logits identical:", [bool(torch.equal(x, y)) for x, y in zip(res["0"][2], res[MODE][2])],
+          "max |diff| / max |ref|:", ["%.2e" % ((x - y).abs().max() / x.abs().max()).item() for x, y in zip(res["0"][2], res[MODE][2])], flush=True)
