@@ -786,22 +786,21 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-  PtSite S;
-  int nblk_site;
-#define OFFK_PT_PICK(i)                                                                                \
-  S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;                           \
-  S.bias_down = p.s[i].bias_down; S.wt = p.s[i].wt16;                                                  \
-  S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
-  S.nrem = p.s[i].nrem; S.rsh = p.s[i].rsh;                                                            \
-  S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
-  nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;          \
-  S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
-  S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
-  OFFK_PT_PICK(0)
+  // the block's site: nine compares on blk_begin, then ONE site's fields (the unrolled pick-by-copy of the other kernels loads
+  // every field of all nine sites first: ~7 k of this kernel's 18 k prologue cycles, and a block is only ~200 k cycles long)
+  int si = 0;
 #pragma unroll
   for (int i = 1; i < kNumSites; ++i)
-    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PT_PICK(i) }
-#undef OFFK_PT_PICK
+    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) si = i;
+  si = __builtin_amdgcn_readfirstlane(si);
+  const PtSite& S0 = p.s[si];
+  PtSite S;
+  S.bias = S0.bias; S.D = S0.D; S.M = S0.M; S.m_cs = S0.m_cs; S.bias_down = S0.bias_down; S.wt = S0.wt16;
+  S.m_coff = S0.m_coff; S.C = S0.C; S.HW = S0.HW; S.chunks = S0.chunks; S.nrem = S0.nrem; S.rsh = S0.rsh;
+  S.blk_begin = S0.blk_begin; S.nparts = S0.nparts;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { S.xp[q] = S0.xp[q]; S.cp[q] = S0.cp[q]; }
+  const int nblk_site = (si + 1 < p.nsites ? p.s[si + 1].blk_begin : p.total_blocks) - S.blk_begin;
   const int C = S.C, HW = S.HW, L = p.L;
   int local = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site);
   const int tg = local % p.tgroups; local /= p.tgroups;
