@@ -1,0 +1,15 @@
+#!/bin/bash
+# End-of-round evidence in one gpurun call: profiles/refresh_final.sh <tag>  -> gpurun_out/<tag>/
+#   bench.json (the driver's command), rocprofv3 kernel stats of the fp32 forward, PMC passes, batch table.
+set -u
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+echo "bench done"
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-secondary --steps 100 --warmup 10 > $OUT/stats.log 2>&1) || exit 1
+echo "stats done"
+bash profiles/collect_pmc.sh $TAG/pmc || exit 1
+timeout -k 10 300 python tools/bench_small.py 1,7 8,7 16,7 42,7 55,7 128,7 10,25 --fp32 > $OUT/batch_table.txt 2>&1 || exit 1
+echo "table done"
