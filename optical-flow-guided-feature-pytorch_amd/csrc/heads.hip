@@ -170,6 +170,49 @@ hipError_t pool_launch(const float* x, int x_cs, int x_coff, int n_img, int H, i
   return hipGetLastError();
 }
 
+// 28-head (RGB_OFF.py:782-787): 3x3 / stride 2 max pool (windows clipped at the border) and the sum of the pooled cells, as
+// FOUR partial rows per image -- block (image, j) takes the pool rows [j * rpb, (j + 1) * rpb), rpb = ceil(Ho / 4) -- in the
+// layout fc_pooled_kernel's tiles mode reads ([n_img * 4][C]).  256 threads = 64 channel quads x 4 window groups; a thread's
+// three or four windows are 27 - 36 independent 16-byte loads (pool_kernel walks 12 windows per thread one after the other on a
+// grid of n_img blocks: 42 us for 77 MB).
+__global__ __launch_bounds__(256) void maxpool_rows_kernel(const float* __restrict__ x, int cs, int coff, int H, int W, int C,
+                                                           float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float red[4][256];
+  const int img = blockIdx.x >> 2, j = blockIdx.x & 3, c0 = blockIdx.y * 256, tid = threadIdx.x;
+  const int q = tid & 63, g = tid >> 6;
+  const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1, rpb = (Ho + 3) / 4;
+  const int oy0 = j * rpb, nwin = max(0, min(rpb, Ho - oy0)) * Wo;
+  const float* xi = x + (size_t)img * H * W * cs + coff + c0 + 4 * q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 + 4 * q < C) {
+#pragma unroll 2
+    for (int wdw = g; wdw < nwin; wdw += 4) {
+      const int oy = oy0 + wdw / Wo, ox = wdw % Wo;
+      float4 v[9];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int y = min(2 * oy + dy, H - 1), xx = min(2 * ox + dx, W - 1);      // a clipped tap repeats its neighbour: same max
+          v[3 * dy + dx] = *reinterpret_cast<const float4*>(xi + (size_t)(y * W + xx) * cs);
+        }
+      float4 m = v[0];
+#pragma unroll
+      for (int t = 1; t < 9; ++t) m = max4(m, v[t]);
+      s = add4(s, m);
+    }
+  }
+  *reinterpret_cast<float4*>(&red[g][4 * q]) = s;
+  __syncthreads();
+  const int c = c0 + tid;
+  if (c < C) part[(size_t)blockIdx.x * C + c] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+hipError_t maxpool_rows_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, float* part, hipStream_t st) {
+  if ((C & 3) || (x_cs & 3) || (x_coff & 3) || n_img <= 0 || H < 3 || W < 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(maxpool_rows_kernel, dim3(n_img * 4, (C + 255) / 256), dim3(256), 0, st, x, x_cs, x_coff, H, W, C, part);
+  return hipGetLastError();
+}
+
 // FC half of a head: grid (image, ceil(classes / 8)); every thread takes one channel quad for eight
 // classes, so all of a block's weight loads are in flight at once (the op is pure latency), then a
 // wavefront-shuffle + LDS reduction.
@@ -233,7 +276,8 @@ __global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* _
     ps[j] = tiles ? part + ((size_t)img * 4 + j) * C + 4 * kq : part + ((size_t)sl * 2 + slot) * C + 4 * kq;
     pw[j] = tiles || s_lo + j <= s_hi ? 1.f : 0.f;
   }
-  const int kbeg = wave * (C / kFcWaves), kend = kbeg + C / kFcWaves;
+  const int per = ((C / kFcWaves + 63) / 64) * 64;       // a wave's K slice: whole batches of 64 channels (C < 512: the last waves idle)
+  const int kbeg = wave * per, kend = min(C, kbeg + per);
   const float* w0 = fw + (size_t)min(cls0 + li, ncls - 1) * C + 4 * kq;
   const float* w1 = fw + (size_t)min(cls0 + 16 + li, ncls - 1) * C + 4 * kq;
   fcx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -277,7 +321,7 @@ __global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* _
 }
 hipError_t fc_pooled_launch(const float* part, int hw, int tiles, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
                             hipStream_t st) {
-  if (C % (64 * kFcWaves) || hw < 32 || n_img <= 0 || ncls <= 0) return hipErrorInvalidValue;
+  if (C % 64 || hw < 32 || n_img <= 0 || ncls <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fc_pooled_kernel, dim3((n_img + 15) / 16, (ncls + 31) / 32), dim3(64 * kFcWaves), 0, st, part, hw, tiles, n_img, C, fw, fb, ncls, out);
   return hipGetLastError();
 }

@@ -140,9 +140,9 @@ struct offk_handle {
   float* merged_b[3] = {};
   int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};   // kMergedPlan at offk_create
   bool merged_dirty = true;
-  // the 28- and 14-heads only depend on sum_28c / sum_14b: they run on a side stream beside the later
-  // fusion stages and are joined back into the caller's stream before offk_forward returns
-  hipStream_t side = nullptr;   // stays null with OFFK_SIDE_STREAM=0 in the environment at offk_create: heads on the caller's stream
+  // the 28- and 14-heads only depend on sum_28c / sum_14b: they CAN run on a side stream beside the later
+  // fusion stages, joined back into the caller's stream before offk_forward returns
+  hipStream_t side = nullptr;   // created with OFFK_SIDE_STREAM=1 in the environment at offk_create; null: heads on the caller's stream
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
   hipStream_t pipe = nullptr;   // second half of the two-half fusion pipeline (offk_forward); only with OFFK_PIPELINE=1 at offk_create
   hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
@@ -285,6 +285,7 @@ void plan_workspace(offk_handle* h) {
   add_region(h, "pooled_7", P * 1024);
   add_region(h, "pooled_14", P * 512);
   add_region(h, "pooled_28", P * 256);
+  add_region(h, "poolpart_28", (size_t)4 * P * 256);   // 28-head: max-pooled cells summed per block of pool rows (maxpool_rows_kernel)
   // average pools of the 7- and 14-heads folded into the producing conv: per 32-row slab, two partial column sums
   add_region(h, "poolpart_7", ((P * 49 + 31) / 32) * 2 * 1024);
   add_region(h, "poolpart_14", ((P * 49 + 31) / 32) * 2 * 512);
@@ -744,7 +745,9 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
-  if (!(side_env && *side_env == '0') &&
+  // (opt-in since the heads became three short launches -- pool sums in conv epilogues / maxpool_rows_kernel, FC on MFMA: in
+  //  line they cost 17 us at B = 64; beside the fusion convs they slowed those by more, 4.30 vs 4.29 ms, B = 1: 0.80 vs 0.77 ms)
+  if (side_env && *side_env == '1' &&
       (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
        hipEventCreateWithFlags(&h->ev_fork[0], hipEventDisableTiming) != hipSuccess ||
        hipEventCreateWithFlags(&h->ev_fork[1], hipEventDisableTiming) != hipSuccess ||
@@ -1205,7 +1208,14 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
         HIP_TRY(h, hipEventRecord(h->ev_fork[0], s));
         HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[0], 0));
       }
-      TRY(run_head(hs, 1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28, i0, n));
+      if (h->fold_pool) {     // pool-row partial sums + the FC as an MFMA GEMM (heads.hip) instead of pool_kernel + fc_kernel
+        float* pp = region(h, ws, "poolpart_28") + (size_t)4 * i0 * 256;
+        TRY(trace_mark(h, hs, "head_28 (max pool rows + fc)"));
+        HIP_TRY(h, maxpool_rows_launch(F14 + (size_t)i0 * 196 * 1056, 1056, 800, n, 14, 14, 256, pp, hs));
+        HIP_TRY(h, fc_pooled_launch(pp, 49, 1, n, 256, h->fc_w[1], h->fc_b[1], ncls, l28 + (size_t)i0 * ncls, hs));
+      } else {
+        TRY(run_head(hs, 1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28, i0, n));
+      }
     }
     // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
     float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);

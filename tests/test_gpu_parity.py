@@ -377,16 +377,15 @@ def test_full_size_b64_vs_oracle(rt, prec):
 
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_side_stream_heads_bit_identical(rt, prec, monkeypatch):
-    """The 28- and 14-heads run on the handle's side stream beside fusion@14/@7 (offk_api.hip).  Repeated
-    full-size forwards must give the same bits as a handle created with OFFK_SIDE_STREAM=0 (everything on
-    the caller's stream).  Guards the fork/join events and the co-residency of the head kernels with the
+    """With OFFK_SIDE_STREAM=1 the 28- and 14-heads run on the handle's side stream beside fusion@14/@7 (offk_api.hip).
+    Repeated full-size forwards must give the same bits as the default handle (everything on the caller's stream).  Guards the fork/join events and the co-residency of the head kernels with the
     MFMA convs (packed op_sel FMAs were wrong there; heads.hip builds without them)."""
     B, L = 64, 7
     feats = [dev(f) for f in synth.make_features(B, L, 2)]
-    monkeypatch.setenv("OFFK_SIDE_STREAM", "0")
     h0, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
-    monkeypatch.delenv("OFFK_SIDE_STREAM")
+    monkeypatch.setenv("OFFK_SIDE_STREAM", "1")
     h1, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    monkeypatch.delenv("OFFK_SIDE_STREAM")
     ref = [t.clone() for t in h0.forward(feats)]
     side = torch.cuda.Stream()
     for it in range(6):
