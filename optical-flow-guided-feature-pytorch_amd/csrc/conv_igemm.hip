@@ -1277,10 +1277,14 @@ static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out, int precision) {
   static const int cand[] = {1, 2, 3, 4, 6, 8, 12};
   if (precision == 0) {
+    // 64x64 tile, split to >= 3500 blocks with >= 24 K-tiles per slice (in-situ sweeps at B = 42 / 64); while the grid does not
+    // even cover the chip twice (small batches: the 7x7 conv of ONE clip is 19 tiles x 490 K-tiles) slices go down to 16 K-tiles
+    // (tools/sweep_splitk_small.py: B = 1, 7x7 48 us at 32 slices, 42 at 12 - 24; 5x5 52 us at 64, 40 - 48 at 24 - 48)
+    static const int cand32[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const long long blocks = ((M + 63) / 64) * (Co / 64);
     int sk = 1;
-    for (int c : cand) {
-      if (c > 1 && nkt / c < 24) break;
+    for (int c : cand32) {
+      if (c > 1 && nkt / c < (blocks * sk < 512 ? 16 : 24)) break;
       sk = c;
       if (blocks * c >= 3500) break;
     }
@@ -1365,7 +1369,8 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
     if (d.pool_hw < 32 || cfg == 6 || cfg == 7 || cfg == 10) { *why = "conv2d: pooled partial sums need >= 32 rows per image and a generic tile"; return hipErrorInvalidValue; }
     sk = 1;                               // the sums are taken in the epilogue of an unsplit conv
   }
-  if (sk > 1 && (!d.partial || d.partial_floats < (size_t)sk * (size_t)M * d.Co)) sk = 1;   // no slab space: unsplit
+  if (sk > 1 && !d.partial) sk = 1;                                                          // no slab space: unsplit
+  while (sk > 1 && d.partial_floats < (size_t)sk * (size_t)M * d.Co) --sk;                   // ... or as many slices as fit
   a.splitk = sk; a.partial = d.partial; a.gm = a.gn = 0;
 #ifdef OFFK_TUNING_KNOBS
   { const char* e = getenv("OFFK_CONV_ABLATE"); a.ablate = e ? atoi(e) : 0; }

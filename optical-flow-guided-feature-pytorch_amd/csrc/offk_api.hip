@@ -153,6 +153,7 @@ struct offk_handle {
   bool winograd = true;          // fp32: Winograd F(4x4, 3x3) for the three 3x3 / stride 1 convs on 7x7 maps (winograd.hip); OFFK_WINOGRAD=0: direct
   float* wino_u[6] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; [36][Co][4 Ci] of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
+  int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
   int wino_cfg = 3;              // tile of the 36 batched GEMMs (OFFK_WINO_CFG at offk_create: tools)
   int wino_cfg_small = 3;        // the same for the short-K ones (K <= 256; OFFK_WINO_CFG_SMALL)
@@ -296,9 +297,9 @@ void plan_workspace(offk_handle* h) {
     add_region(h, "wino_m", (size_t)36 * 4 * P * 512);
     add_region(h, "poolpart_14t", (size_t)4 * P * 512);
   }
-  // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64],
-  // 3x3 @7: [P*49, 256]); a conv whose plan needs more falls back to fewer slices
-  h->splitk_floats = 8 * P * 196 * 64;
+  // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64], 3x3 @7: [P*49, 256]) -- up
+  // to 64 at small P, where the plans split deeper (conv2d_auto_plan); a conv whose plan needs more gets as many as fit
+  h->splitk_floats = (size_t)std::min<size_t>(64, std::max<size_t>(8, 1536 / P)) * P * 196 * 64;
   add_region(h, "splitk", h->splitk_floats + 128);     // + slack: the two-half pipeline cuts the slab at a 64-float boundary
   h->ws_bytes = align_up(h->ws_bytes, 256);
 
@@ -735,7 +736,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
-  { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino5_min_p = atoi(e); }
   { const char* e = getenv("OFFK_WINO_CFG_SMALL"); if (e && *e >= '0' && *e <= '5') h->wino_cfg_small = *e - '0'; }
   { const char* e = getenv("OFFK_WINO_CFG"); if (e && *e >= '0' && *e <= '5') h->wino_cfg = *e - '0'; }
   if (h->winograd) {
@@ -1185,7 +1186,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
       if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
       return OFFK_OK;
     };
-    const bool chained = h->chain && h->cfg.precision == OFFK_PRECISION_FP32 && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
+    // (from P = 72 pairs: a chain block walks its three convs alone -- 45 us per launch however few blocks there are; B = 8: three
+    //  convs per chain 0.885 ms per forward against 0.90, B = 16: 1.37 against 1.345.  h->P, not n: the plan of a split call is the whole call's)
+    const bool chained = h->chain && h->P >= 72 && h->cfg.precision == OFFK_PRECISION_FP32 && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
     if (chained) {
       TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt_, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
                 nullptr, sa_, 256, 0));                                                              // :658-667
@@ -1219,9 +1222,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     }
     // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
     float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);
-    // (from P = 96 pairs: below, its 132-K-tile GEMMs have too few row tiles to fill the chip and the split-K direct conv wins --
-    // B = 1: 0.81 vs 1.04 ms, B = 8: 1.15 vs 1.37 ms, B = 16: equal; profiles/r03/batch_table_fp32_*.txt)
-    if (wino && h->wino_5x5 && h->P >= 96) TRY(wino_conv(C_T14, 5, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128, nullptr));   // :762-763 x1 (polyphase)
+    // (from P = 40 pairs: below, its 132-K-tile GEMMs have too few row tiles to fill the chip and the split-K direct conv wins --
+    // B = 1: 0.435 vs 0.50 ms, B = 4: 0.672 vs 0.695, B = 8: 0.892 vs 0.874, B = 12: 1.157 vs 1.12; OFFK_WINOGRAD_5X5=<pairs> moves the gate)
+    if (wino && h->wino_5x5 && h->P >= h->wino5_min_p) TRY(wino_conv(C_T14, 5, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128, nullptr));   // :762-763 x1 (polyphase)
     else
     TRY(conv(h, s, C_T14, n, 14, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128));          // :762-763 x1
     TRY(conv(h, s, C1_14A, n, 7, View{xu_, 256, 128}, nullptr, 0, 0, RP, u1_, 128, 0));            // :764-765
