@@ -16,14 +16,14 @@
  *  - the caller owns every data buffer (device pointers, e.g. torch tensor.data_ptr());
  *    the library owns the handle and its packed weight copies only.
  *  - all work is enqueued asynchronously on the hipStream_t passed as `void* stream`
- *    (NULL = default stream); there is no implicit synchronisation.  offk_forward forks its two
- *    side heads onto a stream the handle owns (event fork / event join, both inside the call):
- *    seen from the caller everything is ordered on `stream`, and the call can be stream-captured.
- *    OFFK_SIDE_STREAM=0 in the environment at offk_create disables the fork.
+ *    (NULL = default stream); there is no implicit synchronisation.  With OFFK_SIDE_STREAM=1 in the
+ *    environment at offk_create, offk_forward forks its two side heads onto a stream the handle owns
+ *    (event fork / event join, both inside the call): seen from the caller everything is still ordered
+ *    on `stream`, and the call can be stream-captured.  Default: everything on `stream`.
  *  - offk_forward runs the units as ONE kernel that fuses the 1x1 reduces with the temporal difference (the gen output G
  *    never goes to HBM) plus the spatial half of K2; OFFK_FUSED_UNITS=0 in the environment at offk_create selects the
  *    two-kernel form (K1 then K2), which offk_off_units / offk_off_units_train always use (the backward needs G).  Both
- *    give the same bits.
+ *    give the same bits (to 2e-6 in fp32, whose default fused kernel groups k differently: OFFK_PW_DMA).
  *  - a handle is not thread-safe; distinct handles are independent.
  *  - fp32 everywhere.  Boundary tensors are NCHW contiguous exactly as the reference
  *    backbone produces them; INTERNAL activations (workspace, stage entry points) are
