@@ -176,13 +176,16 @@ def launch_work(P):
 
 
 WINOGRAD_CONVS = ("motion_conv2_trans_14a", "motion_conv2_trans_14b", "motion_conv3_trans_14b", "motion_conv_trans",
-                  "motion_conv2_trans", "motion_conv_trans_14")
+                  "motion_conv2_trans", "motion_conv_trans_14", "motion_conv_trans_28")
+POLYPHASE_MIN_PAIRS = {"motion_conv_trans_14": 40, "motion_conv_trans_28": 12}   # the polyphase forms are used from this many pairs (offk_api.hip)
 
 
 def winograd_gemm_flops(P, key):
     """FLOPs of the 36 batched GEMMs [4P tiles][K] x [K][Co] of a conv on the Winograd path: K = Ci for a 3x3 / stride 1
     conv on 7x7 maps, 4 Ci for the polyphase form of the 5x5 / stride 2 conv (four 7x7 phase images concatenated along K)."""
     co, ci, k = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
+    if k == 7:      # F(4x4, 4x4) on four 14x14 phase images: 16 tiles per 14x14 output map, 169 of 196 (point, phase) products
+        return 2.0 * 16 * P * 169 * ci * co
     # polyphase: 121 of the 144 (point, phase) products -- the others have an identically zero transformed kernel and are skipped
     return 2.0 * 4 * P * (121 * ci if k == 5 else 36 * ci) * co
 
@@ -191,7 +194,10 @@ def winograd_saved_flops(P):
     """Direct-conv FLOPs minus the FLOPs of the 36 batched GEMMs (4 tiles of 4x4 outputs per 7x7 map) for the convs the fp32
     path runs as Winograd F(4x4, 3x3) (csrc/winograd.hip)."""
     w = launch_work(P)
-    return sum(w[k] - winograd_gemm_flops(P, k) for k in WINOGRAD_CONVS)
+    on = [k for k in WINOGRAD_CONVS if not (k == "motion_conv_trans_28" and os.environ.get("OFFK_WINOGRAD_7X7", "1") == "0")
+          and not (k == "motion_conv_trans_14" and os.environ.get("OFFK_WINOGRAD_5X5", "1") == "0")
+          and not P < POLYPHASE_MIN_PAIRS.get(k, 0)]
+    return sum(w[k] - winograd_gemm_flops(P, k) for k in on)
 
 
 def roofline_in_path(h, arr, out, B, L, precision, steps):
@@ -235,10 +241,14 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             # they move (V written / M read; the 7x7 map side is a fraction of that)
             key = name.split(" ")[0]
             co, ci, ksz = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
-            T = 4 * P
+            T = 16 * P if ksz == 7 else 4 * P
             if ksz == 5:
                 ci *= 4           # polyphase: four 7x7 phase images along K
-            if "GEMMs" in name:
+            if ksz == 7 and "GEMMs" not in name:
+                # F(4x4, 4x4), four 14x14 phase images: 169 transformed floats per (tile, channel); 49 GEMM outputs per (tile, co)
+                nbytes = (T * 169 * ci + P * 784 * ci) * 4 if "input" in name else (49 * T * co + P * 196 * co) * 4
+                rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
+            elif "GEMMs" in name:
                 fl = winograd_gemm_flops(P, key)
                 rec.update(bound="mfma", flops=fl, direct_conv_flops=work[key], achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
                 small_ms += avg if key not in big else 0.0
@@ -576,11 +586,17 @@ def main():
                      "executed_flops_per_step": ((unit_f + fus_f) * B - winograd_saved_flops(B * (L - 1))
                                                  if args.precision == "fp32" and os.environ.get("OFFK_WINOGRAD", "1") != "0"
                                                  else (unit_f + fus_f) * B),
+                     "executed_frac_of_peak": (((unit_f + fus_f) * B - winograd_saved_flops(B * (L - 1))
+                                                if args.precision == "fp32" and os.environ.get("OFFK_WINOGRAD", "1") != "0"
+                                                else (unit_f + fus_f) * B) / (ms_step * 1e-3) / 1e12 /
+                                               (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0) / world),
                      "note": "algorithmic (direct-convolution) fp32 FLOPs / summed stage time; whole_forward_frac_of_peak = "
                              "the same FLOPs / the wall-clock ms_per_step / peak; bf16x3 peak = dense bf16 MFMA peak / 3 "
-                             "products.  In fp32 the five 3x3 / stride 1 convs on 7x7 maps run as Winograd F(4x4, 3x3) "
-                             "(fp32 arithmetic, 1 / 3.06 of their multiplies): executed_flops_per_step is what the matrix "
-                             "pipe is asked to do, so the algorithmic fraction can exceed any kernel's MFMA-busy share"},
+                             "products.  In fp32 the five 3x3 / stride 1 convs on 7x7 maps and, in polyphase form, the 5x5 / stride 2 conv "
+                             "run as Winograd F(4x4, 3x3), the 7x7 / stride 2 conv as polyphase F(4x4, 4x4) (fp32 arithmetic; 1 / 3.06, "
+                             "1 / 2.1 and 1 / 3.55 of their multiplies): executed_flops_per_step is what the matrix "
+                             "pipe is asked to do (executed_frac_of_peak = that / ms_per_step / peak), so the algorithmic fraction can "
+                             "exceed any kernel's MFMA-busy share -- and 1"},
         }
         if in_path is not None:
             res["roofline_in_path"] = in_path

@@ -151,6 +151,9 @@ struct offk_handle {
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
   bool winograd = true;          // fp32: Winograd F(4x4, 3x3) for the three 3x3 / stride 1 convs on 7x7 maps (winograd.hip); OFFK_WINOGRAD=0: direct
+  float* wino_u7 = nullptr;      // transformed weights of C_T28 in the four groups of winograd7.hip (169 x Co x Ci floats)
+  bool wino_7x7 = true;          // the 7x7 / stride 2 conv of fusion@28 in polyphase Winograd form F(4x4, 4x4) (OFFK_WINOGRAD_7X7=0: direct)
+  int wino7_min_p = 12;          // ... from this many pairs (OFFK_WINOGRAD_7X7=<n> with n > 1 at offk_create: tools)
   float* wino_u[6] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; [36][Co][4 Ci] of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
@@ -293,8 +296,9 @@ void plan_workspace(offk_handle* h) {
   // Winograd path of the 3x3 convs at 7x7 (fp32): transformed input [36][4 P][Ci <= 832], GEMM output [36][4 P][Co <= 512],
   // per-tile sums of sum_14b for the 14-head
   if (h->cfg.precision == OFFK_PRECISION_FP32) {
-    add_region(h, "wino_v", (size_t)36 * 4 * P * 4224);      // widest: the polyphase 5x5 / 2 conv, K = 4 x 1056
-    add_region(h, "wino_m", (size_t)36 * 4 * P * 512);
+    // widest: the polyphase 7x7 / 2 conv (16 P tiles x 169 x 320 floats: 1.33 GB at P = 384), then the polyphase 5x5 / 2 conv (K = 4 x 1056)
+    add_region(h, "wino_v", std::max((size_t)36 * 4 * P * 4224, (size_t)kWino7Tiles * P * kWino7Units * 320));
+    add_region(h, "wino_m", (size_t)36 * 4 * P * 512);       // (7x7: 49 x 16 P x 64 is smaller)
     add_region(h, "poolpart_14t", (size_t)4 * P * 512);
   }
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64], 3x3 @7: [P*49, 256]) -- up
@@ -619,6 +623,7 @@ int finalize_wino(offk_handle* h, hipStream_t st) {
   const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
   for (int k = 0; k < 6; ++k)
     HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, k == 5 ? 4 : 1, h->wino_u[k], st));
+  if (h->wino_u7) HIP_TRY(h, wino7_weight_launch(h->conv_w[C_T28], kConvs[C_T28].Co, kConvs[C_T28].Ci, h->wino_u7, st));
   h->wino_dirty = false;
   return OFFK_OK;
 }
@@ -737,12 +742,14 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
   { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino5_min_p = atoi(e); }
+  { const char* e = getenv("OFFK_WINOGRAD_7X7"); h->wino_7x7 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino7_min_p = atoi(e); }
   { const char* e = getenv("OFFK_WINO_CFG_SMALL"); if (e && *e >= '0' && *e <= '5') h->wino_cfg_small = *e - '0'; }
   { const char* e = getenv("OFFK_WINO_CFG"); if (e && *e >= '0' && *e <= '5') h->wino_cfg = *e - '0'; }
   if (h->winograd) {
     const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
     for (int k = 0; k < 6; ++k)
       if (dev_alloc(h, &h->wino_u[k], (size_t)36 * kConvs[wid[k]].Co * kConvs[wid[k]].Ci * (k == 5 ? 4 : 1)) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
   }
   plan_workspace(h);
   const char* side_env = getenv("OFFK_SIDE_STREAM");
@@ -1166,7 +1173,41 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
     float *xt_ = at(xt, 14, 128), *t1_ = at(t1, 14, 64), *sa_ = at(sa, 14, 256), *sb_ = at(sb, 14, 256);
     float *F28_ = at(F28, 28, 320), *F14_ = at(F14, 14, 1056), *F7_ = at(F7, 7, 832);
-    TRY(conv(h, s, C_T28, n, 28, View{F28_, 320, 0}, nullptr, 0, 0, 0, xt_, 128, 64));             // :657 x0, pre-ReLU kept for the branch
+    // :657 x0, pre-ReLU kept for the branch.  fp32: polyphase Winograd F(4x4, 4x4) (winograd7.hip) -- input transform, 49 batched
+    // GEMMs in four K groups as ONE launch of the 1x1 kernel, output transform
+    // (from P = 12 pairs -- B = 2: 0.495 against 0.503 ms, B = 8: 0.813 against 0.874, B = 64: 3.88 against 4.24; B = 1: equal)
+    if (h->wino_u7 && h->winograd && h->P >= h->wino7_min_p) {
+      const ConvSpec& c = kConvs[C_T28];
+      const int T = kWino7Tiles * n;
+      float* V = region(h, ws, "wino_v") + (size_t)kWino7Tiles * i0 * kWino7Units * 320;
+      float* M = region(h, ws, "wino_m") + (size_t)kWino7Points * kWino7Tiles * i0 * 64;
+      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
+      HIP_TRY(h, wino7_input_launch(F28_, 320, 0, n, c.Ci, V, s));
+      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 49 GEMMs]").c_str()));
+      WinoGroup grp[4];
+      const int ngrp = wino7_groups(T, c.Ci, c.Co, grp);
+      {
+        const int K0 = grp[0].kmul * c.Ci;
+        ConvDesc d;
+        d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = K0;
+        d.w = h->wino_u7; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+        d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+        d.y = M; d.y_cs = c.Co; d.y_coff = 0;
+        d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
+        d.batch = kWino7Points; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
+        d.ngroups = ngrp;
+        for (int gi = 0; gi < ngrp; ++gi) {
+          d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * c.Ci;
+          d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
+        }
+        const char* why = nullptr;
+        hipError_t e = conv2d_launch(d, s, &why);
+        if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
+      }
+      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()));
+      HIP_TRY(h, wino7_output_launch(M, n, c.Co, h->conv_b[C_T28], 0, xt_, 128, 64, s));
+    } else
+    TRY(conv(h, s, C_T28, n, 28, View{F28_, 320, 0}, nullptr, 0, 0, 0, xt_, 128, 64));
     if (after_first) HIP_TRY(h, hipEventRecord(after_first, s));
     // 1x1 -> 3x3 -> 1x1 (+ residual) as ONE launch per chain (exact fp32; a block owns half an image, t1 / t2 stay in LDS)
     auto chain = [&](const char* name, const float* x, int x_cs, int x_coff, int Cin, int relu_in, ConvId c1, ConvId c2,
@@ -1563,6 +1604,47 @@ int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_c
                             int y_cstride, int y_coff, float* scratch, size_t scratch_floats) {
   return winograd_entry("offk_winograd_conv5x5s2", stream, x, x_cstride, x_coff, n_img, Ci, 4, w_packed, bias, Co, res, res_cstride,
                         res_coff, flags, y, y_cstride, y_coff, scratch, scratch_floats, nullptr);
+}
+
+int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, const float* w_packed,
+                            const float* bias, int Co, int flags, float* y, int y_cstride, int y_coff, float* scratch,
+                            size_t scratch_floats) {
+  const char* who = "offk_winograd_conv7x7s2";
+  if (!x || !w_packed || !y || !scratch || n_img < 1 || Ci < 32 || (Ci & 31) || Co < 64 || (Co & 63) || (flags & OFFK_CONV_RELU_IN_))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument (Ci % 32 == 0, Co % 64 == 0, no RELU_IN)");
+  const size_t T = (size_t)kWino7Tiles * n_img;
+  const size_t need = (size_t)kWino7Units * Ci * (Co + T) + (size_t)kWino7Points * T * Co;
+  if (scratch_floats < need) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* U = scratch;
+  float* V = U + (size_t)kWino7Units * Co * Ci;
+  float* M = V + (size_t)kWino7Units * T * Ci;
+  hipError_t e = wino7_weight_launch(w_packed, Co, Ci, U, st);
+  if (e == hipSuccess) e = wino7_input_launch(x, x_cstride, x_coff, n_img, Ci, V, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  WinoGroup grp[4];
+  const int ngrp = wino7_groups((long long)T, Ci, Co, grp);
+  {
+    const int K0 = grp[0].kmul * Ci;
+    ConvDesc d;
+    d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = K0;
+    d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+    d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+    d.y = M; d.y_cs = Co; d.y_coff = 0;
+    d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+    d.batch = kWino7Points; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)T * Co;
+    d.ngroups = ngrp;
+    for (int gi = 0; gi < ngrp; ++gi) {
+      d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
+      d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
+    }
+    const char* why = nullptr;
+    e = conv2d_launch(d, st, &why);
+    if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
+  }
+  e = wino7_output_launch(M, n_img, Co, bias, flags, y, y_cstride, y_coff, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  return OFFK_OK;
 }
 
 int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int splitk) {

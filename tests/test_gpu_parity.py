@@ -887,3 +887,26 @@ def test_winograd_conv5x5s2_vs_torch(rt, ci, co, n):
     print("polyphase winograd 5x5/2 %d -> %d n=%d: max error / max |ref| = %.2e" % (ci, co, n, err))
     assert err < RTOL
     assert torch.all(ybuf[..., :96] == -3.0)
+
+
+@pytest.mark.parametrize("ci,co,n,relu", [(32, 64, 1, False), (320, 64, 3, False), (64, 128, 2, True)])
+def test_winograd_conv7x7s2_vs_torch(rt, ci, co, n, relu):
+    """offk_winograd_conv7x7s2 -- the polyphase Winograd form F(4x4, 4x4) of motion_conv_trans_28 (RGB_OFF.py:657: 7x7, stride 2,
+    pad 3, 28x28 -> 14x14; four 14x14 phase images x 4-tap phase kernels concatenated along K, 49 points in four K groups) --
+    against torch CPU fp32 F.conv2d, input from a channel slice, output into a channel slice (the [t2 | x0] buffer of the forward)."""
+    g = torch.Generator().manual_seed(7 * ci + co)
+    x = torch.randn(n, 28, 28, ci + 32, generator=g).clamp_min(0)
+    w = (torch.rand(co, ci, 7, 7, generator=g) * 2 - 1) / (49 * ci) ** 0.5
+    b = (torch.rand(co, generator=g) * 2 - 1) / (49 * ci) ** 0.5
+    xin = x[..., 32:].permute(0, 3, 1, 2).contiguous()
+    want = F.conv2d(xin, w, b, stride=2, padding=3)
+    if relu:
+        want = F.relu(want)
+    want = want.permute(0, 2, 3, 1)
+    ybuf = torch.full((n, 14, 14, co + 64), -3.0, device="cuda")
+    rt.winograd_conv7x7s2(dev(x), dev(w), dev(b), flags=2 if relu else 0, x_coff=32, y=ybuf, y_coff=64)
+    torch.cuda.synchronize()
+    err = rel_err(ybuf[..., 64:], want)
+    print("polyphase winograd 7x7/2 %d -> %d n=%d: max error / max |ref| = %.2e" % (ci, co, n, err))
+    assert err < RTOL
+    assert torch.all(ybuf[..., :64] == -3.0)
