@@ -184,8 +184,8 @@ def winograd_gemm_flops(P, key):
     """FLOPs of the 36 batched GEMMs [4P tiles][K] x [K][Co] of a conv on the Winograd path: K = Ci for a 3x3 / stride 1
     conv on 7x7 maps, 4 Ci for the polyphase form of the 5x5 / stride 2 conv (four 7x7 phase images concatenated along K)."""
     co, ci, k = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
-    if k == 7:      # F(4x4, 4x4) on four 14x14 phase images: 16 tiles per 14x14 output map, 169 of 196 (point, phase) products
-        return 2.0 * 16 * P * 169 * ci * co
+    if k == 7:      # F(5x5, 4x4) on four 14x14 phase images: 9 tiles per 14x14 output map, 225 of 256 (point, phase) products
+        return 2.0 * 9 * P * 225 * ci * co
     # polyphase: 121 of the 144 (point, phase) products -- the others have an identically zero transformed kernel and are skipped
     return 2.0 * 4 * P * (121 * ci if k == 5 else 36 * ci) * co
 
@@ -241,12 +241,12 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             # they move (V written / M read; the 7x7 map side is a fraction of that)
             key = name.split(" ")[0]
             co, ci, ksz = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
-            T = 16 * P if ksz == 7 else 4 * P
+            T = 9 * P if ksz == 7 else 4 * P
             if ksz == 5:
                 ci *= 4           # polyphase: four 7x7 phase images along K
             if ksz == 7 and "GEMMs" not in name:
-                # F(4x4, 4x4), four 14x14 phase images: 169 transformed floats per (tile, channel); 49 GEMM outputs per (tile, co)
-                nbytes = (T * 169 * ci + P * 784 * ci) * 4 if "input" in name else (49 * T * co + P * 196 * co) * 4
+                # F(5x5, 4x4), four 14x14 phase images: 225 transformed floats per (tile, channel); 64 GEMM outputs per (tile, co)
+                nbytes = (T * 225 * ci + P * 784 * ci) * 4 if "input" in name else (64 * T * co + P * 196 * co) * 4
                 rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
             elif "GEMMs" in name:
                 fl = winograd_gemm_flops(P, key)
@@ -593,8 +593,8 @@ def main():
                      "note": "algorithmic (direct-convolution) fp32 FLOPs / summed stage time; whole_forward_frac_of_peak = "
                              "the same FLOPs / the wall-clock ms_per_step / peak; bf16x3 peak = dense bf16 MFMA peak / 3 "
                              "products.  In fp32 the five 3x3 / stride 1 convs on 7x7 maps and, in polyphase form, the 5x5 / stride 2 conv "
-                             "run as Winograd F(4x4, 3x3), the 7x7 / stride 2 conv as polyphase F(4x4, 4x4) (fp32 arithmetic; 1 / 3.06, "
-                             "1 / 2.1 and 1 / 3.55 of their multiplies): executed_flops_per_step is what the matrix "
+                             "run as Winograd F(4x4, 3x3), the 7x7 / stride 2 conv as polyphase F(5x5, 4x4) (fp32 arithmetic; 1 / 3.06, "
+                             "1 / 2.1 and 1 / 4.7 of their multiplies): executed_flops_per_step is what the matrix "
                              "pipe is asked to do (executed_frac_of_peak = that / ms_per_step / peak), so the algorithmic fraction can "
                              "exceed any kernel's MFMA-busy share -- and 1"},
         }

@@ -255,10 +255,10 @@ int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_c
                             const float* res, int res_cstride, int res_coff, int flags,
                             float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats);
 
-/* The 7x7 / stride 2 / pad 3 conv on 28x28 maps (motion_conv_trans_28, RGB_OFF.py:657) in polyphase Winograd form F(4x4, 4x4):
- * four 14x14 phase images x 4x4 phase kernels concatenated along K, 16 output tiles of 4x4 per image, 49 points (winograd7.hip).
+/* The 7x7 / stride 2 / pad 3 conv on 28x28 maps (motion_conv_trans_28, RGB_OFF.py:657) in polyphase Winograd form F(5x5, 4x4):
+ * four 14x14 phase images x 4x4 phase kernels concatenated along K, 9 output tiles of 5x5 per image, 64 points (winograd7.hip).
  * x: [n_img * 784][x_cstride]; y: [n_img * 196][y_cstride]; w_packed: the packed 7x7 weight [Co][Ci/32][49][32]; flags: ReLU
- * (PRE / POST; no residual input); scratch: 169 * Ci * (Co + 16 * n_img) + 49 * 16 * n_img * Co floats. */
+ * (PRE / POST; no residual input); scratch: 225 * Ci * (Co + 9 * n_img) + 64 * 9 * n_img * Co floats. */
 int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
                             const float* w_packed, const float* bias, int Co, int flags,
                             float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats);

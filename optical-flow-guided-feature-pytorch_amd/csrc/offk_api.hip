@@ -151,8 +151,8 @@ struct offk_handle {
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
   bool fused_units = true;       // forward: K1 fused with the temporal difference (OFFK_FUSED_UNITS=0 at offk_create: K1 + K2)
   bool winograd = true;          // fp32: Winograd F(4x4, 3x3) for the three 3x3 / stride 1 convs on 7x7 maps (winograd.hip); OFFK_WINOGRAD=0: direct
-  float* wino_u7 = nullptr;      // transformed weights of C_T28 in the four groups of winograd7.hip (169 x Co x Ci floats)
-  bool wino_7x7 = true;          // the 7x7 / stride 2 conv of fusion@28 in polyphase Winograd form F(4x4, 4x4) (OFFK_WINOGRAD_7X7=0: direct)
+  float* wino_u7 = nullptr;      // transformed weights of C_T28 in the four groups of winograd7.hip (225 x Co x Ci floats)
+  bool wino_7x7 = true;          // the 7x7 / stride 2 conv of fusion@28 in polyphase Winograd form F(5x5, 4x4) (OFFK_WINOGRAD_7X7=0: direct)
   int wino7_min_p = 12;          // ... from this many pairs (OFFK_WINOGRAD_7X7=<n> with n > 1 at offk_create: tools)
   float* wino_u[6] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; [36][Co][4 Ci] of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
@@ -296,9 +296,9 @@ void plan_workspace(offk_handle* h) {
   // Winograd path of the 3x3 convs at 7x7 (fp32): transformed input [36][4 P][Ci <= 832], GEMM output [36][4 P][Co <= 512],
   // per-tile sums of sum_14b for the 14-head
   if (h->cfg.precision == OFFK_PRECISION_FP32) {
-    // widest: the polyphase 7x7 / 2 conv (16 P tiles x 169 x 320 floats: 1.33 GB at P = 384), then the polyphase 5x5 / 2 conv (K = 4 x 1056)
+    // widest: the polyphase 7x7 / 2 conv (9 P tiles x 225 x 320 floats: 1.0 GB at P = 384), then the polyphase 5x5 / 2 conv (K = 4 x 1056)
     add_region(h, "wino_v", std::max((size_t)36 * 4 * P * 4224, (size_t)kWino7Tiles * P * kWino7Units * 320));
-    add_region(h, "wino_m", (size_t)36 * 4 * P * 512);       // (7x7: 49 x 16 P x 64 is smaller)
+    add_region(h, "wino_m", (size_t)36 * 4 * P * 512);       // (7x7: 64 x 9 P x 64 is smaller)
     add_region(h, "poolpart_14t", (size_t)4 * P * 512);
   }
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64], 3x3 @7: [P*49, 256]) -- up
@@ -1173,7 +1173,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
     float *xt_ = at(xt, 14, 128), *t1_ = at(t1, 14, 64), *sa_ = at(sa, 14, 256), *sb_ = at(sb, 14, 256);
     float *F28_ = at(F28, 28, 320), *F14_ = at(F14, 14, 1056), *F7_ = at(F7, 7, 832);
-    // :657 x0, pre-ReLU kept for the branch.  fp32: polyphase Winograd F(4x4, 4x4) (winograd7.hip) -- input transform, 49 batched
+    // :657 x0, pre-ReLU kept for the branch.  fp32: polyphase Winograd F(5x5, 4x4) (winograd7.hip) -- input transform, 64 batched
     // GEMMs in four K groups as ONE launch of the 1x1 kernel, output transform
     // (from P = 12 pairs -- B = 2: 0.495 against 0.503 ms, B = 8: 0.813 against 0.874, B = 64: 3.88 against 4.24; B = 1: equal)
     if (h->wino_u7 && h->winograd && h->P >= h->wino7_min_p) {
@@ -1183,7 +1183,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
       float* M = region(h, ws, "wino_m") + (size_t)kWino7Points * kWino7Tiles * i0 * 64;
       TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
       HIP_TRY(h, wino7_input_launch(F28_, 320, 0, n, c.Ci, V, s));
-      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 49 GEMMs]").c_str()));
+      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 64 GEMMs]").c_str()));
       WinoGroup grp[4];
       const int ngrp = wino7_groups(T, c.Ci, c.Co, grp);
       {

@@ -73,9 +73,9 @@ hipError_t wino_output_launch(const float* M, int n_img, int Co, int phases, con
 // (25 points K = 4 Ci, 5 + 5 points K = 2 Ci, 1 point K = Ci; winograd.hip).  Offsets in floats for T tiles / Co output channels.
 struct WinoGroup { int batch, kmul; long long v_off, u_off, m_off; };
 int wino_groups(int phases, long long T, int Ci, int Co, WinoGroup out[4]);
-// ---- K4w7: the 7x7 / stride 2 / pad 3 conv on 28x28 maps in polyphase Winograd form, F(4x4, 4x4) (winograd7.hip): 16 tiles per image,
-// 49 points in four groups (36 points K = 4 Ci, 6 + 6 points K = 2 Ci, 1 point K = Ci): 169 row-Ci units of U / V per output channel / tile
-constexpr int kWino7Units = 169, kWino7Points = 49, kWino7Tiles = 16;
+// ---- K4w7: the 7x7 / stride 2 / pad 3 conv on 28x28 maps in polyphase Winograd form, F(5x5, 4x4) (winograd7.hip): 9 tiles per image,
+// 64 points in four groups (49 points K = 4 Ci, 7 + 7 points K = 2 Ci, 1 point K = Ci): 225 row-Ci units of U / V per output channel / tile
+constexpr int kWino7Units = 225, kWino7Points = 64, kWino7Tiles = 9;
 hipError_t wino7_weight_launch(const float* w_packed, int Co, int Ci, float* U, hipStream_t st);
 hipError_t wino7_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, float* V, hipStream_t st);
 hipError_t wino7_output_launch(const float* M, int n_img, int Co, const float* bias, int flags, float* y, int y_cs, int y_coff, hipStream_t st);

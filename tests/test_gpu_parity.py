@@ -891,8 +891,8 @@ def test_winograd_conv5x5s2_vs_torch(rt, ci, co, n):
 
 @pytest.mark.parametrize("ci,co,n,relu", [(32, 64, 1, False), (320, 64, 3, False), (64, 128, 2, True)])
 def test_winograd_conv7x7s2_vs_torch(rt, ci, co, n, relu):
-    """offk_winograd_conv7x7s2 -- the polyphase Winograd form F(4x4, 4x4) of motion_conv_trans_28 (RGB_OFF.py:657: 7x7, stride 2,
-    pad 3, 28x28 -> 14x14; four 14x14 phase images x 4-tap phase kernels concatenated along K, 49 points in four K groups) --
+    """offk_winograd_conv7x7s2 -- the polyphase Winograd form F(5x5, 4x4) of motion_conv_trans_28 (RGB_OFF.py:657: 7x7, stride 2,
+    pad 3, 28x28 -> 14x14; four 14x14 phase images x 4-tap phase kernels concatenated along K, 64 points in four K groups) --
     against torch CPU fp32 F.conv2d, input from a channel slice, output into a channel slice (the [t2 | x0] buffer of the forward)."""
     g = torch.Generator().manual_seed(7 * ci + co)
     x = torch.randn(n, 28, 28, ci + 32, generator=g).clamp_min(0)

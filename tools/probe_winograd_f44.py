@@ -65,3 +65,8 @@ check(4, 4, [0, 1, -1, 0.5, -0.5, 2])
 check(2, 4, [0, 1, -1, 2])
 check(3, 4, [0, 1, -1, 2, -2])
 check(3, 4, [0, 1, -1, 0.5, -0.5])
+check(5, 4, [0, 1, -1, 0.5, -0.5, 2, -2])
+check(5, 4, [0, 1, -1, 0.5, -0.5, 2, -0.25])
+check(5, 4, [0, 1, -1, 0.5, -0.5, 1.5, -1.5])
+check(6, 4, [0, 1, -1, 0.5, -0.5, 2, -2, 0.25])
+check(7, 4, [0, 1, -1, 0.5, -0.5, 2, -2, 0.25, -0.25])
