@@ -181,18 +181,19 @@ POLYPHASE_MIN_PAIRS = {"motion_conv_trans_14": 40, "motion_conv_trans_28": 12}  
 
 
 def winograd_gemm_flops(P, key):
-    """FLOPs of the 36 batched GEMMs [4P tiles][K] x [K][Co] of a conv on the Winograd path: K = Ci for a 3x3 / stride 1
-    conv on 7x7 maps, 4 Ci for the polyphase form of the 5x5 / stride 2 conv (four 7x7 phase images concatenated along K)."""
+    """FLOPs of the batched GEMMs [P images][K] x [K][Co] of a conv on the Winograd path: 121 points with K = Ci for a 3x3 /
+    stride 1 conv on 7x7 maps, four K groups for the polyphase forms (four phase images concatenated along K)."""
     co, ci, k = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
     if k == 7:      # F(5x5, 4x4) on four 14x14 phase images: 9 tiles per 14x14 output map, 225 of 256 (point, phase) products
         return 2.0 * 9 * P * 225 * ci * co
-    # polyphase: 121 of the 144 (point, phase) products -- the others have an identically zero transformed kernel and are skipped
-    return 2.0 * 4 * P * (121 * ci if k == 5 else 36 * ci) * co
+    # a 7x7 map = four tiles, F(4, 3) x F(3, 3) per axis: 121 points per image; polyphase 5x5: 400 of the 484 (point, phase)
+    # products -- the others have an identically zero transformed kernel and are skipped
+    return 2.0 * P * (400 * ci if k == 5 else 121 * ci) * co
 
 
 def winograd_saved_flops(P):
-    """Direct-conv FLOPs minus the FLOPs of the 36 batched GEMMs (4 tiles of 4x4 outputs per 7x7 map) for the convs the fp32
-    path runs as Winograd F(4x4, 3x3) (csrc/winograd.hip)."""
+    """Direct-conv FLOPs minus the FLOPs of the batched GEMMs for the convs the fp32 path runs in a Winograd form
+    (csrc/winograd.hip, csrc/winograd7.hip)."""
     w = launch_work(P)
     on = [k for k in WINOGRAD_CONVS if not (k == "motion_conv_trans_28" and os.environ.get("OFFK_WINOGRAD_7X7", "1") == "0")
           and not (k == "motion_conv_trans_14" and os.environ.get("OFFK_WINOGRAD_5X5", "1") == "0")
@@ -236,14 +237,12 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6,
                        frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
         elif "[winograd:" in name:
-            # Winograd F(4x4, 3x3) of a 3x3 conv on 7x7 maps: the 36 batched GEMMs against the fp32-MFMA peak with THEIR
-            # FLOPs (2 * 36 * 4P * Ci * Co = 1 / 3.06 of the direct conv's), the two transforms against HBM with the bytes
-            # they move (V written / M read; the 7x7 map side is a fraction of that)
+            # a conv on the Winograd path: the batched GEMMs against the fp32-MFMA peak with THEIR FLOPs (3x3 on 7x7 maps:
+            # 2 * 121 * P * Ci * Co = 1 / 3.64 of the direct conv's), the two transforms against HBM with the bytes they move
+            # (V written / M read; the map side is a fraction of that)
             key = name.split(" ")[0]
             co, ci, ksz = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
-            T = 9 * P if ksz == 7 else 4 * P
-            if ksz == 5:
-                ci *= 4           # polyphase: four 7x7 phase images along K
+            T = 9 * P if ksz == 7 else P
             if ksz == 7 and "GEMMs" not in name:
                 # F(5x5, 4x4), four 14x14 phase images: 225 transformed floats per (tile, channel); 64 GEMM outputs per (tile, co)
                 nbytes = (T * 225 * ci + P * 784 * ci) * 4 if "input" in name else (64 * T * co + P * 196 * co) * 4
@@ -254,8 +253,8 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
                 small_ms += avg if key not in big else 0.0
                 small_fl += work[key] if key not in big else 0.0
             else:
-                vpts = 121 * ci / 4 if ksz == 5 else 36 * ci          # transformed-input floats per tile (polyphase: 121 phase-points)
-                nbytes = (T * vpts + P * 49 * ci) * 4 if "input" in name else (36 * T * co + P * 49 * co) * 4
+                vpts = 400 * ci if ksz == 5 else 121 * ci          # transformed-input floats per image (polyphase: 400 phase-points)
+                nbytes = (T * vpts + P * (196 if ksz == 5 else 49) * ci) * 4 if "input" in name else (121 * T * co + P * 49 * co) * 4
                 rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
                 small_ms += avg if key not in big else 0.0
         elif name in work or name.split(" ")[0] in work or name.startswith("chain_"):
@@ -593,8 +592,8 @@ def main():
                      "note": "algorithmic (direct-convolution) fp32 FLOPs / summed stage time; whole_forward_frac_of_peak = "
                              "the same FLOPs / the wall-clock ms_per_step / peak; bf16x3 peak = dense bf16 MFMA peak / 3 "
                              "products.  In fp32 the five 3x3 / stride 1 convs on 7x7 maps and, in polyphase form, the 5x5 / stride 2 conv "
-                             "run as Winograd F(4x4, 3x3), the 7x7 / stride 2 conv as polyphase F(5x5, 4x4) (fp32 arithmetic; 1 / 3.06, "
-                             "1 / 2.1 and 1 / 4.7 of their multiplies): executed_flops_per_step is what the matrix "
+                             "run as Winograd with F(4, 3) x F(3, 3) tiles, the 7x7 / stride 2 conv as polyphase F(5x5, 4x4) (fp32 arithmetic; "
+                             "1 / 3.64, 1 / 3.06 and 1 / 4.7 of their multiplies): executed_flops_per_step is what the matrix "
                              "pipe is asked to do (executed_frac_of_peak = that / ms_per_step / peak), so the algorithmic fraction can "
                              "exceed any kernel's MFMA-busy share -- and 1"},
         }

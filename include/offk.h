@@ -237,11 +237,12 @@ int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_c
                             const float* w1, const float* b1, const float* w2_packed, const float* b2,
                             const float* w3, const float* b3, int K3,
                             const float* res, int res_cstride, int res_coff, float* y, int y_cstride, int y_coff);
-/* K4w. 3x3 / stride 1 / pad 1 convolution on 7x7 maps as Winograd F(4x4, 3x3), fp32 arithmetic (csrc/winograd.hip): the five such
+/* K4w. 3x3 / stride 1 / pad 1 convolution on 7x7 maps in Winograd form, fp32 arithmetic (csrc/winograd.hip: a map = four tiles,
+ * F(4, 3) x F(3, 3) per axis, 121 points): the five such
  * convs of fusion@14 / @7 (RGB_OFF.py:766-767, 775-780, 833-834, 837-838).  Same epilogue and views as offk_conv2d (flags without
- * OFFK_CONV_RELU_IN); w_packed as for offk_conv2d.  scratch: 36 * (Co * Ci + 4 * n_img * (Ci + Co)) floats of device memory
+ * OFFK_CONV_RELU_IN); w_packed as for offk_conv2d.  scratch: 121 * (Co * Ci + n_img * (Ci + Co)) floats of device memory
  * (transformed weights, transformed input, GEMM output).  pool_part != NULL: [4 * n_img][Co] sums of the stored values of each
- * 4x4 output tile (an image = 4 consecutive rows): the average pool of a head that follows. */
+ * output tile (an image = 4 consecutive rows): the average pool of a head that follows. */
 int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
                           const float* w_packed, const float* bias, int Co,
                           const float* res, int res_cstride, int res_coff, int flags,
@@ -249,7 +250,7 @@ int offk_winograd_conv3x3(void* stream, const float* x, int x_cstride, int x_cof
 
 /* The 5x5 / stride 2 / pad 2 conv on 14x14 maps (motion_conv_trans_14, RGB_OFF.py:762-763) through the same machinery in polyphase
  * form: four 7x7 phase images x 3x3 phase kernels concatenated along K.  x: [n_img * 196][x_cstride]; y: [n_img * 49][y_cstride];
- * w_packed: the packed 5x5 weight [Co][Ci/32][25][32]; scratch: 36 * (4 * Co * Ci + 4 * n_img * (4 * Ci + Co)) floats. */
+ * w_packed: the packed 5x5 weight [Co][Ci/32][25][32]; scratch: 400 * Ci * (Co + n_img) + 121 * n_img * Co floats. */
 int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
                             const float* w_packed, const float* bias, int Co,
                             const float* res, int res_cstride, int res_coff, int flags,

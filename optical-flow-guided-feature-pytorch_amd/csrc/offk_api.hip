@@ -154,7 +154,7 @@ struct offk_handle {
   float* wino_u7 = nullptr;      // transformed weights of C_T28 in the four groups of winograd7.hip (225 x Co x Ci floats)
   bool wino_7x7 = true;          // the 7x7 / stride 2 conv of fusion@28 in polyphase Winograd form F(5x5, 4x4) (OFFK_WINOGRAD_7X7=0: direct)
   int wino7_min_p = 12;          // ... from this many pairs (OFFK_WINOGRAD_7X7=<n> with n > 1 at offk_create: tools)
-  float* wino_u[6] = {};         // transformed weights [36][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; [36][Co][4 Ci] of C_T14 (polyphase 5x5 / 2)
+  float* wino_u[6] = {};         // transformed weights [121][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; 400 x Co x Ci floats of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
@@ -293,12 +293,12 @@ void plan_workspace(offk_handle* h) {
   // average pools of the 7- and 14-heads folded into the producing conv: per 32-row slab, two partial column sums
   add_region(h, "poolpart_7", ((P * 49 + 31) / 32) * 2 * 1024);
   add_region(h, "poolpart_14", ((P * 49 + 31) / 32) * 2 * 512);
-  // Winograd path of the 3x3 convs at 7x7 (fp32): transformed input [36][4 P][Ci <= 832], GEMM output [36][4 P][Co <= 512],
+  // Winograd path of the 3x3 convs at 7x7 (fp32): transformed input [121][P][Ci <= 832], GEMM output [121][P][Co <= 512],
   // per-tile sums of sum_14b for the 14-head
   if (h->cfg.precision == OFFK_PRECISION_FP32) {
-    // widest: the polyphase 7x7 / 2 conv (9 P tiles x 225 x 320 floats: 1.0 GB at P = 384), then the polyphase 5x5 / 2 conv (K = 4 x 1056)
-    add_region(h, "wino_v", std::max((size_t)36 * 4 * P * 4224, (size_t)kWino7Tiles * P * kWino7Units * 320));
-    add_region(h, "wino_m", (size_t)36 * 4 * P * 512);       // (7x7: 64 x 9 P x 64 is smaller)
+    // widest: the polyphase 7x7 / 2 conv (9 P tiles x 225 x 320 floats: 1.0 GB at P = 384), then the polyphase 5x5 / 2 conv (400 P x 1056)
+    add_region(h, "wino_v", std::max((size_t)kWinoUnits4 * P * 1056, (size_t)kWino7Tiles * P * kWino7Units * 320));
+    add_region(h, "wino_m", (size_t)kWinoPoints * P * 512);    // (7x7: 64 x 9 P x 64 is smaller)
     add_region(h, "poolpart_14t", (size_t)4 * P * 512);
   }
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64], 3x3 @7: [P*49, 256]) -- up
@@ -748,7 +748,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   if (h->winograd) {
     const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
     for (int k = 0; k < 6; ++k)
-      if (dev_alloc(h, &h->wino_u[k], (size_t)36 * kConvs[wid[k]].Co * kConvs[wid[k]].Ci * (k == 5 ? 4 : 1)) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+      if (dev_alloc(h, &h->wino_u[k], (size_t)(k == 5 ? kWinoUnits4 : kWinoPoints) * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
   }
   plan_workspace(h);
@@ -1137,12 +1137,12 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
                          int y_coff, float* pool_t) -> int {
       const ConvSpec& c = kConvs[id];
-      const int T = 4 * n, phases = c.K == 5 ? 4 : 1;
-      float* V = region(h, ws, "wino_v") + (size_t)36 * 4 * i0 * 4224;      // (a split call gets its own part of the regions)
-      float* M = region(h, ws, "wino_m") + (size_t)36 * 4 * i0 * 512;
+      const int T = n, phases = c.K == 5 ? 4 : 1;          // rows of a batch entry: one per image (winograd.hip)
+      float* V = region(h, ws, "wino_v") + (size_t)kWinoUnits4 * i0 * 1056;      // (a split call gets its own part of the regions)
+      float* M = region(h, ws, "wino_m") + (size_t)kWinoPoints * i0 * 512;
       { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()); if (rc != OFFK_OK) return rc; }
       HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, phases, V, s));
-      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 36 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
+      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 121 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
       WinoGroup grp[4];
       const int ngrp = wino_groups(phases, T, c.Ci, c.Co, grp);
       {       // ONE launch: the groups ride on gridDim.y (four launches left the short groups alone on the chip: slower than no skipping)
@@ -1153,7 +1153,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
         d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
         d.y = M; d.y_cs = c.Co; d.y_coff = 0;
         d.tile_cfg = K0 <= 256 ? h->wino_cfg_small : h->wino_cfg; d.splitk = 1; d.precision = 0;
-        d.batch = 36; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
+        d.batch = kWinoPoints; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
         if (ngrp > 1) {
           d.ngroups = ngrp;
           for (int gi = 0; gi < ngrp; ++gi) {
@@ -1555,12 +1555,13 @@ int winograd_entry(const char* who, void* stream, const float* x, int x_cstride,
                    float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats, float* pool_part) {
   if (!x || !w_packed || !y || !scratch || n_img < 1 || Ci < 32 || (Ci & 31) || Co < 64 || (Co & 63) || (flags & OFFK_CONV_RELU_IN_))
     return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument (Ci % 32 == 0, Co % 64 == 0, no RELU_IN)");
-  const size_t T = 4 * (size_t)n_img, K = (size_t)phases * Ci, need = 36 * ((size_t)Co * K + T * (K + Co));
+  const size_t T = (size_t)n_img, units = phases == 4 ? kWinoUnits4 : kWinoPoints;      // rows per batch entry; row-Ci units of U / V
+  const size_t need = units * Ci * ((size_t)Co + T) + (size_t)kWinoPoints * T * Co;
   if (scratch_floats < need) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* U = scratch;
-  float* V = U + (size_t)36 * Co * K;
-  float* M = V + 36 * T * K;
+  float* V = U + units * Co * Ci;
+  float* M = V + units * T * Ci;
   hipError_t e = wino_weight_launch(w_packed, Co, Ci, phases, U, st);
   if (e == hipSuccess) e = wino_input_launch(x, x_cstride, x_coff, n_img, Ci, phases, V, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
@@ -1574,7 +1575,7 @@ int winograd_entry(const char* who, void* stream, const float* x, int x_cstride,
     d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
     d.y = M; d.y_cs = Co; d.y_coff = 0;
     d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
-    d.batch = 36; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)T * Co;
+    d.batch = kWinoPoints; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)T * Co;
     if (ngrp > 1) {
       d.ngroups = ngrp;
       for (int gi = 0; gi < ngrp; ++gi) {

@@ -63,16 +63,18 @@ struct ChainArgs {
 };
 hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
 
-// ---- K4w: Winograd F(4x4, 3x3) for the 3x3 / stride 1 convs on 7x7 maps (winograd.hip) ----
-// phases = 1: 3x3 / stride 1 on 7x7 maps; phases = 4: the polyphase form of a 5x5 / stride 2 / pad 2 conv on 14x14 maps (K = 4 Ci)
-hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, int phases, float* U, hipStream_t st);           // U [36][Co][phases Ci]
-hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, int phases, float* V, hipStream_t st);   // V [36][4 n_img][phases Ci]
+// ---- K4w: Winograd for the 3x3 / stride 1 convs on 7x7 maps (winograd.hip): a map = four tiles, F(4, 3) x F(3, 3) per axis ----
+// phases = 1: 3x3 / stride 1 on 7x7 maps: 121 points (batches) per image; phases = 4: the polyphase form of a 5x5 / stride 2 / pad 2
+// conv on 14x14 maps (K = 4 Ci, four K groups, 400 row-Ci units per image).  A batch entry has one row per image.
+constexpr int kWinoPoints = 121, kWinoUnits4 = 400;
+hipError_t wino_weight_launch(const float* w_packed, int Co, int Ci, int phases, float* U, hipStream_t st);           // U [121][Co][Ci] / 400 Co Ci floats
+hipError_t wino_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, int phases, float* V, hipStream_t st);   // V [121][n_img][Ci] / 400 n_img Ci floats
 hipError_t wino_output_launch(const float* M, int n_img, int Co, int phases, const float* bias, const float* res, int res_cs,
                               int res_coff, int flags, float* y, int y_cs, int y_coff, float* pool_part, hipStream_t st);
-// the GEMM launches of a conv on the Winograd path: phases == 1: one group of 36 points with K = Ci; phases == 4: four groups
-// (25 points K = 4 Ci, 5 + 5 points K = 2 Ci, 1 point K = Ci; winograd.hip).  Offsets in floats for T tiles / Co output channels.
+// the GEMM launches of a conv on the Winograd path: phases == 1: one group of 121 points with K = Ci; phases == 4: four groups
+// (81 points K = 4 Ci, 18 + 18 points K = 2 Ci, 4 points K = Ci; winograd.hip).  Offsets in floats for `rows` images / Co output channels.
 struct WinoGroup { int batch, kmul; long long v_off, u_off, m_off; };
-int wino_groups(int phases, long long T, int Ci, int Co, WinoGroup out[4]);
+int wino_groups(int phases, long long rows, int Ci, int Co, WinoGroup out[4]);
 // ---- K4w7: the 7x7 / stride 2 / pad 3 conv on 28x28 maps in polyphase Winograd form, F(5x5, 4x4) (winograd7.hip): 9 tiles per image,
 // 64 points in four groups (49 points K = 4 Ci, 7 + 7 points K = 2 Ci, 1 point K = Ci): 225 row-Ci units of U / V per output channel / tile
 constexpr int kWino7Units = 225, kWino7Points = 64, kWino7Tiles = 9;

@@ -360,7 +360,7 @@ def winograd_conv3x3(x, w_oihw, bias, res=None, flags=0, x_coff=0, y=None, y_cof
     Co, Ci = w_oihw.shape[:2]
     if y is None:
         y = torch.empty(n, 7, 7, Co, dtype=torch.float32, device=x.device)
-    nfl = 36 * (Co * Ci + 4 * n * (Ci + Co))
+    nfl = 121 * (Co * Ci + n * (Ci + Co))
     scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
     pool = torch.empty(4 * n, Co, dtype=torch.float32, device=x.device) if want_pool else None
     _lib.check(lib.offk_winograd_conv3x3(_stream(x.device), _ptr(x), cs, x_coff, n, Ci, _ptr(pack_conv_weight(w_oihw)), _ptr(bias), Co,
@@ -378,7 +378,7 @@ def winograd_conv5x5s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0):
     Co, Ci = w_oihw.shape[:2]
     if y is None:
         y = torch.empty(n, 7, 7, Co, dtype=torch.float32, device=x.device)
-    nfl = 36 * (4 * Co * Ci + 4 * n * (4 * Ci + Co))
+    nfl = 400 * Ci * (Co + n) + 121 * n * Co
     scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
     _lib.check(lib.offk_winograd_conv5x5s2(_stream(x.device), _ptr(x), cs, x_coff, n, Ci, _ptr(pack_conv_weight(w_oihw)), _ptr(bias), Co,
                                            None, 0, 0, flags, _ptr(y), y.shape[-1], y_coff, _ptr(scratch), nfl))
