@@ -51,37 +51,144 @@ def _llvm_objdump():
 _OPSEL_RE = re.compile(r"\bv_pk_\w+_f32\b.*\bop_sel:\[")
 
 
-def check_isa(obj):
+def _code_objects(obj):
+    """Unbundles the gfx950 code object(s) of a host object file next to it; returns their paths (the caller removes them)."""
+    objdump = _llvm_objdump()
+    r = subprocess.run([objdump, "--offloading", obj], capture_output=True, text=True, cwd=os.path.dirname(obj))
+    found = []
+    for f in sorted(os.listdir(os.path.dirname(obj))):
+        if not f.startswith(os.path.basename(obj) + "."):
+            continue
+        path = os.path.join(os.path.dirname(obj), f)
+        if "amdgcn" in f:
+            found.append(path)
+        elif "host" in f:
+            os.remove(path)
+    if not found and os.path.basename(obj) != "offk_api.o":       # offk_api.hip has no device code
+        raise RuntimeError("no gfx950 code object found in %s (%s)" % (obj, r.stderr.strip()))
+    return found
+
+
+def check_isa(obj, code_objects):
     """The DESIGN.md co-residency finding: compiler-generated packed-fp32 VALU instructions with an op_sel operand
     swizzle (`v_pk_fma_f32 ... op_sel:[0,1,0]`, what the SLP vectoriser makes of neighbouring scalar FMAs that share a
     broadcast operand) returned wrong low halves on MI355X while the kernel shared CUs with an MFMA kernel of another
     stream.  The mechanism is not established, so the hazard is kept out of the library by construction: disassemble
     the gfx950 code object of every translation unit and refuse to build if one contains such an instruction (fix:
     add the file to EXTRA_FLAGS with -fno-slp-vectorize, or break the pairing in the source)."""
-    objdump = _llvm_objdump()
-    if objdump is None:
-        if os.environ.get("OFFK_SKIP_ISA_CHECK") == "1":
-            print("WARNING: llvm-objdump not found, op_sel ISA check of %s SKIPPED (OFFK_SKIP_ISA_CHECK=1)" % obj, file=sys.stderr)
-            return
-        raise RuntimeError("llvm-objdump not found: cannot run the op_sel ISA check (DESIGN.md section 8); "
-                           "OFFK_SKIP_ISA_CHECK=1 builds without it")
-    r = subprocess.run([objdump, "--offloading", obj], capture_output=True, text=True, cwd=os.path.dirname(obj))
     bad = []
-    found = False
-    for f in sorted(os.listdir(os.path.dirname(obj))):
-        if f.startswith(os.path.basename(obj) + ".") and "amdgcn" in f:
-            found = True
-            path = os.path.join(os.path.dirname(obj), f)
-            d = subprocess.run([objdump, "-d", path], capture_output=True, text=True)
-            bad += [ln.strip() for ln in d.stdout.splitlines() if _OPSEL_RE.search(ln)]
-            os.remove(path)
-        elif f.startswith(os.path.basename(obj) + ".") and "host" in f:
-            os.remove(os.path.join(os.path.dirname(obj), f))
-    if not found and os.path.basename(obj) != "offk_api.o":       # offk_api.hip has no device code
-        raise RuntimeError("ISA check: no gfx950 code object found in %s (%s)" % (obj, r.stderr.strip()))
+    for path in code_objects:
+        d = subprocess.run([_llvm_objdump(), "-d", path], capture_output=True, text=True)
+        bad += [ln.strip() for ln in d.stdout.splitlines() if _OPSEL_RE.search(ln)]
     if bad:
         raise RuntimeError("ISA check failed for %s: %d packed-fp32 instruction(s) with op_sel (see check_isa), first: %s"
                            % (obj, len(bad), bad[0]))
+
+
+# ---- resource guard of the asm-scheduled kernels (VERDICT r03 weak #7) --------------------------------------------------------
+# pw_tdiff16_kernel, chain14_kernel and the LDS-DMA form of conv_igemm_kernel (PREC 4) issue their global -> LDS DMAs and some
+# operand loads through inline asm and count their own `s_waitcnt vmcnt(N)` ("all but my N newest loads have landed").  The
+# memory counter retires in order, so a VMEM instruction hipcc adds on its own -- a register spill, a scratch access -- cannot
+# make such a wait too weak; it makes it WAIT FOR THE LOADS JUST ISSUED, i.e. it silently puts a memory latency into the MFMA
+# stream the counts were written to keep clear (chain14_kernel<4, true> did exactly that until round 4: four spilled address
+# registers, two `s_waitcnt vmcnt(0)` per pass).  And each kernel's block-per-CU plan rests on a register budget.  So the build
+# reads the code-object metadata of every kernel named here and fails unless
+#   vgpr_spill_count == 0 and private_segment_fixed_size == 0   (no compiler VMEM traffic of its own; SGPR spills are lane
+#                                                                 writes into a VGPR -- no memory instruction -- and are
+#                                                                 tolerated only where `sgpr_spills` says so, scratch still 0)
+#   vgpr_count (unified: arch + acc registers) <= the bound the kernel's occupancy plan assumes.
+# (source file, regex on the demangled kernel name, max vgpr_count, SGPR spills tolerated, what the bound stands for)
+ASM_SCHEDULED_KERNELS = (
+    ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 168, False, "three blocks per CU (3 waves / SIMD x 168 <= 512)"),
+    ("chain_fused.hip", r"^void offk::chain14_kernel<", 168, False, "three blocks per CU (52.5 KB of LDS each)"),
+    ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 96, False,
+     "the default 64x64 tile: five blocks per CU (32 KB of LDS each, 5 waves / SIMD x 96 <= 512)"),
+    ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<.*, 4>\(", 512, True, "the other LDS-DMA tiles (set_conv_plan / tools only)"),
+)
+
+
+def _llvm_readelf():
+    p = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    return p if os.path.exists(p) else shutil.which("llvm-readelf")
+
+
+def kernel_resources(code_object):
+    """[{name (demangled), vgpr_count, agpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size}] of one code object."""
+    r = subprocess.run([_llvm_readelf(), "--notes", code_object], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("llvm-readelf --notes failed for %s: %s" % (code_object, r.stderr.strip()))
+    out = []
+    for blk in r.stdout.split("  - .agpr_count:")[1:]:
+        def field(k):
+            return re.search(r"\.%s:\s+(\S+)" % k, blk).group(1)
+        out.append({"mangled": field("name"), "agpr_count": int(blk.split()[0]), "vgpr_count": int(field("vgpr_count")),
+                    "vgpr_spill_count": int(field("vgpr_spill_count")), "sgpr_spill_count": int(field("sgpr_spill_count")),
+                    "private_segment_fixed_size": int(field("private_segment_fixed_size"))})
+    if out:
+        d = subprocess.run(["c++filt"] + [k["mangled"] for k in out], capture_output=True, text=True)
+        names = d.stdout.splitlines() if d.returncode == 0 else []
+        for i, k in enumerate(out):
+            k["name"] = names[i] if i < len(names) else k["mangled"]
+    return out
+
+
+def check_resources(src_name, kernels):
+    """Applies ASM_SCHEDULED_KERNELS to the kernels of one translation unit; returns the rows it checked."""
+    rows, matched = [], set()
+    for k in kernels:
+        for gi, (src, pat, max_vgpr, sgpr_ok, why) in enumerate(ASM_SCHEDULED_KERNELS):
+            if src != src_name or not re.search(pat, k["name"]):
+                continue
+            matched.add(gi)
+            problems = []
+            if k["vgpr_spill_count"] or k["private_segment_fixed_size"]:
+                problems.append("vgpr_spill_count %d, private_segment_fixed_size %d (must be 0: its vmcnt waits are hand-counted)"
+                                % (k["vgpr_spill_count"], k["private_segment_fixed_size"]))
+            if k["sgpr_spill_count"] and not sgpr_ok:
+                problems.append("sgpr_spill_count %d (must be 0)" % k["sgpr_spill_count"])
+            if k["vgpr_count"] > max_vgpr:
+                problems.append("vgpr_count %d > %d: %s" % (k["vgpr_count"], max_vgpr, why))
+            if problems:
+                raise RuntimeError("resource guard failed for %s in %s: %s" % (k["name"], src_name, "; ".join(problems)))
+            rows.append(k)
+            break
+    for gi, (src, pat, _m, _s, _w) in enumerate(ASM_SCHEDULED_KERNELS):
+        if src == src_name and gi not in matched:
+            raise RuntimeError("resource guard: no kernel of %s matches %r (renamed? update ASM_SCHEDULED_KERNELS)" % (src_name, pat))
+    return rows
+
+
+def check_object(obj):
+    """ISA check + resource guard of one freshly compiled object."""
+    if _llvm_objdump() is None or _llvm_readelf() is None:
+        if os.environ.get("OFFK_SKIP_ISA_CHECK") == "1":
+            print("WARNING: llvm-objdump / llvm-readelf not found, checks of %s SKIPPED (OFFK_SKIP_ISA_CHECK=1)" % obj, file=sys.stderr)
+            return
+        raise RuntimeError("llvm-objdump / llvm-readelf not found: cannot run the op_sel ISA check (DESIGN.md section 8) and the "
+                           "resource guard; OFFK_SKIP_ISA_CHECK=1 builds without them")
+    cos = _code_objects(obj)
+    try:
+        check_isa(obj, cos)
+        src = os.path.basename(obj).replace(".o", ".hip")
+        kernels = [k for co in cos for k in kernel_resources(co)]
+        check_resources(src, kernels)
+    finally:
+        for path in cos:
+            os.remove(path)
+
+
+def resource_table():
+    """The guarded kernels of the objects of the last build, for tests/test_build_guard.py: {source: [rows]}."""
+    table = {}
+    for src in sorted(set(g[0] for g in ASM_SCHEDULED_KERNELS)):
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        cos = _code_objects(obj)
+        try:
+            table[src] = check_resources(src, [k for co in cos for k in kernel_resources(co)])
+        finally:
+            for path in cos:
+                os.remove(path)
+    return table
 
 
 def _newer(target, deps):
@@ -110,7 +217,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr)
-        check_isa(o)
+        check_object(o)
         return o
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:

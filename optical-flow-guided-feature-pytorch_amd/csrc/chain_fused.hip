@@ -42,6 +42,7 @@ namespace offk {
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSlot = 256;                              // bytes of one pixel slot of t1 / t2: 64 fp32 channels
 constexpr int kT1Rows = 9;                              // 7 output rows + one halo row either side
@@ -183,7 +184,12 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
     return *reinterpret_cast<const f32x4*>(w2r + ((s >> 1) * 9 + tap) * 32 + 16 * (s & 1));
   };
   constexpr int K3 = MERGED ? 128 : 64, KS3 = K3 / 16;
-  const float* const w3r = a.w3 + (size_t)(64 * wave + li) * K3 + 4 * kq;       // + 16 n' rows, + 16 s
+  // c3 weights through a buffer descriptor: the lane's row offset in one VGPR, (n', s) as a compile-time scalar offset.  (With
+  // 64-bit pointers hipcc kept one address pair per (n', s) row group -- offsets beyond the 4 KB immediate -- ran out of the 168
+  // registers three blocks per CU allow in the MERGED form, spilled four of them and put an s_waitcnt vmcnt(0) of the reload in
+  // front of the dependent weight load, inside the MFMA stream.)
+  const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w3), 0, 256 * K3 * 4, 0x00020000);
+  const int w3voff = ((64 * wave + li) * K3 + 4 * kq) * 4;                       // + 16 n' rows, + 16 s
   const bool px_ok = li >= 1 && li <= 14;
   const int pix0 = img * 196 + R0 * 14 + (px_ok ? li - 1 : 0);                // + row * 14
 
@@ -243,7 +249,10 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
       f32x4 wq[4][2];
       auto w3_load = [&](f32x4 (&w)[2], const int s) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) w[n] = *reinterpret_cast<const f32x4*>(w3r + (size_t)(16 * (2 * np + n)) * K3 + 16 * s);
+        for (int n = 0; n < 2; ++n) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w3rs, w3voff, ((16 * (2 * np + n)) * K3 + 16 * s) * 4, 0);
+          w[n] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
       };
       f32x4 xg[MERGED ? NR : 1];       // MERGED: the chain input (pre-ReLU) of this lane's pixels, channel step s - 4, from global
       auto xg_load = [&](const int s) {

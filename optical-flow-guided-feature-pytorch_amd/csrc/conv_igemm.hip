@@ -615,7 +615,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
         }
         s0 += __shfl_xor(s0, 32);
         s1 += __shfl_xor(s1, 32);
-        if (h == 0 && co < p.co_limit) {
+        if (h == 0 && co < p.co_limit && slab * 32 < p.M) {     // (a sub-tile wholly past M owns no slab: the region ends at ceil(M / 32))
           p.pool_part[((size_t)slab * 2) * p.Co + co] = s0;
           p.pool_part[((size_t)slab * 2 + 1) * p.Co + co] = s1;
         }
@@ -1344,7 +1344,7 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   a.M = (int)M;
   const int nkt = d.KH * d.KW * (d.Ci / 32);
   int cfg = d.tile_cfg, sk = d.splitk;
-  if (cfg < 0 || sk < 1) conv2d_auto_plan(d.plan_n_img > 0 ? (long long)d.plan_n_img * a.Ho * a.Wo : M, d.Co, nkt, &cfg, &sk, d.precision);
+  if (cfg < 0 || sk < 1) conv2d_auto_plan(M, d.Co, nkt, &cfg, &sk, d.precision);
   if (sk > nkt) sk = nkt;
   if (narrow) sk = 1;
   a.co_limit = narrow ? d.co_limit : d.Co;

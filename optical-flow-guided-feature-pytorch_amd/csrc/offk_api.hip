@@ -116,7 +116,6 @@ struct offk_handle {
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
   bool pw_dirty = true;
-  bool pw_presplit = true;
   float* pw_b[kNumSites] = {};   // [160]
   float* dw_w[kNumSites] = {};   // [9][32]
   float* dw_b[kNumSites] = {};   // [32] or null
@@ -140,12 +139,6 @@ struct offk_handle {
   float* merged_b[3] = {};
   int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};   // kMergedPlan at offk_create
   bool merged_dirty = true;
-  // the 28- and 14-heads only depend on sum_28c / sum_14b: they CAN run on a side stream beside the later
-  // fusion stages, joined back into the caller's stream before offk_forward returns
-  hipStream_t side = nullptr;   // created with OFFK_SIDE_STREAM=1 in the environment at offk_create; null: heads on the caller's stream
-  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
-  hipStream_t pipe = nullptr;   // second half of the two-half fusion pipeline (offk_forward); only with OFFK_PIPELINE=1 at offk_create
-  hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
 
   // training side (offk_off_units_backward): workspace superset, K1b chunking, gradient-buffer layout
   float* zero_page = nullptr;    // 256 B of zeros (target of masked-out loads)
@@ -158,10 +151,8 @@ struct offk_handle {
   bool wino_dirty = true;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
-  int wino_cfg = 3;              // tile of the 36 batched GEMMs (OFFK_WINO_CFG at offk_create: tools)
-  int wino_cfg_small = 3;        // the same for the short-K ones (K <= 256; OFFK_WINO_CFG_SMALL)
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
-  int pw_dma = 2;                // fp32 fused units: 2 = 16-pixel LDS-DMA form, 1 = 32-pixel LDS-DMA form, 0 = register-staged (OFFK_PW_DMA at offk_create)
+  int chain_min_p = 72;          // ... from this many pairs (OFFK_CHAIN=<n> with n > 1 at offk_create: tests / tools)
   size_t train_ws_bytes = 0;
   int wg_kpb = 0;                // 32-pixel K-tiles one pw_wgrad block walks
   std::map<std::string, std::pair<size_t, size_t>> grad_slots;   // key -> (offset, count) in floats
@@ -304,7 +295,7 @@ void plan_workspace(offk_handle* h) {
   // split-K partial slabs: room for 8 slices of the widest large-K conv output (7x7: [P*196, 64], 3x3 @7: [P*49, 256]) -- up
   // to 64 at small P, where the plans split deeper (conv2d_auto_plan); a conv whose plan needs more gets as many as fit
   h->splitk_floats = (size_t)std::min<size_t>(64, std::max<size_t>(8, 1536 / P)) * P * 196 * 64;
-  add_region(h, "splitk", h->splitk_floats + 128);     // + slack: the two-half pipeline cuts the slab at a 64-float boundary
+  add_region(h, "splitk", h->splitk_floats);
   h->ws_bytes = align_up(h->ws_bytes, 256);
 
   // ---- training side: backward regions behind the forward layout (offk_train_workspace_bytes) ----
@@ -384,7 +375,7 @@ int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
 // bf16x3: K1 reads the library's pre-split weight copies unless a contraction weight is bound in place -- then every site
 // takes fp32 weights (its bound tensors, or the library's fp32 copy) and the kernel splits them on the way into LDS
 bool pw_presplit_now(const offk_handle* h) {
-  if (h->cfg.precision != OFFK_PRECISION_BF16X3 || !h->pw_presplit) return false;
+  if (h->cfg.precision != OFFK_PRECISION_BF16X3) return false;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) return false;
   return true;
@@ -482,9 +473,10 @@ int finalize_pw(offk_handle* h, hipStream_t st) {
   if (h->cfg.precision == OFFK_PRECISION_BF16X3)
     for (int s = 0; s < kNumSites; ++s)
       HIP_TRY(h, split_bf16_launch(h->pw_w[s], (size_t)kUnitCh * kSites[s].C, h->pw_wb3[s], st));
-  for (int s = 0; s < kNumSites; ++s)
-    HIP_TRY(h, pw_pack_direct_launch(h->pw_w[s], kSites[s].C, h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0, h->pw_wt[s], st));
-  if (h->cfg.precision == OFFK_PRECISION_FP32)
+  // the operand-order image the fused units kernel reads straight into registers: bf16x3 -> pw_tdiff_kernel, fp32 -> pw_tdiff16_kernel
+  if (h->cfg.precision == OFFK_PRECISION_BF16X3)
+    for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct_launch(h->pw_w[s], kSites[s].C, 1, h->pw_wt[s], st));
+  else
     for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16[s], st));
   h->pw_dirty = false;
   return OFFK_OK;
@@ -534,7 +526,6 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   pt.bdirect = 1;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
-  pt.dma = h->pw_dma;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
@@ -575,7 +566,6 @@ int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, i
   d.tile_cfg = cfg; d.splitk = sk;
   d.partial = h->cur_splitk; d.partial_floats = h->splitk_floats;
   d.precision = h->cfg.precision;
-  d.plan_n_img = h->P;                    // the two-half pipeline calls with half the pairs: same plan, same bits
   d.pool_part = h->cur_pool_part; d.pool_hw = h->cur_pool_part ? H * H / (stride * stride) : 0;
   const char* why = nullptr;
   { int rc = trace_mark(h, st, name); if (rc != OFFK_OK) return rc; }
@@ -663,12 +653,9 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->cfg = *cfg;
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
-  { const char* e = getenv("OFFK_PW_PRESPLIT"); if (e && *e == '0') h->pw_presplit = false; }
-  const char* tab_env = getenv("OFFK_PLAN_TABLES");          // "0": the heuristic plans at every size (A/B of the tables)
-  const bool use_tables = !(tab_env && *tab_env == '0');
   for (int c = 0; c < kNumConvs; ++c) {
     const bool b3 = cfg->precision == OFFK_PRECISION_BF16X3;
-    const int (*tab)[2] = !use_tables ? nullptr : h->P == 384 ? (b3 ? kTunedP384B3 : nullptr) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
+    const int (*tab)[2] = h->P == 384 ? (b3 ? kTunedP384B3 : nullptr) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
@@ -688,7 +675,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     add_slot(h, "motion_spatial_down_" + n + ".bias", {kDownCh}, SK_DOWN_B, s);
     rc = dev_alloc(h, &h->pw_w[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wb3[s], (size_t)kUnitCh * C);
-    if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_wt[s], (size_t)kUnitCh * C);
+    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wt[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_FP32) rc = dev_alloc(h, &h->pw_wt16[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
     if (cfg->variant == OFFK_VARIANT_RGB_LEARNED_DW && rc == OFFK_OK) {
@@ -735,16 +722,19 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     offk_destroy(h);
     return OFFK_ERR_HIP;
   }
-  // inference: K1 fused with the temporal difference (pw_tdiff.hip) unless OFFK_FUSED_UNITS=0 at offk_create
+  // The path switches of the product library, all read HERE and nowhere else (INTEGRATION.md lists them): each names one
+  // algorithm choice of the exact-fp32 forward; "0" = off, a number > 1 = use it from that many frame pairs P = B (L - 1).
+  //   OFFK_FUSED_UNITS   K1 fused with the temporal difference (pw_tdiff.hip); 0: K1 + K2 (what training always runs)
+  //   OFFK_WINOGRAD      Winograd forms of the k x k fusion convs (winograd.hip, winograd7.hip); 0: direct implicit GEMMs everywhere
+  //   OFFK_WINOGRAD_5X5  ... of the 5x5 / stride 2 conv (default: from P = 40)     OFFK_WINOGRAD_7X7  ... of the 7x7 / stride 2 conv (from P = 12)
+  //   OFFK_CHAIN         one launch per bottleneck chain of fusion@28 (chain_fused.hip; from P = 72)
+  //   OFFK_FOLD_POOL     7- / 14-head average pools taken in the producing conv's epilogue; 0: pool + fc kernels
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
-  { const char* e = getenv("OFFK_PW_DMA"); if (e && *e >= '0' && *e <= '2') h->pw_dma = *e - '0'; }
-  { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
   { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino5_min_p = atoi(e); }
   { const char* e = getenv("OFFK_WINOGRAD_7X7"); h->wino_7x7 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino7_min_p = atoi(e); }
-  { const char* e = getenv("OFFK_WINO_CFG_SMALL"); if (e && *e >= '0' && *e <= '5') h->wino_cfg_small = *e - '0'; }
-  { const char* e = getenv("OFFK_WINO_CFG"); if (e && *e >= '0' && *e <= '5') h->wino_cfg = *e - '0'; }
   if (h->winograd) {
     const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
     for (int k = 0; k < 6; ++k)
@@ -752,28 +742,6 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
   }
   plan_workspace(h);
-  const char* side_env = getenv("OFFK_SIDE_STREAM");
-  // (opt-in since the heads became three short launches -- pool sums in conv epilogues / maxpool_rows_kernel, FC on MFMA: in
-  //  line they cost 17 us at B = 64; beside the fusion convs they slowed those by more, 4.30 vs 4.29 ms, B = 1: 0.80 vs 0.77 ms)
-  if (side_env && *side_env == '1' &&
-      (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-       hipEventCreateWithFlags(&h->ev_fork[0], hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&h->ev_fork[1], hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
-    g_err = "offk_create: could not create the side stream";
-    offk_destroy(h);
-    return OFFK_ERR_HIP;
-  }
-  const char* pipe_env = getenv("OFFK_PIPELINE");
-  if (pipe_env && *pipe_env == '1' &&
-      (hipStreamCreateWithFlags(&h->pipe, hipStreamNonBlocking) != hipSuccess ||
-       hipEventCreateWithFlags(&h->ev_pipe[0], hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&h->ev_pipe[1], hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&h->ev_pipe[2], hipEventDisableTiming) != hipSuccess)) {
-    g_err = "offk_create: could not create the pipeline stream";
-    offk_destroy(h);
-    return OFFK_ERR_HIP;
-  }
   *out = h;
   return OFFK_OK;
 }
@@ -783,12 +751,6 @@ int offk_destroy(offk_handle* h) {
   DeviceGuard guard(h->cfg.device);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->tr_events) (void)hipEventDestroy(e);
-  if (h->ev_fork[0]) (void)hipEventDestroy(h->ev_fork[0]);
-  if (h->ev_fork[1]) (void)hipEventDestroy(h->ev_fork[1]);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->side) (void)hipStreamDestroy(h->side);
-  for (hipEvent_t e : h->ev_pipe) if (e) (void)hipEventDestroy(e);
-  if (h->pipe) (void)hipStreamDestroy(h->pipe);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return OFFK_OK;
@@ -1104,19 +1066,20 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
 
   TRY(finalize_merged(h, st));
   TRY(finalize_wino(h, st));
-  const bool forked = h->side != nullptr && h->profiling != 2;   // per-launch trace: everything in line on the caller's stream
-  hipStream_t side = forked ? h->side : st;
   const bool cons = h->cfg.consensus == OFFK_CONSENSUS_AVG;
   float* l7 = cons ? region(h, ws, "logit_7") : out7;
   float* l14 = cons ? region(h, ws, "logit_14") : out14;
   float* l28 = cons ? region(h, ws, "logit_28") : out28;
-  // each head = a pooling launch (1536 blocks at C = 1024) + a latency-oriented FC launch
-  auto run_head = [&](hipStream_t hs, int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool,
-                      const char* pooled_name, float* logits, int i0, int n) -> int {
-    float* pooled = region(h, ws, pooled_name) + (size_t)i0 * C;
-    { int rc = trace_mark(h, hs, k == 0 ? "head_7 (pool + fc)" : k == 1 ? "head_28 (pool + fc)" : "head_14 (pool + fc)"); if (rc != OFFK_OK) return rc; }
-    hipError_t e = pool_launch(x + (size_t)i0 * Hh * Hh * x_cs, x_cs, x_coff, n, Hh, Hh, C, maxpool, pooled, hs);
-    if (e == hipSuccess) e = fc_launch(pooled, n, C, h->fc_w[k], h->fc_b[k], ncls, logits + (size_t)i0 * ncls, hs);
+  const int n = P;                 // every launch below covers all P pairs (the buffers are pair-major)
+  hipStream_t s = st;
+  // pool_kernel + fc_kernel: the heads of the paths that cannot fold the average pool into the producing conv (LDS-patch tiles
+  // of the bf16x3 plans, OFFK_FOLD_POOL=0)
+  auto run_head = [&](int k, const float* x, int x_cs, int x_coff, int Hh, int C, int maxpool, const char* pooled_name,
+                      float* logits) -> int {
+    float* pooled = region(h, ws, pooled_name);
+    { int rc = trace_mark(h, s, k == 0 ? "head_7 (pool + fc)" : k == 1 ? "head_28 (pool + fc)" : "head_14 (pool + fc)"); if (rc != OFFK_OK) return rc; }
+    hipError_t e = pool_launch(x, x_cs, x_coff, n, Hh, Hh, C, maxpool, pooled, s);
+    if (e == hipSuccess) e = fc_launch(pooled, n, C, h->fc_w[k], h->fc_b[k], ncls, logits, s);
     if (e != hipSuccess) return fail_hip(h, e, "head");
     return OFFK_OK;
   };
@@ -1124,247 +1087,171 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   float *sa = region(h, ws, "sa_28"), *sb = region(h, ws, "sb_28");
   float *xu = region(h, ws, "xu_14"), *u1 = region(h, ws, "u1_14"), *s14 = region(h, ws, "sa_14");   // xu = [u2 | x1]
   float *xv = region(h, ws, "xv_7"), *v1 = region(h, ws, "v1_7"), *s7 = region(h, ws, "sum_7");   // xv = [v2 | x2]
-  // The three fusion stages + heads for the pairs [i0, i0 + n) on stream s.  Every buffer is pair-major, so a range of
-  // pairs is a pointer offset; results do not depend on how the pairs are split (same plans, same K order per output).
-  // side_heads: the 28- and 14-heads go to the handle's side stream (joined by the caller); after_first: recorded behind
-  // the first conv (the stagger point of the two-half pipeline below).
-  auto fusion = [&](hipStream_t s, int i0, int n, bool side_heads, hipEvent_t after_first, hipEvent_t* sev) -> int {
-    auto at = [&](float* base, int Hh, int cs) { return base + (size_t)i0 * Hh * Hh * cs; };
-    hipStream_t hs = side_heads ? side : s;
-    // 3x3 / stride 1 conv on 7x7 maps as Winograd F(4x4, 3x3): input transform, 36 batched GEMMs on the 1x1 kernel, output
-    // transform with the conv's epilogue (winograd.hip).  Every buffer is indexed from this call's first pair.
-    const bool wino = h->winograd && h->cfg.precision == OFFK_PRECISION_FP32;
-    auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
-                         int y_coff, float* pool_t) -> int {
-      const ConvSpec& c = kConvs[id];
-      const int T = n, phases = c.K == 5 ? 4 : 1;          // rows of a batch entry: one per image (winograd.hip)
-      float* V = region(h, ws, "wino_v") + (size_t)kWinoUnits4 * i0 * 1056;      // (a split call gets its own part of the regions)
-      float* M = region(h, ws, "wino_m") + (size_t)kWinoPoints * i0 * 512;
-      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()); if (rc != OFFK_OK) return rc; }
-      HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, phases, V, s));
-      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: 121 GEMMs]").c_str()); if (rc != OFFK_OK) return rc; }
-      WinoGroup grp[4];
-      const int ngrp = wino_groups(phases, T, c.Ci, c.Co, grp);
-      {       // ONE launch: the groups ride on gridDim.y (four launches left the short groups alone on the chip: slower than no skipping)
-        const int K0 = grp[0].kmul * c.Ci;
-        ConvDesc d;
-        d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = K0;
-        d.w = h->wino_u[uidx]; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-        d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-        d.y = M; d.y_cs = c.Co; d.y_coff = 0;
-        d.tile_cfg = K0 <= 256 ? h->wino_cfg_small : h->wino_cfg; d.splitk = 1; d.precision = 0;
-        d.batch = kWinoPoints; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
-        if (ngrp > 1) {
-          d.ngroups = ngrp;
-          for (int gi = 0; gi < ngrp; ++gi) {
-            d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * c.Ci;
-            d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
-          }
-        }
-        const char* why = nullptr;
-        hipError_t e = conv2d_launch(d, s, &why);
-        if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
-      }
-      { int rc = trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()); if (rc != OFFK_OK) return rc; }
-      HIP_TRY(h, wino_output_launch(M, n, c.Co, phases, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
-      return OFFK_OK;
-    };
-    // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
-    // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
-    float *xt_ = at(xt, 14, 128), *t1_ = at(t1, 14, 64), *sa_ = at(sa, 14, 256), *sb_ = at(sb, 14, 256);
-    float *F28_ = at(F28, 28, 320), *F14_ = at(F14, 14, 1056), *F7_ = at(F7, 7, 832);
-    // :657 x0, pre-ReLU kept for the branch.  fp32: polyphase Winograd F(5x5, 4x4) (winograd7.hip) -- input transform, 64 batched
-    // GEMMs in four K groups as ONE launch of the 1x1 kernel, output transform
-    // (from P = 12 pairs -- B = 2: 0.495 against 0.503 ms, B = 8: 0.813 against 0.874, B = 64: 3.88 against 4.24; B = 1: equal)
-    if (h->wino_u7 && h->winograd && h->P >= h->wino7_min_p) {
-      const ConvSpec& c = kConvs[C_T28];
-      const int T = kWino7Tiles * n;
-      float* V = region(h, ws, "wino_v") + (size_t)kWino7Tiles * i0 * kWino7Units * 320;
-      float* M = region(h, ws, "wino_m") + (size_t)kWino7Points * kWino7Tiles * i0 * 64;
-      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
-      HIP_TRY(h, wino7_input_launch(F28_, 320, 0, n, c.Ci, V, s));
-      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 64 GEMMs]").c_str()));
-      WinoGroup grp[4];
-      const int ngrp = wino7_groups(T, c.Ci, c.Co, grp);
-      {
-        const int K0 = grp[0].kmul * c.Ci;
-        ConvDesc d;
-        d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = T; d.H = 1; d.W = 1; d.Ci = K0;
-        d.w = h->wino_u7; d.bias = nullptr; d.Co = c.Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-        d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-        d.y = M; d.y_cs = c.Co; d.y_coff = 0;
-        d.tile_cfg = h->wino_cfg; d.splitk = 1; d.precision = 0;
-        d.batch = kWino7Points; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)c.Co * K0; d.y_bstride = (long long)T * c.Co;
-        d.ngroups = ngrp;
-        for (int gi = 0; gi < ngrp; ++gi) {
-          d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * c.Ci;
-          d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
-        }
-        const char* why = nullptr;
-        hipError_t e = conv2d_launch(d, s, &why);
-        if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(c.key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
-      }
-      TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()));
-      HIP_TRY(h, wino7_output_launch(M, n, c.Co, h->conv_b[C_T28], 0, xt_, 128, 64, s));
-    } else
-    TRY(conv(h, s, C_T28, n, 28, View{F28_, 320, 0}, nullptr, 0, 0, 0, xt_, 128, 64));
-    if (after_first) HIP_TRY(h, hipEventRecord(after_first, s));
-    // 1x1 -> 3x3 -> 1x1 (+ residual) as ONE launch per chain (exact fp32; a block owns half an image, t1 / t2 stay in LDS)
-    auto chain = [&](const char* name, const float* x, int x_cs, int x_coff, int Cin, int relu_in, ConvId c1, ConvId c2,
-                     const float* w3, const float* b3, int K3, const float* res, float* y, int y_cs, int y_coff) -> int {
-      ChainArgs a;
-      a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in;
-      a.w1 = h->conv_w[c1]; a.b1 = h->conv_b[c1]; a.w2 = h->conv_w[c2]; a.b2 = h->conv_b[c2];
-      a.w3 = w3; a.b3 = b3; a.K3 = K3;
-      a.res = res; a.res_cs = 256; a.res_coff = 0;
-      a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
-      a.n_img = n; a.relu_out = 1;
-      const unsigned long long xb = ((unsigned long long)n * 196 * x_cs - x_coff) * 4ull;
-      a.x_bytes = xb < 0x7fffffffull ? (unsigned)xb : 0u;
-      { int rc = trace_mark(h, s, name); if (rc != OFFK_OK) return rc; }
-      const char* why = nullptr;
-      hipError_t e = chain14_launch(a, s, &why);
-      if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
-      return OFFK_OK;
-    };
-    // (from P = 72 pairs: a chain block walks its three convs alone -- 45 us per launch however few blocks there are; B = 8: three
-    //  convs per chain 0.885 ms per forward against 0.90, B = 16: 1.37 against 1.345.  h->P, not n: the plan of a split call is the whole call's)
-    const bool chained = h->chain && h->P >= 72 && h->cfg.precision == OFFK_PRECISION_FP32 && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
-    if (chained) {
-      TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt_, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
-                nullptr, sa_, 256, 0));                                                              // :658-667
-      TRY(chain("chain_28b = motion_conv1_trans_28b + motion_conv2_trans_28b + motion_conv3_trans_28b", sa_, 256, 0, 256, 0, C1_28B, C2_28B, h->conv_w[C3_28B], h->conv_b[C3_28B], 64, sa_, sb_, 256, 0));   // :670-676
-      TRY(chain("chain_28c = motion_conv1_trans_28c + motion_conv2_trans_28c + motion_conv3_trans_28c", sb_, 256, 0, 256, 0, C1_28C, C2_28C, h->conv_w[C3_28C], h->conv_b[C3_28C], 64, sb_, F14_, 1056, 800)); // :679-685 -> cat at :760
-    } else {
-    TRY(conv(h, s, C1_28A, n, 14, View{xt_, 128, 64}, nullptr, 0, 0, RI | RP, t1_, 64, 0));        // :658-660
-    TRY(conv(h, s, C2_28A, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :661-662 t2
-    TRY(conv_merged(h, s, 0, n, 14, View{xt_, 128, 0}, RO, sa_, 256, 0));                           // :663-667
-    TRY(conv(h, s, C1_28B, n, 14, View{sa_, 256, 0}, nullptr, 0, 0, RP, t1_, 64, 0));              // :670-671
-    TRY(conv(h, s, C2_28B, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :672-673
-    TRY(conv(h, s, C3_28B, n, 14, View{xt_, 128, 0}, sa_, 256, 0, RO, sb_, 256, 0));                // :674-676
-    TRY(conv(h, s, C1_28C, n, 14, View{sb_, 256, 0}, nullptr, 0, 0, RP, t1_, 64, 0));              // :679-680
-    TRY(conv(h, s, C2_28C, n, 14, View{t1_, 64, 0}, nullptr, 0, 0, RP, xt_, 128, 0));              // :681-682
-    TRY(conv(h, s, C3_28C, n, 14, View{xt_, 128, 0}, sb_, 256, 0, RO, F14_, 1056, 800));            // :683-685 -> cat at :760
-    }
-    if (sev) HIP_TRY(h, hipEventRecord(sev[3], s));
-    if (out28) {   // 28-head (:782-787) beside fusion@14: only reads sum_28c
-      if (side_heads && forked) {
-        HIP_TRY(h, hipEventRecord(h->ev_fork[0], s));
-        HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[0], 0));
-      }
-      if (h->fold_pool) {     // pool-row partial sums + the FC as an MFMA GEMM (heads.hip) instead of pool_kernel + fc_kernel
-        float* pp = region(h, ws, "poolpart_28") + (size_t)4 * i0 * 256;
-        TRY(trace_mark(h, hs, "head_28 (max pool rows + fc)"));
-        HIP_TRY(h, maxpool_rows_launch(F14 + (size_t)i0 * 196 * 1056, 1056, 800, n, 14, 14, 256, pp, hs));
-        HIP_TRY(h, fc_pooled_launch(pp, 49, 1, n, 256, h->fc_w[1], h->fc_b[1], ncls, l28 + (size_t)i0 * ncls, hs));
-      } else {
-        TRY(run_head(hs, 1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28, i0, n));
+  // the batched GEMMs of a conv on a Winograd path: ONE launch of the 1x1 kernel, the K groups ride on gridDim.y (four launches
+  // left the short groups alone on the chip: slower than not skipping their zero products)
+  auto wino_gemms = [&](const char* key, const WinoGroup* grp, int ngrp, int npoints, int rows, int Ci, int Co, const float* V,
+                        const float* U, float* M) -> int {
+    const int K0 = grp[0].kmul * Ci;
+    ConvDesc d;
+    d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = rows; d.H = 1; d.W = 1; d.Ci = K0;
+    d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+    d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+    d.y = M; d.y_cs = Co; d.y_coff = 0;
+    d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+    d.batch = npoints; d.x_bstride = (long long)rows * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)rows * Co;
+    if (ngrp > 1) {
+      d.ngroups = ngrp;
+      for (int gi = 0; gi < ngrp; ++gi) {
+        d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
+        d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
       }
     }
-    // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
-    float *xu_ = at(xu, 7, 256), *u1_ = at(u1, 7, 128), *s14_ = at(s14, 7, 512);
-    // (from P = 40 pairs: below, its 132-K-tile GEMMs have too few row tiles to fill the chip and the split-K direct conv wins --
-    // B = 1: 0.435 vs 0.50 ms, B = 4: 0.672 vs 0.695, B = 8: 0.892 vs 0.874, B = 12: 1.157 vs 1.12; OFFK_WINOGRAD_5X5=<pairs> moves the gate)
-    if (wino && h->wino_5x5 && h->P >= h->wino5_min_p) TRY(wino_conv(C_T14, 5, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128, nullptr));   // :762-763 x1 (polyphase)
-    else
-    TRY(conv(h, s, C_T14, n, 14, View{F14_, 1056, 0}, nullptr, 0, 0, RP, xu_, 256, 128));          // :762-763 x1
-    TRY(conv(h, s, C1_14A, n, 7, View{xu_, 256, 128}, nullptr, 0, 0, RP, u1_, 128, 0));            // :764-765
-    if (wino) TRY(wino_conv(C2_14A, 3, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0, nullptr));   // :766-767 u2
-    else
-    TRY(conv(h, s, C2_14A, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :766-767 u2
-    TRY(conv_merged(h, s, 1, n, 7, View{xu_, 256, 0}, RO, s14_, 512, 0));                           // :768-771
-    TRY(conv(h, s, C1_14B, n, 7, View{s14_, 512, 0}, nullptr, 0, 0, RP, u1_, 128, 0));             // :773-774
-    if (wino) TRY(wino_conv(C2_14B, 4, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0, nullptr));   // :775-776
-    else
-    TRY(conv(h, s, C2_14B, n, 7, View{u1_, 128, 0}, nullptr, 0, 0, RP, xu_, 256, 0));              // :775-776
-    // (fold: the conv's epilogue also leaves per-slab column sums of sum_14b: the 14-head's average pool.  Slabs are 32
-    // rows of the whole pair range, so only a call on all pairs -- i0 = 0 -- can fold)
-    auto generic = [](int cfg) { return cfg != 6 && cfg != 7 && cfg != 10; };      // the LDS-patch kernels have no pooling epilogue
-    const bool fold = h->fold_pool && !h->pipe && i0 == 0 && n == P && generic(h->conv_cfg[C3_14B]) && generic(h->merged_cfg[2]);
-    float* pp14 = region(h, ws, "poolpart_14");
-    float* pp7 = region(h, ws, "poolpart_7");
-    float* pp14t = wino ? region(h, ws, "poolpart_14t") + (size_t)4 * i0 * 512 : nullptr;
-    const bool fold14t = wino && h->fold_pool && !h->pipe;
-    if (wino) {
-      TRY(wino_conv(C3_14B, 0, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320, fold14t ? pp14t : nullptr));   // :777-780 -> cat at :832
-    } else {
-      h->cur_pool_part = fold ? pp14 : nullptr;
-      int rc_ = conv(h, s, C3_14B, n, 7, View{xu_, 256, 0}, s14_, 512, 0, RP | RO, F7_, 832, 320);   // :777-780 -> cat at :832
-      h->cur_pool_part = nullptr;
-      if (rc_ != OFFK_OK) return rc_;
-    }
-    if (sev) HIP_TRY(h, hipEventRecord(sev[4], s));
-    {              // 14-head (:789-793) beside fusion@7: only reads sum_14b
-      if (side_heads && forked) {
-        HIP_TRY(h, hipEventRecord(h->ev_fork[1], s));
-        HIP_TRY(h, hipStreamWaitEvent(side, h->ev_fork[1], 0));
-      }
-      if (fold14t) {
-        TRY(trace_mark(h, hs, "head_14 (fc on folded pool)"));
-        HIP_TRY(h, fc_pooled_launch(pp14t, 49, 1, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14 + (size_t)i0 * ncls, hs));
-      } else if (fold && !wino) {
-        TRY(trace_mark(h, hs, "head_14 (fc on folded pool)"));
-        HIP_TRY(h, fc_pooled_launch(pp14, 49, 0, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, hs));
-      } else {
-        TRY(run_head(hs, 2, F7, 832, 320, 7, 512, 0, "pooled_14", l14, i0, n));
-      }
-    }
-    // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
-    float *xv_ = at(xv, 7, 512), *v1_ = at(v1, 7, 256), *s7_ = at(s7, 7, 1024);
-    if (wino) TRY(wino_conv(C_T7, 1, View{F7_, 832, 0}, nullptr, 0, 0, RP, xv_, 512, 256, nullptr));  // :833-834 x2
-    else
-    TRY(conv(h, s, C_T7, n, 7, View{F7_, 832, 0}, nullptr, 0, 0, RP, xv_, 512, 256));              // :833-834 x2
-    TRY(conv(h, s, C1_7, n, 7, View{xv_, 512, 256}, nullptr, 0, 0, RP, v1_, 256, 0));              // :835-836
-    if (wino) TRY(wino_conv(C2_7, 2, View{v1_, 256, 0}, nullptr, 0, 0, RP, xv_, 512, 0, nullptr));     // :837-838 v2
-    else
-    TRY(conv(h, s, C2_7, n, 7, View{v1_, 256, 0}, nullptr, 0, 0, RP, xv_, 512, 0));                // :837-838 v2
-    h->cur_pool_part = fold ? pp7 : nullptr;
-    { int rc_ = conv_merged(h, s, 2, n, 7, View{xv_, 512, 0}, 0, s7_, 1024, 0);                     // :839-841 (no ReLU)
-      h->cur_pool_part = nullptr;
-      if (rc_ != OFFK_OK) return rc_; }
-    if (sev) HIP_TRY(h, hipEventRecord(sev[5], s));
-    // ---- 7-head on the chain's stream (:843-847)
-    if (fold) {
-      TRY(trace_mark(h, s, "head_7 (fc on folded pool)"));
-      HIP_TRY(h, fc_pooled_launch(pp7, 49, 0, n, 1024, h->fc_w[0], h->fc_b[0], ncls, l7, s));
-    } else {
-      TRY(run_head(s, 0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7, i0, n));
-    }
+    const char* why = nullptr;
+    hipError_t e = conv2d_launch(d, s, &why);
+    if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
     return OFFK_OK;
   };
-  // Two-half pipeline (opt-in: OFFK_PIPELINE=1 at offk_create): the bottleneck chains between the big convs are small,
-  // latency-bound launches (a partial wave of blocks, 2-18 K-tiles each) that leave the matrix pipe half idle.  With the
-  // pairs split in two halves on two streams, the second half one big conv behind the first, a half's chain runs beside the
-  // other half's big conv.  Bit-identical to the single-stream order (per-output arithmetic does not depend on the split).
-  // Measured at B = 64 (same box): bf16x3 2.644 -> 2.622 ms, fp32 5.35 -> 5.44 ms (two MFMA-bound kernels sharing the CUs
-  // lose more than the chains gain) -- hence not the default.  Off while stage timing is on.
-  const bool pipelined = h->pipe && !ev && h->profiling == 0 && P >= 96;
-  if (!pipelined) {
-    TRY(fusion(st, 0, P, true, nullptr, ev));
-    if (forked) {
-      HIP_TRY(h, hipEventRecord(h->ev_join, side));
-      HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
-    }
+  // 3x3 / stride 1 conv on 7x7 maps (phases = 1) or the 5x5 / stride 2 conv on 14x14 maps in polyphase form (phases = 4) on the
+  // Winograd path: input transform, batched GEMMs, output transform with the conv's epilogue (winograd.hip)
+  const bool wino = h->winograd && h->cfg.precision == OFFK_PRECISION_FP32;
+  float* const wino_V = wino ? region(h, ws, "wino_v") : nullptr;
+  float* const wino_M = wino ? region(h, ws, "wino_m") : nullptr;
+  auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
+                       int y_coff, float* pool_t) -> int {
+    const ConvSpec& c = kConvs[id];
+    const int phases = c.K == 5 ? 4 : 1;          // rows of a batch entry: one per image
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
+    HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, phases, wino_V, s));
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 121 GEMMs]").c_str()));
+    WinoGroup grp[4];
+    const int ngrp = wino_groups(phases, n, c.Ci, c.Co, grp);
+    TRY(wino_gemms(c.key, grp, ngrp, kWinoPoints, n, c.Ci, c.Co, wino_V, h->wino_u[uidx], wino_M));
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()));
+    HIP_TRY(h, wino_output_launch(wino_M, n, c.Co, phases, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
+    return OFFK_OK;
+  };
+  // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
+  // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
+  // :657 x0, pre-ReLU kept for the branch.  fp32: polyphase Winograd F(5x5, 4x4) (winograd7.hip) -- input transform, 64 batched
+  // GEMMs in four K groups as ONE launch of the 1x1 kernel, output transform
+  // (from P = 12 pairs -- B = 2: 0.495 against 0.503 ms, B = 8: 0.813 against 0.874, B = 64: 3.88 against 4.24; B = 1: equal)
+  if (h->wino_u7 && wino && h->wino_7x7 && P >= h->wino7_min_p) {
+    const ConvSpec& c = kConvs[C_T28];
+    const int T = kWino7Tiles * n;
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
+    HIP_TRY(h, wino7_input_launch(F28, 320, 0, n, c.Ci, wino_V, s));
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 64 GEMMs]").c_str()));
+    WinoGroup grp[4];
+    const int ngrp = wino7_groups(T, c.Ci, c.Co, grp);
+    TRY(wino_gemms(c.key, grp, ngrp, kWino7Points, T, c.Ci, c.Co, wino_V, h->wino_u7, wino_M));
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()));
+    HIP_TRY(h, wino7_output_launch(wino_M, n, c.Co, h->conv_b[C_T28], 0, xt, 128, 64, s));
   } else {
-    const int nA = (P + 1) / 2, nB = P - nA;
-    float* slab = h->cur_splitk;
-    // each half gets its share of the split-K slab (rounded up; the region carries 128 floats of slack)
-    const size_t all = h->splitk_floats, half = ((all * (size_t)nA / (size_t)P) + 63) & ~(size_t)63;
-    HIP_TRY(h, hipEventRecord(h->ev_pipe[0], st));                 // units done
-    HIP_TRY(h, hipStreamWaitEvent(h->pipe, h->ev_pipe[0], 0));
-    h->splitk_floats = half;
-    int rc = fusion(st, 0, nA, false, h->ev_pipe[1], nullptr);
-    if (rc == OFFK_OK) {
-      hipError_t e = hipStreamWaitEvent(h->pipe, h->ev_pipe[1], 0);   // half B starts behind half A's first conv
-      h->cur_splitk = slab + half;
-      h->splitk_floats = all + 128 - half;
-      if (e == hipSuccess) rc = fusion(h->pipe, nA, nB, false, nullptr, nullptr);
-      else rc = fail_hip(h, e, "pipeline");
+    TRY(conv(h, s, C_T28, n, 28, View{F28, 320, 0}, nullptr, 0, 0, 0, xt, 128, 64));
+  }
+  // 1x1 -> 3x3 -> 1x1 (+ residual) as ONE launch per chain (exact fp32; a block owns half an image, t1 / t2 stay in LDS)
+  auto chain = [&](const char* name, const float* x, int x_cs, int x_coff, int Cin, int relu_in, ConvId c1, ConvId c2,
+                   const float* w3, const float* b3, int K3, const float* res, float* y, int y_cs, int y_coff) -> int {
+    ChainArgs a;
+    a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in;
+    a.w1 = h->conv_w[c1]; a.b1 = h->conv_b[c1]; a.w2 = h->conv_w[c2]; a.b2 = h->conv_b[c2];
+    a.w3 = w3; a.b3 = b3; a.K3 = K3;
+    a.res = res; a.res_cs = 256; a.res_coff = 0;
+    a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
+    a.n_img = n; a.relu_out = 1;
+    const unsigned long long xb = ((unsigned long long)n * 196 * x_cs - x_coff) * 4ull;
+    a.x_bytes = xb < 0x7fffffffull ? (unsigned)xb : 0u;
+    { int rc = trace_mark(h, s, name); if (rc != OFFK_OK) return rc; }
+    const char* why = nullptr;
+    hipError_t e = chain14_launch(a, s, &why);
+    if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
+    return OFFK_OK;
+  };
+  // (from P = 72 pairs: a chain block walks its three convs alone -- 45 us per launch however few blocks there are; B = 8: three
+  //  convs per chain 0.885 ms per forward against 0.90, B = 16: 1.37 against 1.345; OFFK_CHAIN=<pairs> moves the gate)
+  const bool chained = h->chain && P >= h->chain_min_p && h->cfg.precision == OFFK_PRECISION_FP32 && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
+  if (chained) {
+    TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
+              nullptr, sa, 256, 0));                                                              // :658-667
+    TRY(chain("chain_28b = motion_conv1_trans_28b + motion_conv2_trans_28b + motion_conv3_trans_28b", sa, 256, 0, 256, 0, C1_28B, C2_28B, h->conv_w[C3_28B], h->conv_b[C3_28B], 64, sa, sb, 256, 0));   // :670-676
+    TRY(chain("chain_28c = motion_conv1_trans_28c + motion_conv2_trans_28c + motion_conv3_trans_28c", sb, 256, 0, 256, 0, C1_28C, C2_28C, h->conv_w[C3_28C], h->conv_b[C3_28C], 64, sb, F14, 1056, 800)); // :679-685 -> cat at :760
+  } else {
+    TRY(conv(h, s, C1_28A, n, 14, View{xt, 128, 64}, nullptr, 0, 0, RI | RP, t1, 64, 0));         // :658-660
+    TRY(conv(h, s, C2_28A, n, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));               // :661-662 t2
+    TRY(conv_merged(h, s, 0, n, 14, View{xt, 128, 0}, RO, sa, 256, 0));                            // :663-667
+    TRY(conv(h, s, C1_28B, n, 14, View{sa, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));               // :670-671
+    TRY(conv(h, s, C2_28B, n, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));               // :672-673
+    TRY(conv(h, s, C3_28B, n, 14, View{xt, 128, 0}, sa, 256, 0, RO, sb, 256, 0));                  // :674-676
+    TRY(conv(h, s, C1_28C, n, 14, View{sb, 256, 0}, nullptr, 0, 0, RP, t1, 64, 0));               // :679-680
+    TRY(conv(h, s, C2_28C, n, 14, View{t1, 64, 0}, nullptr, 0, 0, RP, xt, 128, 0));               // :681-682
+    TRY(conv(h, s, C3_28C, n, 14, View{xt, 128, 0}, sb, 256, 0, RO, F14, 1056, 800));              // :683-685 -> cat at :760
+  }
+  if (ev) HIP_TRY(h, hipEventRecord(ev[3], s));
+  if (out28) {   // 28-head (:782-787): only reads sum_28c
+    if (h->fold_pool) {     // pool-row partial sums + the FC as an MFMA GEMM (heads.hip) instead of pool_kernel + fc_kernel
+      float* pp = region(h, ws, "poolpart_28");
+      TRY(trace_mark(h, s, "head_28 (max pool rows + fc)"));
+      HIP_TRY(h, maxpool_rows_launch(F14, 1056, 800, n, 14, 14, 256, pp, s));
+      HIP_TRY(h, fc_pooled_launch(pp, 49, 1, n, 256, h->fc_w[1], h->fc_b[1], ncls, l28, s));
+    } else {
+      TRY(run_head(1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28));
     }
-    h->cur_splitk = slab; h->splitk_floats = all;
-    if (rc != OFFK_OK) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev_pipe[2], h->pipe));
-    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_pipe[2], 0));
+  }
+  // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
+  // (from P = 40 pairs: below, its 132-K-tile GEMMs have too few row tiles to fill the chip and the split-K direct conv wins --
+  // B = 1: 0.435 vs 0.50 ms, B = 4: 0.672 vs 0.695, B = 8: 0.892 vs 0.874, B = 12: 1.157 vs 1.12; OFFK_WINOGRAD_5X5=<pairs> moves the gate)
+  if (wino && h->wino_5x5 && P >= h->wino5_min_p) TRY(wino_conv(C_T14, 5, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128, nullptr));   // :762-763 x1 (polyphase)
+  else TRY(conv(h, s, C_T14, n, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128));        // :762-763 x1
+  TRY(conv(h, s, C1_14A, n, 7, View{xu, 256, 128}, nullptr, 0, 0, RP, u1, 128, 0));               // :764-765
+  if (wino) TRY(wino_conv(C2_14A, 3, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0, nullptr));  // :766-767 u2
+  else TRY(conv(h, s, C2_14A, n, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));            // :766-767 u2
+  TRY(conv_merged(h, s, 1, n, 7, View{xu, 256, 0}, RO, s14, 512, 0));                              // :768-771
+  TRY(conv(h, s, C1_14B, n, 7, View{s14, 512, 0}, nullptr, 0, 0, RP, u1, 128, 0));                // :773-774
+  if (wino) TRY(wino_conv(C2_14B, 4, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0, nullptr));  // :775-776
+  else TRY(conv(h, s, C2_14B, n, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));            // :775-776
+  // (fold: the conv's epilogue also leaves per-slab column sums of sum_14b: the 14-head's average pool)
+  auto generic = [](int cfg) { return cfg != 6 && cfg != 7 && cfg != 10; };      // the LDS-patch kernels have no pooling epilogue
+  const bool fold = h->fold_pool && generic(h->conv_cfg[C3_14B]) && generic(h->merged_cfg[2]);
+  float* pp14 = region(h, ws, "poolpart_14");
+  float* pp7 = region(h, ws, "poolpart_7");
+  float* pp14t = wino ? region(h, ws, "poolpart_14t") : nullptr;
+  const bool fold14t = wino && h->fold_pool;
+  if (wino) {
+    TRY(wino_conv(C3_14B, 0, View{xu, 256, 0}, s14, 512, 0, RP | RO, F7, 832, 320, fold14t ? pp14t : nullptr));   // :777-780 -> cat at :832
+  } else {
+    h->cur_pool_part = fold ? pp14 : nullptr;
+    int rc_ = conv(h, s, C3_14B, n, 7, View{xu, 256, 0}, s14, 512, 0, RP | RO, F7, 832, 320);   // :777-780 -> cat at :832
+    h->cur_pool_part = nullptr;
+    if (rc_ != OFFK_OK) return rc_;
+  }
+  if (ev) HIP_TRY(h, hipEventRecord(ev[4], s));
+  // 14-head (:789-793): only reads sum_14b
+  if (fold14t) {
+    TRY(trace_mark(h, s, "head_14 (fc on folded pool)"));
+    HIP_TRY(h, fc_pooled_launch(pp14t, 49, 1, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, s));
+  } else if (fold && !wino) {
+    TRY(trace_mark(h, s, "head_14 (fc on folded pool)"));
+    HIP_TRY(h, fc_pooled_launch(pp14, 49, 0, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, s));
+  } else {
+    TRY(run_head(2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));
+  }
+  // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
+  if (wino) TRY(wino_conv(C_T7, 1, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256, nullptr));  // :833-834 x2
+  else TRY(conv(h, s, C_T7, n, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256));            // :833-834 x2
+  TRY(conv(h, s, C1_7, n, 7, View{xv, 512, 256}, nullptr, 0, 0, RP, v1, 256, 0));                 // :835-836
+  if (wino) TRY(wino_conv(C2_7, 2, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0, nullptr));    // :837-838 v2
+  else TRY(conv(h, s, C2_7, n, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0));              // :837-838 v2
+  h->cur_pool_part = fold ? pp7 : nullptr;
+  { int rc_ = conv_merged(h, s, 2, n, 7, View{xv, 512, 0}, 0, s7, 1024, 0);                        // :839-841 (no ReLU)
+    h->cur_pool_part = nullptr;
+    if (rc_ != OFFK_OK) return rc_; }
+  if (ev) HIP_TRY(h, hipEventRecord(ev[5], s));
+  // ---- 7-head (:843-847)
+  if (fold) {
+    TRY(trace_mark(h, s, "head_7 (fc on folded pool)"));
+    HIP_TRY(h, fc_pooled_launch(pp7, 49, 0, n, 1024, h->fc_w[0], h->fc_b[0], ncls, l7, s));
+  } else {
+    TRY(run_head(0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7));
   }
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;

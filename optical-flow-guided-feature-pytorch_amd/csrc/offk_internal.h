@@ -36,8 +36,6 @@ struct ConvDesc {
   long long g_x[4] = {0, 0, 0, 0}, g_w[4] = {0, 0, 0, 0}, g_y[4] = {0, 0, 0, 0};
   float* pool_part = nullptr;             // != nullptr: [ceil(M / 32)][2][Co] partial column sums of the stored output (heads.hip: fc_pooled)
   int pool_hw = 0;                        //   rows per image (>= 32); forces splitk = 1
-  int plan_n_img = 0;                     // > 0: the automatic plan is the one of this many images (a call on part of a batch
-                                          // then splits K exactly as the whole-batch call: same bits)
 };
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out, int precision);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
@@ -143,9 +141,8 @@ struct PtParams {
   int nsites, total_blocks;
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
-  int bdirect;               // every site carries wt: the weight operand bypasses LDS (two LDS stages for the feature-map tile)
-  int dma;                   // fp32 + bdirect: 2 = the 16-pixel LDS-DMA form (pw_tdiff16_kernel), 1 = the 32-pixel one (pw_tdiff_dma_kernel),
-                             // 0 = register-staged (OFFK_PW_DMA at offk_create)
+  int bdirect;               // every site carries wt / wt16: the weight operand bypasses LDS.  Exact fp32 then runs the 16-pixel LDS-DMA
+                             // form (pw_tdiff16_kernel), bf16x3 the register-staged kernel with two LDS stages for the feature-map tile
   const float* zeros;
 #ifdef OFFK_PT_TIMING
   unsigned long long* dbg;   // cycle-counter sums (tools only)

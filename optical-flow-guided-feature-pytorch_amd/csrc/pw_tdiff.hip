@@ -491,277 +491,9 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// DMA form (exact fp32 only, round 3): the feature-map tile goes global -> LDS by the load unit itself
-// (`buffer_load_dwordx4 ... lds`, 1 KB per wave instruction) in the layout the maps already have -- per frame [32 k][32
-// pixels], a k row = one 128-byte run of NCHW -- so there is no prefetch register set, no register transpose (32 v_mov per
-// thread and K-tile in the BD form) and no ds_write in the K loop.  Lane (r32, h) of MFMA (g, e) needs
-// X[k = 8g + 4h + e][pixel r32]: one dword read, 256 contiguous bytes per wave instruction (conflict-free), so the x
-// operand is read as plain dwords (the ISA of the BD form showed each ds_read_b128 issued right in front of its first
-// MFMA, i.e. one exposed LDS latency per eight MFMAs; here the reads of unit u + 2 are issued before the MFMAs of unit u).
-// The weight operand stays direct-to-register (pw_pack_direct_kernel image) but is loaded through inline asm with
-// hand-counted `s_waitcnt vmcnt`: the compiler does not see the DMA instructions, so the counts it would emit for
-// builtin loads treat every DMA issued in between as a load that must have landed (a memory latency per K-tile).
-// Queue per step, in issue order: the seven DMAs of tile kt + 1 go out one behind each of the first seven units (bunched
-// at the top of the step they cost the wave 60-180 cycles each with nothing multiplying behind them: 1.335 -> 1.318 ms),
-// and behind k-group g the two weight loads of (kt + 1, g).  In front of group 0 the weights of (kt, 0) must be there =
-// all but the 6 newest operations; in front of groups 1-3 all but the 13 newest; at the end of the step the DMAs = all but
-// the 8 newest.  `wave` is made an SGPR (readfirstlane): as a VGPR it turned the scalar offset of every weight load into
-// a waterfall loop inside the MFMA stream.
-// Measured and not kept (profiles/r03/k1t_experiments.txt): a persistent form (2 x CUs resident blocks pulling items from
-// a device-side queue, the K-tile stream running across items: 1.335 ms, no gain -- dispatch gaps and prologues were not
-// the loss); MFMAs of two units interleaved so that no two consecutive ones share an accumulator (1.35 ms, no gain).  The
-// timing build (-DOFFK_PT_TIMING) says why: with two blocks per CU a K-tile takes a wave 17.6 k cycles of issue + 1.9 k at
-// the barrier against 18.4 k for two waves sharing a SIMD's pipe; a block ALONE on its CU needs 11.1 k per K-tile against
-// 9.2 k (83 %), so whenever the partner block is in its epilogue (~19 k cycles per item) or at a barrier the pipe is not
-// full, and three blocks per CU do not fit (202 VGPRs, 56 KB of LDS).
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void pw_tdiff_dma_kernel(PtParams p) {
-  constexpr int FRAME_B = 32 * 128;              // one frame's K-tile image [32 k][32 pixels] fp32
-  constexpr int STAGE_B = PT_FT * FRAME_B;       // 28 KB; two stages
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-
-  PtSite S;
-  int nblk_site;
-#define OFFK_PT_PICK(i)                                                                                \
-  S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;                           \
-  S.bias_down = p.s[i].bias_down; S.wt = p.s[i].wt;                                                    \
-  S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
-  S.nrem = p.s[i].nrem; S.rsh = p.s[i].rsh;                                                            \
-  S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
-  nblk_site = (i + 1 < p.nsites ? p.s[i + 1].blk_begin : p.total_blocks) - p.s[i].blk_begin;          \
-  S.xp[0] = p.s[i].xp[0]; S.xp[1] = p.s[i].xp[1]; S.xp[2] = p.s[i].xp[2]; S.xp[3] = p.s[i].xp[3];     \
-  S.cp[0] = p.s[i].cp[0]; S.cp[1] = p.s[i].cp[1]; S.cp[2] = p.s[i].cp[2]; S.cp[3] = p.s[i].cp[3];
-  OFFK_PT_PICK(0)
-#pragma unroll
-  for (int i = 1; i < kNumSites; ++i)
-    if (i < p.nsites && (int)blockIdx.x >= p.s[i].blk_begin) { OFFK_PT_PICK(i) }
-#undef OFFK_PT_PICK
-  const int C = S.C, HW = S.HW, L = p.L;
-  int local = xcd_contiguous((int)blockIdx.x - S.blk_begin, nblk_site);
-  const int tg = local % p.tgroups; local /= p.tgroups;
-  const int nfull = p.B * S.chunks;
-  const bool leftover = local >= nfull;
-  const int rsh = leftover ? S.rsh : 5, rmask = (1 << rsh) - 1;
-  const int b = leftover ? (local - nfull) << (5 - rsh) : local / S.chunks;
-  const int q0 = (leftover ? S.chunks : local - b * S.chunks) * 32;
-  const int t0 = tg * (PT_FT - 1);
-  const int nf = min(PT_FT, L - t0);
-  const bool last_group = tg == p.tgroups - 1;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int r32 = lane & 31, h = lane >> 5;
-
-  // ---- DMA lane mapping: k row 8 * wave + (lane >> 3) of the K-tile, pixel quad lane & 7; instruction i = frame i ----
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const int pq = lane & 7;
-  const int cq = (4 * pq) >> rsh;                                  // clip of the quad within the block (0 unless packed)
-  const int k0px = q0 + ((4 * pq) & rmask);
-  const bool px_ok = k0px < HW && b + cq < p.B;
-  const int vbase = px_ok ? ((8 * wave + (lane >> 3)) * HW + k0px) * 4 : (int)0x80000000;   // past every descriptor -> zeros
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) + (unsigned)wave * 1024u;
-  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
-  };
-  // tile kt -> LDS stage: dma_prep computes the descriptor and offsets (scalar + one vector multiply-add), dma_issue sends
-  // frame i.  In the K loop the seven DMAs go out one behind each of the first seven units of a step: issued in a bunch at
-  // the top of the step they cost the wave ~60-180 cycles each with nothing multiplying behind them (a block alone on its
-  // CU ran at 74 % of the matrix pipe, two at 84 %).
-  i32x4 dm_desc = {0, 0, 0, 0};
-  int dm_fstride = 0, dm_s0 = 0, dm_vclip = 0;
-  auto dma_prep = [&](int kt) {
-    const float* xb = S.xp[0]; int cpart = S.cp[0], kl = kt * BK;
-    if (S.nparts > 1 && kl >= S.cp[0]) {
-      kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
-      if (S.nparts > 2 && kl >= S.cp[1]) {
-        kl -= S.cp[1]; xb = S.xp[2]; cpart = S.cp[2];
-        if (S.nparts > 3 && kl >= S.cp[2]) { kl -= S.cp[2]; xb = S.xp[3]; cpart = S.cp[3]; }
-      }
-    }
-    const unsigned long long xa = reinterpret_cast<unsigned long long>(xb);
-    dm_desc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
-    dm_fstride = cpart * HW * 4;                                      // bytes per frame of this part (scalar)
-    dm_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;                   // scalar: frame t0, channel kl
-    dm_vclip = cq * L * dm_fstride + vbase;                           // an invalid vbase stays >= 2^31 (the sum is < 2^30 more)
-  };
-  auto dma_issue = [&](const int i, const int stage) {
-    const int voff = i < nf ? dm_vclip + i * dm_fstride : (int)0x80000000;   // frame slot past the group: zeros
-    dma16(dm_desc, lds_base + stage * STAGE_B + i * FRAME_B, voff, dm_s0);
-  };
-  auto dma_tile = [&](int kt, const int stage) {
-    dma_prep(kt);
-#pragma unroll
-    for (int i = 0; i < PT_FT; ++i) dma_issue(i, stage);
-  };
-
-  // ---- weight operand: asm loads into bq (hand-counted waits, see the header) ----
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 bq[8];                  // [0..3]: this wave's 32 gen rows, k-group g; [4..7]: the 32 down rows
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x4 wdesc;
-  {
-    const unsigned long long wa = reinterpret_cast<unsigned long long>(S.wt);
-    wdesc = i32x4{(int)(unsigned)wa, (int)(unsigned)(wa >> 32) & 0xffff, kUnitCh * C * 4, 0x00020000};
-  }
-  const int wlane = lane * 16;
-  auto load_w = [&](const int sel, const int g, int kt) {
-    const int soff = ((kt * 5 + (sel ? 4 : wave)) * 4 + g) * 1024;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(bq[sel * 4 + g]) : "v"(wlane), "s"(wdesc), "s"(soff));
-  };
-  // all but the newest N vector-memory operations are done; ties the registers the MFMAs of group g read to the wait
-#define OFFK_WAIT_W(N, g) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[g]), "+v"(bq[4 + (g)]))
-
-  f32x16 acc[PT_FT + 2];
-#pragma unroll
-  for (int t = 0; t < PT_FT + 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  const bool d1 = wave + 4 < PT_FT;          // waves 0-2 own a second down tile
-  const int nkt = C / BK;
-  // x operand of unit (g, t): lane (r32, h) reads k rows 8g + 4h + e, e = 0..3, of frame f(t) at pixel r32
-  const char* const xl = lds + h * 512 + r32 * 4;
-  const char* const xld = xl + wave * FRAME_B;
-  const char* const xld2 = xl + min(wave + 4, PT_FT - 1) * FRAME_B;     // wave 3 has no second down tile: its unit 8 reads are unused
-  auto rdx = [&](float (&x)[4], const int st, const int g, const int t) {
-    const char* q = (t < PT_FT ? xl + t * FRAME_B : (t == PT_FT ? xld : xld2)) + st * STAGE_B + g * 1024;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = *reinterpret_cast<const float*>(q + e * 128);
-  };
-  auto mm4 = [&](f32x16& c, const f32x4& w, const float (&x)[4]) {
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x[3], c, 0, 0, 0);
-  };
-  // one K-tile out of stage `st`: nine units per k-group (7 gen tiles, the down tiles of frames `wave` and, waves 0-2,
-  // wave + 4), x reads two units ahead; behind group g the weight registers of group g are re-loaded for tile ktn
-  auto mma = [&](const int st, int ktn) {
-    constexpr int NU = PT_FT + 2, TOT = 4 * NU;
-    float x[3][4];
-    rdx(x[0], st, 0, 0);
-    rdx(x[1], st, 0, 1);
-#pragma unroll
-    for (int u = 0; u < TOT; ++u) {
-      const int g = u / NU, t = u % NU;
-      if (u + 2 < TOT) rdx(x[(u + 2) % 3], st, (u + 2) / NU, (u + 2) % NU);
-      if (t == 0) {      // group 0 waits before this step's DMAs are in the queue: 6 newer weight loads only
-        if (g == 0) OFFK_WAIT_W(6, 0); else if (g == 1) OFFK_WAIT_W(13, 1); else if (g == 2) OFFK_WAIT_W(13, 2); else OFFK_WAIT_W(13, 3);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t < NU - 1 || d1) mm4(acc[t], bq[t < PT_FT ? g : 4 + g], x[u % 3]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g == 0 && t < PT_FT) dma_issue(t, st ^ 1);      // every wave has left stage st ^ 1 at the last barrier
-      if (t == NU - 1) { load_w(0, g, ktn); load_w(1, g, ktn); }
-    }
-  };
-#ifdef OFFK_PT_TIMING
-  unsigned long long tm_mma = 0, tm_wait = 0, tm_bar = 0;
-  const unsigned long long tm_begin = __builtin_readcyclecounter();
-#define OFFK_STAMP(var, stmt) { const unsigned long long q0_ = __builtin_readcyclecounter(); stmt; var += __builtin_readcyclecounter() - q0_; }
-#else
-#define OFFK_STAMP(var, stmt) stmt;
-#endif
-  auto step = [&](int kt, const int st) {
-    OFFK_STAMP(tm_mma, dma_prep(min(kt + 1, nkt - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    mma(st, min(kt + 1, nkt - 1)))
-    OFFK_STAMP(tm_wait, asm volatile("s_waitcnt vmcnt(8)" ::: "memory"))   // this wave's DMAs of the step have landed
-    OFFK_STAMP(tm_bar, __syncthreads())
-  };
-  // prologue: tile 0 and the weights of tile 0 (queue: 7 DMAs, 8 weight loads), then as every step leaves it:
-  // 8 weight loads in flight in front of the next step's DMAs
-  dma_tile(0, 0);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { load_w(0, g, 0); load_w(1, g, 0); }
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __syncthreads();
-#ifdef OFFK_PT_TIMING
-  const unsigned long long tm_loop = __builtin_readcyclecounter();
-#endif
-  int kt = 0;
-  for (; kt + 1 < nkt; kt += 2) {
-    step(kt, 0);
-    step(kt + 1, 1);
-  }
-  if (kt < nkt) step(kt, 0);
-#ifdef OFFK_PT_TIMING
-  const unsigned long long tm_epi = __builtin_readcyclecounter();
-#endif
-#undef OFFK_STAMP
-  // nothing may still be landing when the LDS is handed on -- and the weight registers stay allocated until the last asm load
-  // into them has returned: with their values dead after the last step the compiler re-used them as temporaries while
-  // the loads were still in flight (wrong x operands in the tail step of the two odd-K sites)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bq[4]), "+v"(bq[5]), "+v"(bq[6]), "+v"(bq[7]) :: "memory");
-#undef OFFK_WAIT_W
-
-  // ---- epilogue (as pw_tdiff_kernel): G = relu(acc + bias) in registers, T = G[j+1] - G[j] -> M; D -> HBM ----
-  float4 bg4[4], bd4[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    bg4[g] = *reinterpret_cast<const float4*>(S.bias + wave * 32 + 8 * g + 4 * h);
-    bd4[g] = *reinterpret_cast<const float4*>(S.bias_down + 8 * g + 4 * h);
-  }
-#pragma unroll
-  for (int j = 0; j < PT_FT; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 v = make_float4(fmaxf(acc[j][4 * g] + bg4[g].x, 0.f), fmaxf(acc[j][4 * g + 1] + bg4[g].y, 0.f),
-                             fmaxf(acc[j][4 * g + 2] + bg4[g].z, 0.f), fmaxf(acc[j][4 * g + 3] + bg4[g].w, 0.f));
-      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-      acc[j][4 * g] = v.x; acc[j][4 * g + 1] = v.y; acc[j][4 * g + 2] = v.z; acc[j][4 * g + 3] = v.w;
-    }
-#pragma unroll
-  for (int t = PT_FT; t < PT_FT + 2; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 v = make_float4(acc[t][4 * g] + bd4[g].x, acc[t][4 * g + 1] + bd4[g].y, acc[t][4 * g + 2] + bd4[g].z, acc[t][4 * g + 3] + bd4[g].w);
-      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-      acc[t][4 * g] = v.x; acc[t][4 * g + 1] = v.y; acc[t][4 * g + 2] = v.z; acc[t][4 * g + 3] = v.w;
-    }
-  const int bl = b + (r32 >> rsh), pixl = q0 + (r32 & rmask);      // this lane's clip and pixel
-  const size_t pair0 = (size_t)bl * (L - 1) + t0;
-  const bool pix_ok = pixl < HW && bl < p.B;
-#pragma unroll
-  for (int j = 0; j + 1 < PT_FT; ++j) {
-    if (j + 1 < nf && pix_ok) {
-      float* mrow = S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f4v tv = {acc[j + 1][4 * g] - acc[j][4 * g], acc[j + 1][4 * g + 1] - acc[j][4 * g + 1],
-                        acc[j + 1][4 * g + 2] - acc[j][4 * g + 2], acc[j + 1][4 * g + 3] - acc[j][4 * g + 3]};
-        *reinterpret_cast<f4v*>(mrow + 8 * g) = tv;
-      }
-    }
-  }
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int j = wave + 4 * half;
-    if (j < nf && (last_group || j < PT_FT - 1) && pix_ok) {
-      const int dr = pt_down_row(bl, t0 + j, L, p.P, p.slice_mode);
-      if (dr >= 0) {
-        float* drow = S.D + ((size_t)dr * HW + pixl) * kDownCh + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f4v dv = {acc[PT_FT + half][4 * g], acc[PT_FT + half][4 * g + 1], acc[PT_FT + half][4 * g + 2], acc[PT_FT + half][4 * g + 3]};
-          *reinterpret_cast<f4v*>(drow + 8 * g) = dv;
-        }
-      }
-    }
-  }
-#ifdef OFFK_PT_TIMING
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (p.dbg && lane == 0 && wave == 0) {
-    const unsigned long long tm_end = __builtin_readcyclecounter();
-    atomicAdd(p.dbg + 0, tm_loop - tm_begin); atomicAdd(p.dbg + 1, tm_epi - tm_loop); atomicAdd(p.dbg + 2, tm_end - tm_epi);
-    atomicAdd(p.dbg + 3, tm_mma); atomicAdd(p.dbg + 4, tm_wait); atomicAdd(p.dbg + 5, tm_bar);
-    atomicAdd(p.dbg + 6, (unsigned long long)nkt); atomicAdd(p.dbg + 7, 1ull);
-  }
-#endif
-}
-
+// (Round 3 also built a 32-pixel LDS-DMA form of this kernel -- pw_tdiff_dma_kernel, 32x32x2 tiles, two blocks per CU: 1.318 ms at
+//  B = 64 against 1.246 ms for the 16-pixel form below.  It was retired from the product build in round 4; DESIGN.md section 16.1
+//  keeps its measurements, the git history its text.)
 // ---------------------------------------------------------------------------------------------------------------
 // 16-pixel form of the LDS-DMA kernel (round 3): v_mfma_f32_16x16x4_f32 tiles, a block owns (clip, 16-pixel chunk) x all
 // frames.  Why: pw_tdiff_dma_kernel keeps 9 accumulator tiles of 32x32 per wave (144 registers, 202 in all), so two blocks per
@@ -1096,23 +828,18 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #endif
   constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4, kStageB3 = 2 * (size_t)(PT_BM + PT_BN) * B3_ROW;
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
-  constexpr size_t kStageA32 = (size_t)PT_BM * LDS_K * 4, kStageAB3 = 2 * (size_t)PT_BM * B3_ROW;   // BD: feature-map tile only, two stages
+  constexpr size_t kStageAB3 = 2 * (size_t)PT_BM * B3_ROW;   // BD (bf16x3): feature-map tile only, two stages
 #define OFFK_PT_LAUNCH_BD(P)                                                                                         \
-  if (P == 0 && form16) {                                                                                            \
+  if (P == 0) {              /* exact fp32 + direct weights: always the 16-pixel LDS-DMA form */                      \
     constexpr int k16Lds = 2 * PT_FT * 32 * 64 + 1024;                                                               \
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff16_kernel), k16Lds);                         \
     if (er != hipSuccess) return er;                                                                                 \
     hipLaunchKernelGGL(pw_tdiff16_kernel, dim3(p.total_blocks), dim3(256), k16Lds, st, p);                           \
-  } else if (P == 0 && p.dma) {                                                                                      \
-    constexpr int kDmaLds = 2 * PT_FT * 32 * 128;                                                                    \
-    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_dma_kernel), kDmaLds);                      \
+  } else {                                                                                                           \
+    const size_t bytes = 2 * kStageAB3;                                                                              \
+    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 0, 0, 1, 1>), (int)bytes);        \
     if (er != hipSuccess) return er;                                                                                 \
-    hipLaunchKernelGGL(pw_tdiff_dma_kernel, dim3(p.total_blocks), dim3(256), kDmaLds, st, p);                        \
-  } else {                                                                                                                  \
-    const size_t bytes = 2 * (P == 0 ? kStageA32 : kStageAB3);                                                       \
-    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<P, 0, 0, 1, 1>), (int)bytes);        \
-    if (er != hipSuccess) return er;                                                                                 \
-    hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 1, 1>), dim3(p.total_blocks), dim3(256), bytes, st, p);             \
+    hipLaunchKernelGGL((pw_tdiff_kernel<1, 0, 0, 1, 1>), dim3(p.total_blocks), dim3(256), bytes, st, p);             \
   }
   // buffer addressing needs every byte offset below 2^31: each feature-map part and the weight tables
   bool lean = true;
@@ -1131,7 +858,7 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   const bool pc_form = p.precision == 1 && pce && *pce == '1';
   if (pc_form) lean = bd = pack = false;
 #endif
-  const bool form16 = p.precision == 0 && p.dma == 2 && bd;      // the 16-pixel form (pw_tdiff16_kernel)
+  const bool form16 = p.precision == 0 && bd;      // exact fp32 with the library's own weight image: the 16-pixel form (pw_tdiff16_kernel)
   auto layout = [&]() {      // block layout of every site (PtSite)
     if (form16) {
       int blk = 0;

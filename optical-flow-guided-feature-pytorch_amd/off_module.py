@@ -321,12 +321,21 @@ class BNInception_OFF(nn.Module):
             return self.RGB_OFF_forward(input)
         feats, fgs, conv2 = self._features(input)
         fc7, fc14, _fc28 = self.off(feats, want28=False)
+        # K6 / K7 are raw library calls on data_ptr: they do not record an autograd graph.  The reference uses this path at test time
+        # only (test_flow_off.py:343 under volatile=True); when a caller DOES want gradients through the backbone's score (grad mode
+        # on and the score requires grad) the same arithmetic runs as torch ops so the graph stays intact.
+        wants_grad = torch.is_grad_enabled() and fgs is not None and fgs.requires_grad
         if fgs is not None and fgs.shape[0] == self.batch * self.length:
-            fgs = runtime.segment_consensus(fgs.contiguous().float(), self.batch)   # Flow_OFF.py:867,873 (K6)
+            if wants_grad:
+                fgs = fgs.float().view(self.batch, self.length, -1).mean(dim=1)          # basic_ops.py:19-21
+            else:
+                fgs = runtime.segment_consensus(fgs.contiguous().float(), self.batch)   # Flow_OFF.py:867,873 (K6)
         if self.modality_fuse:
             if fgs is None:
                 raise ValueError("modality_fuse adds the backbone's Feature_Generation_Score (Flow_OFF.py:881): "
                                  "attach a backbone that returns it")
+            if wants_grad or fc7.requires_grad or fc14.requires_grad:
+                return fc7 + fgs.to(fc7.dtype) + fc14                                    # Flow_OFF.py:881, differentiable
             # Flow_OFF.py:881 `fc7 + fgs + fc14`: K7 with unit weights and one "crop" (offk_score_fusion), not a torch op
             fused, _ = runtime.score_fusion([fc7, fgs.to(fc7.dtype).contiguous(), fc14], (1.0, 1.0, 1.0), want_pred=False)
             return fused

@@ -1,0 +1,46 @@
+"""CPU test of build.py's resource guard: the kernels that count their own `s_waitcnt vmcnt(N)` must
+compile without register spills / scratch and inside the register budget their blocks-per-CU plan assumes.  The guard runs at
+build time; this pins the table and shows that it fires."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def build_mod():
+    path = os.path.join(ROOT, "optical-flow-guided-feature-pytorch_amd", "build.py")
+    spec = importlib.util.spec_from_file_location("offk_build_guard", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()                      # no-op when the objects are current
+    return mod
+
+
+def test_guarded_kernels_have_no_spills_and_fit_their_budget(build_mod):
+    table = build_mod.resource_table()
+    assert set(table) == {"pw_tdiff.hip", "chain_fused.hip", "conv_igemm.hip"}
+    k16 = [k for k in table["pw_tdiff.hip"] if "pw_tdiff16_kernel" in k["name"]]
+    assert len(k16) == 1 and k16[0]["vgpr_count"] <= 168
+    chains = [k for k in table["chain_fused.hip"] if "chain14_kernel" in k["name"]]
+    assert len(chains) == 3 and all(k["vgpr_count"] <= 168 for k in chains)
+    dflt = [k for k in table["conv_igemm.hip"] if ", 1, 1, 2, 2, 4>" in k["name"]]
+    assert len(dflt) == 4 and all(k["vgpr_count"] <= 96 for k in dflt)          # 1x1, 3x3, 5x5 / 2, 7x7 / 2
+    for rows in table.values():
+        for k in rows:
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    for k in k16 + chains + dflt:
+        assert k["sgpr_spill_count"] == 0, k
+
+
+def test_guard_fires(build_mod):
+    ok = {"name": "offk::pw_tdiff16_kernel(offk::PtParams)", "vgpr_count": 152, "agpr_count": 0, "vgpr_spill_count": 0,
+          "sgpr_spill_count": 0, "private_segment_fixed_size": 0}
+    assert build_mod.check_resources("pw_tdiff.hip", [ok]) == [ok]
+    for bad in ({"vgpr_spill_count": 2, "private_segment_fixed_size": 12}, {"vgpr_count": 176}, {"sgpr_spill_count": 3}):
+        with pytest.raises(RuntimeError, match="resource guard failed"):
+            build_mod.check_resources("pw_tdiff.hip", [dict(ok, **bad)])
+    with pytest.raises(RuntimeError, match="no kernel of pw_tdiff.hip matches"):
+        build_mod.check_resources("pw_tdiff.hip", [dict(ok, name="offk::renamed_kernel(offk::PtParams)")])

@@ -375,32 +375,6 @@ def test_full_size_b64_vs_oracle(rt, prec):
     assert torch.equal(out7, o7b)
 
 
-@pytest.mark.parametrize("prec", PRECISIONS)
-def test_side_stream_heads_bit_identical(rt, prec, monkeypatch):
-    """With OFFK_SIDE_STREAM=1 the 28- and 14-heads run on the handle's side stream beside fusion@14/@7 (offk_api.hip).
-    Repeated full-size forwards must give the same bits as the default handle (everything on the caller's stream).  Guards the fork/join events and the co-residency of the head kernels with the
-    MFMA convs (packed op_sel FMAs were wrong there; heads.hip builds without them)."""
-    B, L = 64, 7
-    feats = [dev(f) for f in synth.make_features(B, L, 2)]
-    h0, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
-    monkeypatch.setenv("OFFK_SIDE_STREAM", "1")
-    h1, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
-    monkeypatch.delenv("OFFK_SIDE_STREAM")
-    ref = [t.clone() for t in h0.forward(feats)]
-    side = torch.cuda.Stream()
-    for it in range(6):
-        if it % 2:     # also from a non-default caller stream
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                got = h1.forward(feats)
-            torch.cuda.current_stream().wait_stream(side)
-        else:
-            got = h1.forward(feats)
-        torch.cuda.synchronize()
-        for a, b in zip(ref, got):
-            assert torch.equal(a, b), "iteration %d" % it
-
-
 def test_two_stream_fused_forward(rt):
     """BASELINE config 5 at small size: RGB-OFF + Flow-OFF on two streams, K7 late fusion."""
     from offk_amd import scores, two_stream
@@ -452,8 +426,7 @@ def test_forward_from_inception_branch_parts(rt, prec):
 
 
 def test_forward_is_stream_capturable(rt):
-    """include/offk.h: offk_forward (side-stream fork/join included) can be captured into a HIP graph;
-    replaying the graph reproduces the eager bits."""
+    """include/offk.h: offk_forward can be captured into a HIP graph; replaying the graph reproduces the eager bits."""
     B, L = 2, 3
     h, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
     feats = [dev(f) for f in synth.make_features(B, L, 2)]
@@ -479,12 +452,12 @@ def test_forward_is_stream_capturable(rt):
 
 @pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("B,L", [(2, 3), (3, 9)])
-def test_fused_units_path_bit_identical(rt, prec, B, L, monkeypatch):
+def test_fused_units_path_matches_unfused(rt, prec, B, L, monkeypatch):
     """The default inference path fuses K1 with the temporal difference (pw_tdiff.hip: G never written to HBM);
-    OFFK_FUSED_UNITS=0 at offk_create keeps K1 + K2 apart.  The 32-pixel forms of the fused kernel (register-staged and
-    LDS-DMA, OFFK_PW_DMA=0 / 1; bf16x3 always) add the k of an output element in K1's order: the unfused path's bits, also with
-    two temporal groups (L = 9).  The 16-pixel fp32 form (the default, round 3) runs 16x16x4 MFMA tiles, whose k grouping
-    differs: same values to a few fp32 ulps (asserted at 2e-6 of the logits' magnitude)."""
+    OFFK_FUSED_UNITS=0 at offk_create keeps K1 + K2 apart.  bf16x3 (the 32-pixel register-staged form) adds the k of an output
+    element in K1's order: the unfused path's bits, also with two temporal groups (L = 9).  Exact fp32 runs the 16-pixel
+    LDS-DMA form on 16x16x4 MFMA tiles, whose k grouping differs: same values to a few fp32 ulps (asserted at 2e-6 of the
+    logits' magnitude)."""
     feats = [dev(f) for f in synth.make_features(B, L, 4)]
     monkeypatch.setenv("OFFK_FUSED_UNITS", "0")
     h0, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
@@ -497,42 +470,14 @@ def test_fused_units_path_bit_identical(rt, prec, B, L, monkeypatch):
             grp.append(dev(np.ascontiguousarray(f[:, off:off + wd])))
             off += wd
         parts.append(grp)
-    for mode in ("1", "0", "2"):
-        monkeypatch.setenv("OFFK_PW_DMA", mode)
-        h1, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
-        monkeypatch.delenv("OFFK_PW_DMA")
-        exact = mode != "2" or prec != "fp32"
-        # whole maps, and the branches-as-parts entry point (same path)
-        for got in (h1.forward(feats), h1.forward(parts)):
-            for a, b in zip(ref, got):
-                if exact:
-                    assert torch.equal(a, b), mode
-                else:
-                    assert rel_err(b, a.cpu()) < 2e-6, mode
-
-
-@pytest.mark.parametrize("prec", PRECISIONS)
-@pytest.mark.parametrize("variant,B,L", [(spec.VARIANT_RGB, 17, 7), (spec.VARIANT_FLOW, 16, 8)])
-def test_two_half_pipeline_bit_identical(rt, variant, B, L, prec, monkeypatch):
-    """OFFK_PIPELINE=1 at offk_create runs the fusion stages of the two halves of the pairs on two streams, one big conv
-    apart (offk_api.hip).  Every buffer is pair-major and the per-output arithmetic does not depend on the split: the
-    logits are the single-stream bits, with an odd pair count (17 * 6 = 102 -> 51 + 51; 16 * 7 = 112) and with the
-    consensus of the Flow variant behind the join."""
-    feats = [dev(f) for f in synth.make_features(B, L, 3)]
-    # the single-stream handle with the heads' average pools NOT folded into the conv epilogues: the folded sums are taken
-    # per 32-row slab of the call's pair range, so a call on half the pairs groups them differently (same values to ~1e-7,
-    # not the same bits); the pipelined handle never folds
-    monkeypatch.setenv("OFFK_FOLD_POOL", "0")
-    h0, _ = make_handle(rt, B, L, variant, precision=prec)
-    monkeypatch.setenv("OFFK_PIPELINE", "1")
-    h1, _ = make_handle(rt, B, L, variant, precision=prec)
-    monkeypatch.delenv("OFFK_PIPELINE")
-    monkeypatch.delenv("OFFK_FOLD_POOL")
-    ref = h0.forward(feats)
-    for _ in range(2):                       # twice: the second run re-uses the events / the split-K slabs
-        got = h1.forward(feats)
+    h1, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
+    # whole maps, and the branches-as-parts entry point (same path)
+    for got in (h1.forward(feats), h1.forward(parts)):
         for a, b in zip(ref, got):
-            assert torch.equal(a, b)
+            if prec == "fp32":
+                assert rel_err(b, a.cpu()) < 2e-6
+            else:
+                assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
@@ -560,8 +505,7 @@ def test_test_time_shape_vs_oracle(rt, variant, prec):
 
 
 def test_forward_without_the_28_head(rt):
-    """out28 = NULL (the reference never returns the 28x28 head, RGB_OFF.py:860): the other two logits are unchanged and
-    no side-stream work is left dangling."""
+    """out28 = NULL (the reference never returns the 28x28 head, RGB_OFF.py:860): the other two logits are unchanged."""
     B, L = 2, 3
     h, _ = make_handle(rt, B, L, spec.VARIANT_FLOW, precision="bf16x3")
     feats = [dev(f) for f in synth.make_features(B, L, 2)]

@@ -1,0 +1,265 @@
+"""GPU parity tests for the pair-count-gated kernels of the exact-fp32 forward.
+
+Three default-path kernels are selected by the number of frame pairs P = B (L - 1): the fused bottleneck chains of fusion@28
+(`chain14_kernel`, from P = 72), the polyphase Winograd form of the 5x5 / stride 2 conv (from P = 40) and of the 7x7 / stride 2
+conv (from P = 12).  The reference-held goldens have P <= 18, so with the default gates they never reach the first two.  Here
+
+* every golden and both stress distributions run with ALL gates forced open (OFFK_CHAIN / OFFK_WINOGRAD_5X5 /
+  OFFK_WINOGRAD_7X7 = 2 at offk_create): reference-held outputs and stage tensors pass through those kernels;
+* the stress distributions run at P = 72 with the default gates;
+* the full-size forwards (BASELINE configs 2 and 3) compare the fusion-stage tensors, not only the logits;
+* the Winograd stage kernels run on heavy-tailed inputs and are held to a backward-error bound per element,
+  |err| <= c 2^-24 sum_k |w_k x_k| (as test_pw_reduce_cancellation_case does for K1), beside the max-normalised check --
+  Winograd's error sits where the outputs are small;
+* a fusion-conv weight update at P >= 40 reaches the transformed Winograd weights.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import offk_amd  # noqa: F401
+from offk_amd import spec, synth
+from oracle import off_oracle as orc
+
+from .test_gpu_parity import GOLDEN, RTOL, RTOL_NORTH_STAR, dev, make_handle, rel_err, rt, signal_err  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+STAGES = (("fusion_28", 320, 28), ("fusion_14", 1056, 14), ("fusion_7", 832, 7), ("sum_7", 1024, 7))
+FORCE = {"OFFK_CHAIN": "2", "OFFK_WINOGRAD_5X5": "2", "OFFK_WINOGRAD_7X7": "2"}
+
+
+def forced_handle(rt, monkeypatch, *args, **kw):
+    for k, v in FORCE.items():
+        monkeypatch.setenv(k, v)
+    try:
+        return make_handle(rt, *args, **kw)
+    finally:
+        for k in FORCE:
+            monkeypatch.delenv(k)
+
+
+def stage_errs(h, st, P):
+    return dict((name, rel_err(h.region(name, ch).view(P, H, H, ch).permute(0, 3, 1, 2), st[name])) for name, ch, H in STAGES)
+
+
+def launches_of(h, feats):
+    """Names of the launch groups one forward enqueues (per-launch trace of the library)."""
+    h.set_profiling(2)
+    h.forward(feats)
+    torch.cuda.synchronize()
+    names = list(h.launch_times().keys())
+    h.set_profiling(0)
+    return names
+
+
+@pytest.mark.parametrize("tag", GOLDEN)
+def test_goldens_through_the_gated_kernels(rt, tag, golden_dir, monkeypatch):
+    """All seven reference goldens with every pair-count gate forced open: the reference's own outputs (fc7 / fc14 / fc28) and the
+    oracle's stage tensors after chain14_kernel, the polyphase 5x5 and the 7x7 Winograd kernels."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    variant, B, L, cfg = (int(v) for v in g["meta"])
+    h, w = forced_handle(rt, monkeypatch, B, L, variant, consensus=False)
+    feats_np = synth.make_features(B, L, cfg)
+    feats = [dev(f) for f in feats_np]
+    names = launches_of(h, feats)
+    assert any(n.startswith("chain_28a") for n in names), names
+    assert any(n.startswith("motion_conv_trans_14 [winograd") for n in names), names
+    assert any(n.startswith("motion_conv_trans_28 [winograd") for n in names), names
+    out7, out14, out28 = h.forward(feats)
+    torch.cuda.synchronize()
+    for out, key in ((out7, "fc7"), (out14, "fc14"), (out28, "fc28")):
+        assert rel_err(out, g[key]) < RTOL, key
+    with torch.no_grad():
+        _ref, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, variant, orc.SLICE_FLAT, consensus=False,
+                                   return_stages=True)
+    P = B * (L - 1)
+    errs = stage_errs(h, st, P)
+    print("%s gates open: stage errors %s" % (tag, " ".join("%s %.1e" % kv for kv in errs.items())))
+    assert max(errs.values()) < RTOL, errs
+    if P >= 2:
+        for out, key in ((out7, "fc7"), (out14, "fc14"), (out28, "fc28")):
+            se = signal_err(out, g[key])
+            assert se < RTOL_NORTH_STAR, (key, se)
+
+
+@pytest.mark.parametrize("kind", ["full_mantissa", "heavy_tail"])
+@pytest.mark.parametrize("mode", ["gates_open_p18", "default_gates_p72"])
+def test_stress_inputs_through_the_gated_kernels(rt, kind, mode, monkeypatch):
+    """Full-mantissa / heavy-tailed maps (synth.make_features_kind) through the chain and polyphase-Winograd kernels: at B = 3
+    with the gates forced open, and at B = 12 (P = 72) where the default gates select them."""
+    B, L = (3, 7) if mode == "gates_open_p18" else (12, 7)
+    feats_np = synth.make_features_kind(B, L, 3, kind)
+    if mode == "gates_open_p18":
+        h, w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    else:
+        h, w = make_handle(rt, B, L, spec.VARIANT_RGB)
+    feats = [dev(f) for f in feats_np]
+    names = launches_of(h, feats)
+    assert any(n.startswith("chain_28a") for n in names) and any(n.startswith("motion_conv_trans_14 [winograd") for n in names), names
+    got = h.forward(feats)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, spec.VARIANT_RGB, orc.SLICE_FLAT, return_stages=True)
+    P = B * (L - 1)
+    errs = stage_errs(h, st, P)
+    lerr = [rel_err(a, b) for a, b in zip(got, want)]
+    sig = signal_err(got[0], want[0])
+    print("forward fp32 on %s maps, %s: logits %.2e %.2e %.2e, stages %s, fc7 row-to-row signal %.2e"
+          % ((kind, mode) + tuple(lerr) + (" ".join("%.1e" % v for v in errs.values()), sig)))
+    assert max(lerr) < RTOL and max(errs.values()) < RTOL and sig < RTOL_NORTH_STAR
+
+
+@pytest.mark.parametrize("variant", [spec.VARIANT_RGB, spec.VARIANT_FLOW])
+def test_full_size_b64_stage_tensors_vs_oracle(rt, variant):
+    """BASELINE configs 2 / 3 at full size (B = 64, P = 384 -- where every gated kernel runs by default): the fusion-stage tensors
+    against the oracle, beside the logit checks of test_full_size_b64_vs_oracle / test_flow_full_size_b64_vs_oracle."""
+    B, L = 64, 7
+    feats_np = synth.make_features(B, L, 2 if variant == spec.VARIANT_RGB else 3)
+    h, w = make_handle(rt, B, L, variant, consensus=False)
+    got = h.forward([dev(f) for f in feats_np])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, variant, orc.SLICE_FLAT, consensus=False,
+                                   return_stages=True)
+    P = B * (L - 1)
+    errs = stage_errs(h, st, P)
+    print("full size variant %d: stage errors %s" % (variant, " ".join("%s %.1e" % kv for kv in errs.items())))
+    assert max(errs.values()) < RTOL, errs
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < RTOL and signal_err(a, b) < RTOL_NORTH_STAR
+
+
+# ---- Winograd stage kernels on heavy-tailed inputs, backward-error bound per element -------------------------------------------
+
+def heavy_tail(shape, seed):
+    """expm1(1.151 z) of the portable generator's ReLU-like z (synth.make_features_kind 'heavy_tail'): ~half zeros, tail to ~1e2."""
+    n = int(np.prod(shape))
+    z = synth.feature_values(seed, 0, n).astype(np.float64)
+    return torch.from_numpy(np.expm1(z * 1.151).astype(np.float32).reshape(shape))
+
+
+# c of |err| <= c 2^-24 sum |w x|: a direct fp32 contraction sits at c ~ 1-2 (test_pw_reduce_cancellation_case); the Winograd forms
+# amplify rounding by the norms of their transform matrices -- measured on the GPU (printed by the tests): F(4,3)xF(3,3) c ~ 10,
+# polyphase 5x5 ~ 12, F(5x5, 4x4) ~ 25.  The bounds below leave a factor ~4.
+WINO_BOUND = {"3x3": 64.0, "5x5s2": 64.0, "7x7s2": 128.0}
+
+
+def backward_error(got, x_nchw, w, b, stride, pad, relu):
+    ref = F.conv2d(x_nchw.double(), w.double(), b.double(), stride=stride, padding=pad)
+    mag = F.conv2d(x_nchw.double().abs(), w.double().abs(), b.double().abs(), stride=stride, padding=pad)
+    if relu:
+        ref = F.relu(ref)
+    err = (got.permute(0, 3, 1, 2).double().cpu() - ref).abs()
+    return (err / mag).max().item() * 2.0 ** 24, (err.max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize("ci,co,n", [(128, 128, 5), (128, 512, 3), (256, 256, 4), (832, 256, 2)])
+def test_winograd_conv3x3_heavy_tail_backward_error(rt, ci, co, n):
+    g = torch.Generator().manual_seed(3 * ci + co)
+    x = heavy_tail((n, 7, 7, ci), 0x3300 + ci)
+    w = (torch.rand(co, ci, 3, 3, generator=g) * 2 - 1) / (9 * ci) ** 0.5
+    b = (torch.rand(co, generator=g) * 2 - 1) / (9 * ci) ** 0.5
+    got = rt.winograd_conv3x3(dev(x), dev(w), dev(b), flags=2)
+    torch.cuda.synchronize()
+    c, fwd = backward_error(got, x.permute(0, 3, 1, 2), w, b, 1, 1, True)
+    print("winograd 3x3 %d -> %d heavy tail: max err / (2^-24 sum|w x|) = %.1f, err / max|ref| = %.2e" % (ci, co, c, fwd))
+    assert c < WINO_BOUND["3x3"] and fwd < RTOL
+
+
+@pytest.mark.parametrize("ci,co,n", [(64, 64, 2), (1056, 128, 3)])
+def test_winograd_conv5x5s2_heavy_tail_backward_error(rt, ci, co, n):
+    g = torch.Generator().manual_seed(5 * ci + co)
+    x = heavy_tail((n, 14, 14, ci), 0x5500 + ci)
+    w = (torch.rand(co, ci, 5, 5, generator=g) * 2 - 1) / (25 * ci) ** 0.5
+    b = (torch.rand(co, generator=g) * 2 - 1) / (25 * ci) ** 0.5
+    got = rt.winograd_conv5x5s2(dev(x), dev(w), dev(b), flags=2)
+    torch.cuda.synchronize()
+    c, fwd = backward_error(got, x.permute(0, 3, 1, 2), w, b, 2, 2, True)
+    print("polyphase winograd 5x5/2 %d -> %d heavy tail: max err / (2^-24 sum|w x|) = %.1f, err / max|ref| = %.2e" % (ci, co, c, fwd))
+    assert c < WINO_BOUND["5x5s2"] and fwd < RTOL
+
+
+@pytest.mark.parametrize("ci,co,n", [(64, 64, 2), (320, 64, 3)])
+def test_winograd_conv7x7s2_heavy_tail_backward_error(rt, ci, co, n):
+    g = torch.Generator().manual_seed(7 * ci + co)
+    x = heavy_tail((n, 28, 28, ci), 0x7700 + ci)
+    w = (torch.rand(co, ci, 7, 7, generator=g) * 2 - 1) / (49 * ci) ** 0.5
+    b = (torch.rand(co, generator=g) * 2 - 1) / (49 * ci) ** 0.5
+    got = rt.winograd_conv7x7s2(dev(x), dev(w), dev(b))
+    torch.cuda.synchronize()
+    c, fwd = backward_error(got, x.permute(0, 3, 1, 2), w, b, 2, 3, False)
+    print("polyphase winograd 7x7/2 %d -> %d heavy tail: max err / (2^-24 sum|w x|) = %.1f, err / max|ref| = %.2e" % (ci, co, c, fwd))
+    assert c < WINO_BOUND["7x7s2"] and fwd < RTOL
+
+
+@pytest.mark.parametrize("n", [3, 11])
+def test_bottleneck_chain14_heavy_tail(rt, n):
+    """chain14_kernel (residual form) on a heavy-tailed post-ReLU input against an fp64 chain."""
+    g = torch.Generator().manual_seed(900 + n)
+    x = heavy_tail((n, 14, 14, 256), 0x1400 + n)
+    w1 = (torch.rand(64, 256, generator=g) * 2 - 1) / 16.0
+    b1 = (torch.rand(64, generator=g) * 2 - 1) / 16.0
+    w2 = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    b2 = (torch.rand(64, generator=g) * 2 - 1) / 24.0
+    w3 = (torch.rand(256, 64, generator=g) * 2 - 1) / 8.0
+    b3 = (torch.rand(256, generator=g) * 2 - 1) / 8.0
+    xin = x.permute(0, 3, 1, 2).double()
+    t1 = F.relu(F.conv2d(xin, w1.double()[:, :, None, None], b1.double()))
+    t2 = F.relu(F.conv2d(t1, w2.double(), b2.double(), padding=1))
+    want = F.relu(F.conv2d(t2, w3.double()[:, :, None, None], b3.double()) + xin).permute(0, 2, 3, 1)
+    got = rt.bottleneck_chain14(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), res=dev(x))
+    torch.cuda.synchronize()
+    err = rel_err(got, want)
+    print("chain14 n=%d heavy tail: max error / max |ref| = %.2e" % (n, err))
+    assert err < 1e-5
+
+
+def test_mirror_picks_up_fusion_conv_updates_at_winograd_sizes(rt):
+    """A fusion-conv weight written after the first forward at P >= 40 (B = 7, L = 7: P = 42 -- the 7x7 / 5x5 / 3x3 convs all on
+    their Winograd paths) must reach the TRANSFORMED weights (wino_u7, wino_u[..]) before the next forward."""
+    from offk_amd import off_module
+    B, L = 7, 7
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    net = off_module.OFFSubNetwork(101, B, L, "rgb").cuda()
+    w0 = synth.make_weights(spec.VARIANT_RGB)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    a = [t.clone() for t in net(feats)]
+    keys = ("motion_conv_trans_28", "motion_conv_trans_14", "motion_conv3_trans_14b", "motion_conv_trans", "motion_conv2_trans")
+    with torch.no_grad():
+        for i, k in enumerate(keys):
+            getattr(net, k).weight.mul_(1.25 + 0.125 * i)
+    b = net(feats)
+    w1 = dict(w0)
+    for i, k in enumerate(keys):
+        w1[k + ".weight"] = w0[k + ".weight"] * np.float32(1.25 + 0.125 * i)
+    with torch.no_grad():
+        want = orc.off_forward([f.cpu() for f in feats], orc.to_torch_weights(w1), B, L, 0, orc.SLICE_FLAT)
+    for x, y in zip(b, want):
+        assert rel_err(x, y) < RTOL and signal_err(x, y) < RTOL_NORTH_STAR
+    assert not torch.equal(a[0], b[0])
+
+
+def test_modality_fuse_keeps_the_backbone_score_differentiable(rt):
+    """`fc7 + Feature_Generation_Score + fc14` (Flow_OFF.py:881) runs as K7 on raw pointers at inference; when the
+    backbone's score requires grad (fine-tuning the TSN stream through the fused score) the sum must stay on the autograd graph:
+    d fused / d fgs = 1 / L per frame (SegmentConsensus avg, basic_ops.py:19-21, 29-33)."""
+    from offk_amd import off_module
+    from .test_gpu_parity import _StubBackbone
+    B, L = 2, 3
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    fgs = torch.randn(B * L, 101, device="cuda", requires_grad=True)
+    m = off_module.bninception_off(101, B, L, variant="flow", backbone=_StubBackbone(feats, fgs))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(spec.VARIANT_FLOW).items()}, strict=False)
+    m.modality_fuse = True
+    frames = torch.zeros(B * L, 10, 8, 8, device="cuda")
+    fused = m(frames)
+    assert fused.requires_grad
+    fused.sum().backward()
+    assert torch.allclose(fgs.grad, torch.full_like(fgs, 1.0 / L))
+    with torch.no_grad():                                   # inference: the K6 + K7 path, same numbers
+        fused2 = m(frames)
+    assert not fused2.requires_grad and rel_err(fused2, fused.detach()) < 1e-6
