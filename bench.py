@@ -15,10 +15,15 @@ owns 64 clips (weak scaling, no data-path collective), takes the SegmentConsensu
 clip and the per-clip scores are exchanged once per step with one RCCL all-gather over xGMI.
 Rank 0 prints ONE JSON line.
 
-What the line's `value` is: the library's exact-fp32 arithmetic mode (v_mfma_f32_32x32x2_f32 --
-the reference's arithmetic: fp32 products, fp32 accumulation) at the full --steps.  The faster
-bf16x3 mode of the same library (each fp32 operand split into two bf16, three matrix-core products)
-is timed beside it as the named secondary object `bf16x3_mode`, with its measured error.
+    python bench.py --collective-smoke                # N = 1 with a single-rank RCCL group: librccl init + the per-step score
+                                                      # exchange (all-gather AND the all-reduce form) inside the timed step --
+                                                      # NOT a scaling number (a dev box has one GPU)
+
+What the line's `value` is: the library's fp32 mode (v_mfma_f32_* : fp32 products, fp32 accumulation -- the reference's
+arithmetic type; the k x k fusion convs run in Winograd forms, i.e. a different fp32 summation, measured ~1e-5 of max|ref|
+against the reference-pinned oracle) at the full --steps.  The faster bf16x3 mode of the same library (each fp32 operand
+split into two bf16, three matrix-core products) is timed beside it as the named secondary object `bf16x3_mode`, with its
+error measured against the DIRECT-convolution fp32 path (OFFK_WINOGRAD=0).
 """
 import argparse
 import json
@@ -43,6 +48,10 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the bf16x3 / training / CPU-baseline objects")
     ap.add_argument("--collective", choices=("allgather", "allreduce"), default="allgather",
                     help="N > 1: the one exchange of per-clip scores (allreduce = zeroed [B,101] buffer + sum, north_star's wording)")
+    ap.add_argument("--collective-smoke", action="store_true",
+                    help="N = 1: create a single-rank RCCL process group in this process and run the per-step score exchange "
+                         "(dist.py: all-gather and the all-reduce form) inside the timed step.  Executes librccl on the one GPU "
+                         "there is; labelled as a smoke run, not a scaling number")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="N > 1 on a box with fewer GPUs than ranks: ranks share devices (rank %% device_count), scores go "
                          "over a gloo group (host-staged).  Exercises the multi-rank code path; not a scaling measurement")
@@ -102,7 +111,7 @@ def cpu_baseline(feats_np, weights, length, variant, clips_large):
         orc.off_forward(x, w, clips, length, variant, orc.SLICE_FLAT)
         return time.perf_counter() - t0
 
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
 
     def best_threads(clips, cands):
         best_t, best_n, sweep = None, None, {}
@@ -138,11 +147,76 @@ def cpu_baseline(feats_np, weights, length, variant, clips_large):
     one = {"value": 1.0 / t1, "unit": "clips/s", "cores": n1, "sec_per_forward": t1,
            "sample": "1 clip x %d segments per call, median of 5 at the fastest thread count" % length,
            "clips_per_s_by_threads": sweep1}
-    best = one if one["value"] >= large["value"] else large      # `value` = the host's BEST operating point, not the bench batch
+    conc = cpu_concurrent(length, variant)
+    best = max((one, large, conc), key=lambda r: r["value"])     # `value` = the host's BEST operating point, not the bench batch
     return {"value": best["value"], "unit": "clips/s", "cores": best["cores"], "kind": "port",
             "sample": "oracle/off_oracle.py (torch CPU ops, bit-exact vs the reference import) on the same synthetic maps; "
-                      "the faster of two operating points: " + best["sample"],
-            "batch_1": one, "batch_large": large, "cpu_model": model, "host_logical_cpus": os.cpu_count()}
+                      "the fastest of three operating points: " + best["sample"],
+            "batch_1": one, "batch_large": large, "concurrent_batch_1": conc, "cpu_model": model,
+            "host_logical_cpus": os.cpu_count(), "usable_cpus": usable_cpus()}
+
+
+_CPU_WORKER = r"""
+import sys, time
+sys.path.insert(0, %(root)r)
+import torch
+torch.set_num_threads(%(threads)d)
+import offk_amd  # noqa: F401
+from offk_amd import spec, synth
+from oracle import off_oracle as orc
+L, variant = %(length)d, %(variant)d
+w = orc.to_torch_weights(synth.make_weights(variant))
+x = [torch.from_numpy(f) for f in synth.make_features(1, L, 2)]
+with torch.no_grad():
+    for _ in range(2):
+        orc.off_forward(x, w, 1, L, variant, orc.SLICE_FLAT)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < %(seconds)f:
+        orc.off_forward(x, w, 1, L, variant, orc.SLICE_FLAT)
+        n += 1
+    print(n / (time.perf_counter() - t0))
+"""
+
+
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup's cpu.max quota (a GPU box hands a
+    job a share of the host, e.g. 16 of 256 logical CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_concurrent(length, variant, seconds=6.0):
+    """The host's throughput operating point: N independent single-clip oracle processes side by side, N x threads = the CPUs
+    this job may use (one process at a time leaves most of them idle on these small convs).  Tried at 2 and 4 threads per
+    process; the faster split is reported."""
+    ncpu = usable_cpus()
+    best = None
+    for threads in (2, 4):
+        procs = max(1, ncpu // threads)
+        src = _CPU_WORKER % {"root": ROOT, "threads": threads, "length": length, "variant": variant, "seconds": seconds}
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        ps = [subprocess.Popen([sys.executable, "-c", src], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+              for _ in range(procs)]
+        rates = []
+        for q in ps:
+            o, _ = q.communicate()
+            try:
+                rates.append(float(o.strip().splitlines()[-1]))
+            except (ValueError, IndexError):
+                rates.append(0.0)
+        rec = {"value": sum(rates), "unit": "clips/s", "processes": procs, "threads_per_process": threads, "cores": procs * threads,
+               "sample": "%d concurrent processes x %d threads, each looping 1 clip x %d segments per call for %.0f s (2 warm-ups)"
+                         % (procs, threads, length, seconds)}
+        if best is None or rec["value"] > best["value"]:
+            best = rec
+    best["usable_cpus"] = ncpu
+    return best
 
 
 def measured_traffic(batch, length, variant):
@@ -343,13 +417,23 @@ def units_training(B, L, variant, weights, feats, dev, precision, iters=10):
 
 
 def bf16x3_error(B, L, variant, weights, dev, kinds=("synth", "full_mantissa", "heavy_tail"), clips=8):
-    """Measured difference between the two arithmetic modes of the library (bf16x3 against exact fp32) on maps with
-    full 24-bit mantissas and a realistic dynamic range (synth.make_features_kind), max |diff| / max |fp32 value|
-    over the three logit tensors and over the last fusion-stage tensor (sum_7)."""
+    """Measured difference between the bf16x3 mode and the library's DIRECT-convolution fp32 path (OFFK_WINOGRAD=0 at
+    offk_create: every conv an fp32-MFMA implicit GEMM, ~4e-7 of the oracle -- the Winograd default has an error of its
+    own of ~1e-5, the same order as bf16x3's) on maps with full 24-bit mantissas and a realistic dynamic range
+    (synth.make_features_kind): max |diff| / max |fp32 value| over the three logit tensors and over the last fusion-stage
+    tensor (sum_7)."""
     out = {}
     hs = {}
     for prec in ("fp32", "bf16x3"):
-        hs[prec] = runtime.OffForward(clips, L, variant, spec.SLICE_FLAT, False, device=dev, precision=prec)
+        old = os.environ.get("OFFK_WINOGRAD")
+        os.environ["OFFK_WINOGRAD"] = "0"            # read at offk_create
+        try:
+            hs[prec] = runtime.OffForward(clips, L, variant, spec.SLICE_FLAT, False, device=dev, precision=prec)
+        finally:
+            if old is None:
+                del os.environ["OFFK_WINOGRAD"]
+            else:
+                os.environ["OFFK_WINOGRAD"] = old
         hs[prec].load_state_dict(weights)
     for kind in kinds:
         feats = [torch.from_numpy(f).to(dev) for f in synth.make_features_kind(clips, L, 2, kind)]
@@ -396,6 +480,58 @@ def two_stream_leg(B, L, dev, steps, warmup, rgb_feats, rgb_weights):
             "steps": steps, "warmup": warmup, "dtype": DTYPES["fp32"]}
 
 
+def init_single_rank_rccl(dev):
+    """A world_size-1 RCCL ("nccl" backend on ROCm) process group in THIS process: no launcher, no re-exec after the GPU is
+    initialised.  Rendezvous over a loopback TCP store on a free port."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+
+
+def rccl_smoke_object(B, L, variant, weights, feats, dev, steps):
+    """Secondary object of the default N = 1 line: the per-step score exchange of config 4 executed on RCCL
+    with a single-rank group on the one GPU of the box -- librccl init, `all_gather_into_tensor` and the zero-buffer `all_reduce`
+    form, both through offk_amd.dist, behind a consensus forward.  NOT a scaling number.  Failures are recorded, not raised: the
+    headline measurement above does not depend on RCCL."""
+    rec = {"what": "single-rank RCCL smoke, not a scaling number", "world_size": 1}
+    try:
+        if not dist.is_initialized():
+            init_single_rank_rccl(dev)
+        rec["backend"] = dist.get_backend()
+        h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, True, device=dev, precision="fp32")
+        h.load_state_dict(weights)
+        arr = h._feat_array(feats)
+        ncls = spec.NUM_CLASSES
+        local = torch.empty(3, B, ncls, device=dev)
+        gathered = torch.empty(1, 3, B, ncls, device=dev)
+        reduced = torch.zeros(3, B, ncls, device=dev)
+
+        def step():
+            h.forward_into(arr, local[0], local[1], local[2])
+            odist.all_gather_scores_into(gathered, local)
+            reduced.zero_()
+            reduced.copy_(local)
+            odist.all_reduce_scores_inplace(reduced)
+
+        def fence():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(3):
+            step()
+        dt = timed_loop(step, steps, fence)
+        rec.update(ms_per_step=dt / steps * 1e3, steps=steps, n_ranks_seen=dist.get_world_size(),
+                   per_step="consensus forward + all_gather_into_tensor + zero-buffer all_reduce",
+                   exchange_ok=bool(torch.equal(gathered[0], local) and torch.equal(reduced, local)))
+    except Exception as e:      # noqa: BLE001 -- a broken RCCL install must not take the headline line with it
+        rec["error"] = "%s: %s" % (type(e).__name__, e)
+    return rec
+
+
 def main():
     args = ARGS
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -409,6 +545,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = None
+    smoke = bool(args.collective_smoke) and world == 1
+    if smoke:
+        init_single_rank_rccl(dev)
+        backend = dist.get_backend()
+    coll = world > 1 or smoke            # the step ends with the score exchange
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if over:    # several ranks per device: RCCL refuses that, the scores travel over gloo (host-staged)
@@ -428,7 +569,7 @@ def main():
 
     variant = spec.VARIANT_RGB if args.variant == "rgb" else spec.VARIANT_FLOW
     B, L = args.batch, args.length
-    consensus = (variant == spec.VARIANT_FLOW) or world > 1
+    consensus = (variant == spec.VARIANT_FLOW) or coll
     weights = synth.make_weights(variant)
     feats_np = synth.make_features(B, L, config_id=2, clip_offset=rank * B)
     feats = [torch.from_numpy(f).to(dev) for f in feats_np]
@@ -437,18 +578,20 @@ def main():
     out = [torch.empty(rows, ncls, device=dev) for _ in range(3)]
     # two buffer sets, alternated per step: the collective of step i (RCCL stream) may still be reading
     # its input while the forward of step i+1 is enqueued on the compute stream
-    gathered = local = None
-    if world > 1 and args.collective == "allgather":
+    gathered = local = reduced = None
+    if coll and (args.collective == "allgather" or smoke):
         gathered = [torch.empty(world, 3, rows, ncls, device=dev) for _ in range(2)]
         local = [torch.empty(3, rows, ncls, device=dev) for _ in range(2)]
-    elif world > 1:   # all-reduce form: the forward writes this rank's rows of a zeroed [head][world * rows][class] buffer
-        gathered = [torch.zeros(3, world * rows, ncls, device=dev) for _ in range(2)]
-        local = [g[:, rank * rows:(rank + 1) * rows] for g in gathered]
+    if coll and (args.collective == "allreduce" or smoke):
+        # all-reduce form: this rank's rows of a zeroed [head][world * rows][class] buffer + one sum
+        reduced = [torch.zeros(3, world * rows, ncls, device=dev) for _ in range(2)]
+        if local is None:     # the forward writes straight into its rows of the buffer
+            local = [g[:, rank * rows:(rank + 1) * rows] for g in reduced]
     last_exchange = [None, 0]
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -459,12 +602,18 @@ def main():
             mine = torch.stack([local[i][k] for k in range(3)], 0).cpu()
             fn = odist.gather_scores if args.collective == "allgather" else odist.gather_scores_allreduce
             last_exchange[0] = fn(mine)
+        elif smoke:       # single-rank RCCL group: BOTH forms of the exchange, every step
+            odist.all_gather_scores_into(gathered[i], local[i])
+            reduced[i].zero_()
+            reduced[i][:, rank * rows:(rank + 1) * rows] = local[i]
+            odist.all_reduce_scores_inplace(reduced[i])
+            last_exchange[0] = gathered[i]
         elif args.collective == "allgather":
-            dist.all_gather_into_tensor(gathered[i].view(world * 3 * rows, -1), local[i].view(3 * rows, -1))
+            odist.all_gather_scores_into(gathered[i], local[i])
             last_exchange[0] = gathered[i]
         else:
-            dist.all_reduce(gathered[i], op=dist.ReduceOp.SUM)
-            last_exchange[0] = gathered[i]
+            odist.all_reduce_scores_inplace(reduced[i])
+            last_exchange[0] = reduced[i]
 
     def measure(precision, steps, warmup, variant=variant, weights=weights, feats=feats, consensus=consensus, k2=True):
         """W untimed steps, K timed steps between fences (profiling off), then a second loop of K steps with the
@@ -475,11 +624,11 @@ def main():
         counter = [0]
 
         def step():
-            if world > 1:
+            if coll:
                 i = counter[0] & 1
                 counter[0] += 1
-                if args.collective == "allreduce":
-                    gathered[i].zero_()
+                if args.collective == "allreduce" and not smoke:
+                    reduced[i].zero_()
                 h.forward_into(arr, local[i][0], local[i][1], local[i][2])
                 exchange(i)
             else:
@@ -500,7 +649,7 @@ def main():
         h.stage_times(reset=True)
         k2_ev = []
         for _ in range(steps):
-            h.forward_into(arr, out[0], out[1], out[2]) if world == 1 else step()
+            h.forward_into(arr, out[0], out[1], out[2]) if not coll else step()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(K2_PER_PAIR):
@@ -515,20 +664,32 @@ def main():
 
     h, dt, stages, k2_us = measure(args.precision, args.steps, args.warmup)
     in_path = roofline_in_path(h, h._feat_array(feats), out, B, L, args.precision, min(args.steps, 20)) if world == 1 else None
-    # N > 1: the exchanged scores must hold every rank's shard in clip order (checked once, outside the timed region):
-    # each rank finds its own rows where they belong and different rows everywhere else (the shards are different clips)
+    # With an exchange on the step: the exchanged scores must hold EVERY rank's shard in clip order.  Checked once, outside the timed
+    # region, against an independent reference: one more forward + exchange, this rank's rows cloned BEFORE the collective (in the
+    # all-reduce form `local` is a view of the buffer being reduced), the clones of all ranks gathered by a second, plain collective.
     exchange_ok = None
-    if world > 1:
-        i_last = last_exchange[1]
+    if coll:
+        i_chk = 0
+        if reduced is not None and not smoke and args.collective == "allreduce":
+            reduced[i_chk].zero_()
+        h.forward_into(h._feat_array(feats), local[i_chk][0], local[i_chk][1], local[i_chk][2])
+        torch.cuda.synchronize()
+        mine = torch.stack([local[i_chk][k] for k in range(3)], 0).clone()
+        exchange(i_chk)
+        torch.cuda.synchronize()
         got = last_exchange[0]
-        if not over and args.collective == "allgather":      # [rank][head][row] -> [head][rank * rows + row]
+        if torch.is_tensor(got) and got.dim() == 4:      # all-gather layout [rank][head][row] -> [head][rank * rows + row]
             got = got.view(world, 3, rows, ncls).permute(1, 0, 2, 3).reshape(3, world * rows, ncls)
         got = got.cpu()
-        mine = torch.stack([local[i_last][k] for k in range(3)], 0).cpu()
-        good = tuple(got.shape) == (3, world * rows, ncls) and bool(torch.isfinite(got).all())
-        for r in range(world):
-            same = good and torch.equal(got[:, r * rows:(r + 1) * rows], mine)
-            good = good and (same if r == rank else not same)
+        ref_parts = [torch.empty_like(mine.cpu() if over else mine) for _ in range(world)]
+        dist.all_gather(ref_parts, mine.cpu() if over else mine)
+        ref = torch.cat([r_.cpu() for r_ in ref_parts], 1)
+        good = tuple(got.shape) == (3, world * rows, ncls) and bool(torch.isfinite(got).all()) and torch.equal(got, ref)
+        if smoke:       # ... and the all-reduce form of the same step
+            good = good and torch.equal(reduced[i_chk].cpu(), ref)
+        for r in range(world):      # the shards are different clips: no two ranks may hold the same rows
+            if r != rank:
+                good = good and not torch.equal(ref[:, r * rows:(r + 1) * rows], mine.cpu())
         ok = torch.tensor([1.0 if good else 0.0], device="cpu" if over else dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         exchange_ok = bool(ok.item() == 1.0)
@@ -542,13 +703,22 @@ def main():
         unit_f, fus_f = spec.flops_per_clip(L)
         stage_ms = dict((k, v[0] / max(v[1], 1)) for k, v in stages.items())
         gpu_ms = sum(stage_ms.values())
-        if world == 1:
-            coll = ""
+        if not coll:
+            coll_txt = ""
+        elif smoke:
+            coll_txt = (" + SegmentConsensus avg + SINGLE-RANK RCCL SMOKE (world_size 1 on the one GPU of this box: librccl init, "
+                        "all_gather_into_tensor and the zero-buffer all_reduce form of the per-clip score exchange inside every "
+                        "timed step; not a scaling number)")
         elif over:
-            coll = " + SegmentConsensus avg + %s of per-clip scores over gloo (host-staged; OVERSUBSCRIBED: %d ranks on %d GPU(s))" % (
+            coll_txt = " + SegmentConsensus avg + %s of per-clip scores over gloo (host-staged; OVERSUBSCRIBED: %d ranks on %d GPU(s))" % (
                 args.collective, world, ndev)
         else:
-            coll = " + SegmentConsensus avg + RCCL %s of per-clip scores" % args.collective
+            coll_txt = " + SegmentConsensus avg + RCCL %s of per-clip scores" % args.collective
+        peak_tf = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0
+        algo_flops = (unit_f + fus_f) * B                  # per rank; ms_step is a rank's time: the fractions below are per GPU
+        wino_on = args.precision == "fp32" and os.environ.get("OFFK_WINOGRAD", "1") != "0"
+        exec_flops = algo_flops - winograd_saved_flops(B * (L - 1)) if wino_on else algo_flops
+        s_blocks = next((k for k in (in_path or {}).get("kernels", []) if k["launch"].startswith("units:sobel S-blocks")), None)
         res = {
             "metric": "OFF-forward clips/sec (7-seg 224x224)", "value": clips_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -557,10 +727,13 @@ def main():
             "data": "synthetic (portable counter-based generator: ReLU-like non-negative BN-Inception "
                     "feature maps, fan-in-scaled uniform weights; features resident in HBM)",
             "config": {"workload": "%s_OFF forward, batch=%d clips/GPU x %d segments, nine 224x224-geometry "
-                                   "feature maps%s" % (args.variant.upper(), B, L, coll),
+                                   "feature maps%s" % (args.variant.upper(), B, L, coll_txt),
                        "global_batch": world * B, "segments": L, "parallelism": "clip-shard x%d" % world,
-                       "slice_mode": "reference_flat"},
-            "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "collective_backend": backend,
+                       "slice_mode": "reference_flat",
+                       "arithmetic": "fp32 MFMA products, fp32 accumulation; the k x k fusion convs in Winograd forms (fp32 transforms)"
+                                     if wino_on else ("fp32 MFMA products, fp32 accumulation, direct convolutions" if args.precision == "fp32"
+                                                      else "bf16x3 split-fp32 on the bf16 MFMA pipe")},
+            "n_ranks_seen": dist.get_world_size() if coll else 1, "collective_backend": backend,
             "roofline": {"bound": "hbm", "kernel": "sobel_tdiff_kernel (K2: temporal difference + spatial gradient + concat, "
                                                    "all nine sites, one launch; offk_sobel_tdiff_all)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -568,6 +741,13 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": k2_avg_s * 1e6,
                          "min_launch_us": min(k2_us), "launches": len(k2_us) * K2_PER_PAIR,
                          "on_default_forward_path": False,
+                         "in_path": None if s_blocks is None else {
+                             "kernel": "sobel_tdiff_kernel<..., ROLES = 3> (the S-blocks: read D, depthwise 3x3 / diagonal Sobel, write S)",
+                             "achieved": s_blocks["achieved_gbs"], "frac": s_blocks["frac"], "avg_launch_us": s_blocks["avg_ms"] * 1e3,
+                             "algorithmic_bytes_per_launch": s_blocks["algorithmic_bytes"]},
+                         "quote_as": "%.2f of 8 TB/s standalone (the whole Sobel + temporal-difference kernel) / %s in path (its S-blocks, "
+                                     "the part the timed forward launches)" % (achieved / HBM_PEAK_GBS,
+                                                                               "n/a" if s_blocks is None else "%.2f" % s_blocks["frac"]),
                          "path_note": "the north-star object (Sobel + temporal-diff kernel) launched STANDALONE: the default "
                                       "inference forward fuses the temporal difference into the 1x1 reduce (pw_tdiff, MFMA-bound) "
                                       "and runs only this kernel's S-blocks; the full kernel serves training and "
@@ -577,30 +757,31 @@ def main():
                                 "pair around a single launch adds ~5 us of command-processor time to this kernel -- "
                                 "rocprofv3's kernel-trace average (profiles/) is the cross-check" % K2_PER_PAIR},
             "stage_ms": stage_ms,
-            "mfma": {"flops_per_step": (unit_f + fus_f) * B, "achieved_tflops": (unit_f + fus_f) * B / (gpu_ms * 1e-3) / 1e12
-                     if gpu_ms > 0 else 0.0,
-                     "peak_tflops": MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0,
-                     "whole_forward_frac_of_peak": (unit_f + fus_f) * B / (ms_step * 1e-3) / 1e12 /
-                                                   (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0) / world,
-                     "executed_flops_per_step": ((unit_f + fus_f) * B - winograd_saved_flops(B * (L - 1))
-                                                 if args.precision == "fp32" and os.environ.get("OFFK_WINOGRAD", "1") != "0"
-                                                 else (unit_f + fus_f) * B),
-                     "executed_frac_of_peak": (((unit_f + fus_f) * B - winograd_saved_flops(B * (L - 1))
-                                                if args.precision == "fp32" and os.environ.get("OFFK_WINOGRAD", "1") != "0"
-                                                else (unit_f + fus_f) * B) / (ms_step * 1e-3) / 1e12 /
-                                               (MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else 2500.0 / 3.0) / world),
-                     "note": "algorithmic (direct-convolution) fp32 FLOPs / summed stage time; whole_forward_frac_of_peak = "
-                             "the same FLOPs / the wall-clock ms_per_step / peak; bf16x3 peak = dense bf16 MFMA peak / 3 "
-                             "products.  In fp32 the five 3x3 / stride 1 convs on 7x7 maps and, in polyphase form, the 5x5 / stride 2 conv "
-                             "run as Winograd with F(4, 3) x F(3, 3) tiles, the 7x7 / stride 2 conv as polyphase F(5x5, 4x4) (fp32 arithmetic; "
-                             "1 / 3.64, 1 / 3.06 and 1 / 4.7 of their multiplies): executed_flops_per_step is what the matrix "
-                             "pipe is asked to do (executed_frac_of_peak = that / ms_per_step / peak), so the algorithmic fraction can "
-                             "exceed any kernel's MFMA-busy share -- and 1"},
+            "mfma": {"peak_tflops": peak_tf,
+                     "executed_flops_per_step": exec_flops,
+                     "executed_frac_of_peak": exec_flops / (ms_step * 1e-3) / 1e12 / peak_tf,
+                     "algorithmic_flops_per_step": algo_flops,
+                     "algorithmic_flops_over_peak": algo_flops / (ms_step * 1e-3) / 1e12 / peak_tf,
+                     "algorithmic_tflops_over_summed_stage_time": algo_flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else 0.0,
+                     "note": "THE fraction to quote is executed_frac_of_peak: the FLOPs the matrix pipe is actually asked for (direct-conv "
+                             "FLOPs minus what the Winograd forms save: the 3x3 / stride 1 convs on 7x7 maps run 1 / 3.64 of their multiplies, "
+                             "the polyphase 5x5 / stride 2 conv 1 / 3.06, the polyphase 7x7 / stride 2 conv 1 / 4.7) / the wall-clock "
+                             "ms_per_step / the dense MFMA peak of the arithmetic (fp32: 157.3 TF; bf16x3: 2.5 PF / 3 products), per GPU.  "
+                             "algorithmic_flops_over_peak counts DIRECT-convolution FLOPs instead: a throughput-equivalent, NOT a "
+                             "utilisation -- it can exceed 1 under Winograd."},
         }
         if in_path is not None:
+            dom = max((k for k in in_path["kernels"] if "frac" in k), key=lambda k: k["avg_ms"], default=None)
+            if dom is not None:
+                in_path["dominant"] = {"launch": dom["launch"], "avg_ms": dom["avg_ms"], "bound": dom["bound"], "frac": dom["frac"],
+                                       "share_of_step": dom["avg_ms"] / ms_step}
             res["roofline_in_path"] = in_path
-        if world > 1:
+        if coll:
             res["exchange_ok"] = exchange_ok
+            if smoke:
+                res["single_rank_rccl_smoke"] = {"backend": backend, "world_size": dist.get_world_size(),
+                                                 "per_step": "forward + all_gather_into_tensor + zero-buffer all_reduce (dist.py)",
+                                                 "note": "NOT a scaling number: executes librccl (init + both collectives) on the one GPU there is"}
             if over:
                 res["oversubscribed"] = {"ranks": world, "gpus_visible": ndev,
                                          "note": "NOT a scaling number: %d ranks time-share %d GPU(s); this run exists to execute "
@@ -625,12 +806,15 @@ def main():
             res["flow_variant"] = flow_variant(B, L, dev, args.steps, args.warmup, measure)
             res["two_stream"] = two_stream_leg(B, L, dev, args.steps, args.warmup, feats, weights)
             res["units_training"] = [units_training(B, L, variant, weights, feats, dev, p) for p in ("fp32", "bf16x3")]
+            if not coll:
+                res["rccl_single_rank_smoke"] = rccl_smoke_object(B, L, variant, weights, feats, dev, min(args.steps, 20))
             if args.cpu_clips > 0:
                 res["cpu_baseline"] = cpu_baseline(feats_np, weights, L, variant, min(args.cpu_clips, B))
                 res["gpu_over_cpu"] = clips_s / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if coll:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

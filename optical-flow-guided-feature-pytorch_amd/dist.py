@@ -31,10 +31,32 @@ def shard_features(feats, total_clips, length, world, rank):
     return [f[first * length:(first + n) * length] for f in feats]
 
 
-def gather_scores(local, group=None):
+def _active(group, always):
+    """A collective is issued when a process group exists and has more than one rank -- or, ``always``, also on a single-rank group
+    (bench.py's single-rank RCCL smoke: the same librccl calls, init included, on the one GPU a dev box has)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return always or dist.get_world_size(group) > 1
+
+
+def all_gather_scores_into(gathered, local, group=None):
+    """One fused all-gather of this rank's [heads, b, classes] scores into ``gathered`` [world, heads, b, classes] (both contiguous,
+    caller-owned: the benchmark alternates two buffer sets).  CUDA/HIP tensors: RCCL ``all_gather_into_tensor``."""
+    world, heads, b, c = gathered.shape
+    dist.all_gather_into_tensor(gathered.view(world * heads * b, c), local.view(heads * b, c), group=group)
+    return gathered
+
+
+def all_reduce_scores_inplace(buf, group=None):
+    """The literal north-star form: ``buf`` [heads, world * b, classes] is zero except for this rank's rows; ONE sum all-reduce."""
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def gather_scores(local, group=None, always=False):
     """local: [heads, b, classes] (or [b, classes]) per-clip consensus scores of this rank.
     Returns the same with b -> B = world*b, clips in global order, on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group, always):
         return local
     world = dist.get_world_size(group)
     squeeze = local.dim() == 2
@@ -43,7 +65,7 @@ def gather_scores(local, group=None):
     heads, b, c = x.shape
     buf = torch.empty(world, heads, b, c, dtype=x.dtype, device=x.device)
     if x.is_cuda:
-        dist.all_gather_into_tensor(buf.view(world * heads * b, c), x.view(heads * b, c), group=group)
+        all_gather_scores_into(buf, x, group=group)
     else:  # gloo (CPU tests): list form
         parts = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(parts, x, group=group)
@@ -52,12 +74,12 @@ def gather_scores(local, group=None):
     return out[0] if squeeze else out
 
 
-def gather_scores_allreduce(local, group=None, rank=None):
+def gather_scores_allreduce(local, group=None, rank=None, always=False):
     """The literal north-star form of the same exchange ("RCCL ... only for the final consensus all-reduce"; SURVEY.md
     section 8(e)): every rank writes its shard into a zeroed [heads, B, classes] buffer at its clips' rows and ONE sum
     all-reduce assembles the whole batch on every rank.  x + 0 is exact, so the result equals gather_scores bit for bit;
     it moves world x the bytes (still <= 620 KB at 8 GPUs: latency-bound either way)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group, always):
         return local
     world = dist.get_world_size(group)
     r = dist.get_rank(group) if rank is None else rank
@@ -66,15 +88,15 @@ def gather_scores_allreduce(local, group=None, rank=None):
     heads, b, c = x.shape
     buf = torch.zeros(heads, world * b, c, dtype=x.dtype, device=x.device)
     buf[:, r * b:(r + 1) * b] = x
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_scores_inplace(buf, group=group)
     return buf[0] if squeeze else buf
 
 
-def fuse_scores_allreduce(weighted_local, group=None):
+def fuse_scores_allreduce(weighted_local, group=None, always=False):
     """Late two-stream fusion when the RGB and Flow streams live on different ranks
     (score_fusion.ipynb lines 300-301: sum_i w_i * score_i): every rank passes its own
     pre-weighted [B, classes] contribution; a sum all-reduce yields the fused scores."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group, always):
         return weighted_local
     out = weighted_local.contiguous().clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
