@@ -99,7 +99,7 @@ def check_isa(obj, code_objects):
 #   vgpr_count (unified: arch + acc registers) <= the bound the kernel's occupancy plan assumes.
 # (source file, regex on the demangled kernel name, max vgpr_count, SGPR spills tolerated, what the bound stands for)
 ASM_SCHEDULED_KERNELS = (
-    ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 168, False, "three blocks per CU (3 waves / SIMD x 168 <= 512)"),
+    ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 128, True, "four blocks per CU (4 waves / SIMD x 128 = 512; 4 x 29 KB of LDS)"),
     ("chain_fused.hip", r"^void offk::chain14_kernel<", 168, False, "three blocks per CU (52.5 KB of LDS each)"),
     ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 96, False,
      "the default 64x64 tile: five blocks per CU (32 KB of LDS each, 5 waves / SIMD x 96 <= 512)"),

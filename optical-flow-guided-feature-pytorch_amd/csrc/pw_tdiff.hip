@@ -511,7 +511,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 //   over four waves, the two missing ones land in a dummy KB -- behind the first four units; the 4 weight loads of a k half
 //   behind that half's last unit.  Waits: half 0: all but the 4 newest; half 1: all but 8; end of step (DMAs): all but 8.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
+__global__ __launch_bounds__(256, 4) void pw_tdiff16_kernel(PtParams p) {
   constexpr int FRAME_B = 32 * 64;               // one frame's K-tile image [32 k][16 pixels] fp32
   constexpr int STAGE_B = PT_FT * FRAME_B;       // 14 KB; two stages, then 1 KB that the surplus DMA slots write
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -550,26 +550,22 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
   const int li = lane & 15, kq = lane >> 4;
 
   // ---- DMA: instruction slot q = wave + 4 i (i = 0..3) lands frame q >> 1, k rows 16 (q & 1) + (lane >> 2), pixel quad lane & 3;
-  //      slots 14, 15 (waves 2, 3, i = 3) go to the dummy KB with an out-of-range source ----
+  //      slots 14, 15 (waves 2, 3, i = 3) go to the dummy KB.  q & 1 == wave & 1 for every i: ONE per-lane offset register serves
+  //      the four slots, the frame rides on the scalar offset (round 3 kept four 64-bit offset pairs: eight registers) ----
   const int pq = lane & 3;
   const int cq = (4 * pq) >> rsh;                                  // clip of the quad within the block (0 unless packed)
   const int k0px = q0 + ((4 * pq) & rmask);
   const bool px_ok = k0px < HW && b + cq < p.B;
-  int vrow[4];                                                     // per slot: byte offset of (k row, pixel quad) inside a frame
-  int dframe[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = wave + 4 * i;
-    dframe[i] = q >> 1;
-    vrow[i] = px_ok && q < 2 * PT_FT ? ((16 * (q & 1) + (lane >> 2)) * HW + k0px) * 4 : (int)0x80000000;
-  }
+  // byte offset of (k row, pixel quad) inside a frame's K-tile; bit 31 (= past every descriptor) where the quad lies outside
+  const int vrow0 = px_ok ? ((16 * (wave & 1) + (lane >> 2)) * HW + k0px) * 4 : (int)0x80000000;
+  const int vclip = cq * L;                                        // frames between the block's first clip and the lane's
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
   auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
   };
   i32x4 dm_desc = {0, 0, 0, 0};
-  int dm_fstride = 0, dm_s0 = 0, dm_clip = 0;
+  int dm_fstride = 0, dm_s0 = 0, dm_voff = 0;
   auto dma_prep = [&](int kt) {
     const float* xb = S.xp[0]; int cpart = S.cp[0], kl = kt * BK;
     if (S.nparts > 1 && kl >= S.cp[0]) {
@@ -583,36 +579,41 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
     dm_desc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
     dm_fstride = cpart * HW * 4;
     dm_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;
-    dm_clip = cq * L * dm_fstride;
+    dm_voff = vrow0 + (int)__umul24((unsigned)vclip, (unsigned)dm_fstride);   // (< 2^24 each; one v_mad_u32_u24 -- a full 32-bit multiply
+                                                                               //  became a 64-bit mad with a spilled addend pair; an invalid vrow0 stays >= 2^31)
   };
   auto dma_issue = [&](const int i, const int stage) {
-    const int q = wave + 4 * i;                                     // scalar
-    const int voff = dframe[i] < nf ? vrow[i] + dm_clip + dframe[i] * dm_fstride : (int)0x80000000;   // (an invalid vrow stays >= 2^31)
-    const unsigned dst = q < 2 * PT_FT ? lds_base + stage * STAGE_B + dframe[i] * FRAME_B + (q & 1) * 1024 : lds_base + 2 * STAGE_B;
-    dma16(dm_desc, dst, voff, dm_s0);
+    const int q = wave + 4 * i, fr = q >> 1;                        // scalar
+    const int voff = fr < nf ? dm_voff : (int)0x80000000;
+    const unsigned dst = q < 2 * PT_FT ? lds_base + stage * STAGE_B + fr * FRAME_B + (q & 1) * 1024 : lds_base + 2 * STAGE_B;
+    dma16(dm_desc, dst, voff, dm_s0 + fr * dm_fstride);
   };
 
-  // ---- weight operand: asm loads (hand-counted waits).  wg[2 ct + hf]: gen channel tile ct of this wave, k half hf (the
-  //      lane's W[ch][kt * 32 + 16 hf + 4 e + kq], e = 0..3); wd likewise for the two down channel tiles ----
-  f32x4 wg[4], wd[4];
+  // ---- weight operand: asm loads (hand-counted waits), one k QUARTER (8 k) at a time.  wg[set][ct]: gen channel tile ct of this
+  //      wave, the lane's W[ch][kt * 32 + 8 qd + 4 e + kq], e = 0, 1; wd likewise for the two down channel tiles.  Two register
+  //      sets: quarter qd multiplies out of set qd & 1 while the loads of quarter qd + 1 are in flight in the other.  (Round 3 kept
+  //      both k HALVES of a tile resident -- 32 registers for weights and 16 for x, 152 in all: three blocks per CU.  Quarters make it
+  //      16 + 8 and the kernel fits 128 registers: FOUR blocks per CU, 4 x 29 KB of LDS.) ----
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 wg[2][2], wd[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { wg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; wd[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < 2; ++i) { wg[i][0] = f32x2{0.f, 0.f}; wg[i][1] = f32x2{0.f, 0.f}; wd[i][0] = f32x2{0.f, 0.f}; wd[i][1] = f32x2{0.f, 0.f}; }
   i32x4 wdesc;
   {
     const unsigned long long wa = reinterpret_cast<unsigned long long>(S.wt);
     wdesc = i32x4{(int)(unsigned)wa, (int)(unsigned)(wa >> 32) & 0xffff, kUnitCh * C * 4, 0x00020000};
   }
-  const int wlane = lane * 16;
-  // image: [kt][slab (4 gen + 1 down)][ct][hf][lane] float4 (pw_pack_direct16_kernel)
-  auto load_w = [&](const int hf, int kt) {
+  const int wlane = lane * 8;
+  // image: [kt][slab (4 gen + 1 down)][ct][quarter][lane] float2 (pw_pack_direct16_kernel)
+  auto load_w = [&](const int set, const int qd, int kt) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const int so_g = (((kt * 5 + wave) * 2 + ct) * 2 + hf) * 1024, so_d = (((kt * 5 + 4) * 2 + ct) * 2 + hf) * 1024;
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wg[2 * ct + hf]) : "v"(wlane), "s"(wdesc), "s"(so_g));
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wd[2 * ct + hf]) : "v"(wlane), "s"(wdesc), "s"(so_d));
+      const int so_g = (((kt * 5 + wave) * 2 + ct) * 4 + qd) * 512, so_d = (((kt * 5 + 4) * 2 + ct) * 4 + qd) * 512;
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(wg[set][ct]) : "v"(wlane), "s"(wdesc), "s"(so_g));
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(wd[set][ct]) : "v"(wlane), "s"(wdesc), "s"(so_d));
     }
   };
-#define OFFK_WAIT16(N, hf) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[hf]), "+v"(wg[2 + (hf)]), "+v"(wd[hf]), "+v"(wd[2 + (hf)]))
+#define OFFK_WAIT16(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[set][0]), "+v"(wg[set][1]), "+v"(wd[set][0]), "+v"(wd[set][1]))
 
   f32x4 ag[PT_FT][2], ad[2][2];          // gen tiles [frame][ct]; down tiles [frame wave / wave + 4][ct]
 #pragma unroll
@@ -621,61 +622,61 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
   for (int i = 0; i < 2; ++i) { ad[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ad[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nkt = C / BK;
-  // nine frame slots per k half: slots 0..6 = the gen tiles of frame s, slot 7 / 8 = the down tiles of frames `wave` / wave + 4
+  // nine frame slots per k quarter: slots 0..6 = the gen tiles of frame s, slot 7 / 8 = the down tiles of frames `wave` / wave + 4
   // (wave 3 has no second down frame: it multiplies frame 6 again and never stores the result -- no branch in the MFMA stream:
-  // per-unit tests of a runtime wave index made hipcc copy accumulators at every merge).  Units of two slots = four accumulator
-  // tiles in rotation; x reads one unit ahead.
-  const char* const xl = lds + kq * 64 + li * 4;         // + frame * 2048 + step * 256
+  // per-unit tests of a runtime wave index made hipcc copy accumulators at every merge).  Units of two slots x two channel tiles =
+  // four accumulator tiles in rotation, two k steps each; x reads one unit ahead.
+  // Queue per wave and quarter, in issue order: ONE DMA of the next tile behind the quarter's first unit, the 4 weight loads of
+  // quarter qd + 2 (same set) behind its last unit.  In front of quarter qd its weights must be there = all but the 5 newest
+  // operations (the DMA and the 4 loads issued during quarter qd - 1); at the end of the step the tile's DMAs = all but the 4 newest.
+  const char* const xl = lds + kq * 64 + li * 4;         // + frame * 2048 + quarter * 512 + e * 256
   const int xoffA = wave * FRAME_B, xoffB = min(wave + 4, PT_FT - 1) * FRAME_B;
-  auto rdx = [&](float (&x)[4], const int st, const int hf, const int slot) {
-    const char* q = xl + st * STAGE_B + hf * 1024 + (slot < PT_FT ? slot * FRAME_B : (slot == PT_FT ? xoffA : xoffB));
+  auto rdx = [&](float (&x)[2], const int st, const int qd, const int slot) {
+    const char* q = xl + st * STAGE_B + qd * 512 + (slot < PT_FT ? slot * FRAME_B : (slot == PT_FT ? xoffA : xoffB));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = *reinterpret_cast<const float*>(q + e * 256);
+    for (int e = 0; e < 2; ++e) x[e] = *reinterpret_cast<const float*>(q + e * 256);
   };
   auto mf = [&](f32x4& c, float a, float b) { c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); };
-  auto mma = [&](const int st, int ktn) {
-    constexpr int NS = PT_FT + 2, NU = (NS + 1) / 2;          // slots, units per k half
-    float x[2][2][4];
+  auto mma = [&](const int st, int kt, int ktn) {
+    constexpr int NS = PT_FT + 2, NU = (NS + 1) / 2;          // slots, units per k quarter
+    float x[2][2][2];
     rdx(x[0][0], st, 0, 0);
     rdx(x[0][1], st, 0, 1);
 #pragma unroll
-    for (int u = 0; u < 2 * NU; ++u) {
-      const int hf = u / NU, uu = u % NU, s0 = 2 * uu, s1 = s0 + 1;
-      if (u + 1 < 2 * NU) {
-        const int hn = (u + 1) / NU, un = (u + 1) % NU;
-        rdx(x[(u + 1) & 1][0], st, hn, 2 * un);
-        if (2 * un + 1 < NS) rdx(x[(u + 1) & 1][1], st, hn, 2 * un + 1);
+    for (int u = 0; u < 4 * NU; ++u) {
+      const int qd = u / NU, uu = u % NU, s0 = 2 * uu, s1 = s0 + 1, set = qd & 1;
+      if (u + 1 < 4 * NU) {
+        const int qn = (u + 1) / NU, un = (u + 1) % NU;
+        rdx(x[(u + 1) & 1][0], st, qn, 2 * un);
+        if (2 * un + 1 < NS) rdx(x[(u + 1) & 1][1], st, qn, 2 * un + 1);
       }
-      if (uu == 0) { if (hf == 0) OFFK_WAIT16(4, 0); else OFFK_WAIT16(8, 1); }
+      if (uu == 0) { if (set == 0) OFFK_WAIT16(5, 0); else OFFK_WAIT16(5, 1); }
       __builtin_amdgcn_sched_barrier(0);
-      const float (&xa)[4] = x[u & 1][0];
-      const float (&xb)[4] = x[u & 1][1];
+      const float (&xa)[2] = x[u & 1][0];
+      const float (&xb)[2] = x[u & 1][1];
       // accumulators and weights of the two slots (literals: s0 / s1 are compile-time)
       f32x4 &a00 = s0 < PT_FT ? ag[s0][0] : ad[s0 - PT_FT][0], &a01 = s0 < PT_FT ? ag[s0][1] : ad[s0 - PT_FT][1];
-      const f32x4 &w00 = s0 < PT_FT ? wg[hf] : wd[hf], &w01 = s0 < PT_FT ? wg[2 + hf] : wd[2 + hf];
+      const f32x2 &w00 = s0 < PT_FT ? wg[set][0] : wd[set][0], &w01 = s0 < PT_FT ? wg[set][1] : wd[set][1];
       if (s1 < NS) {
         f32x4 &a10 = s1 < PT_FT ? ag[s1][0] : ad[s1 - PT_FT][0], &a11 = s1 < PT_FT ? ag[s1][1] : ad[s1 - PT_FT][1];
-        const f32x4 &w10 = s1 < PT_FT ? wg[hf] : wd[hf], &w11 = s1 < PT_FT ? wg[2 + hf] : wd[2 + hf];
+        const f32x2 &w10 = s1 < PT_FT ? wg[set][0] : wd[set][0], &w11 = s1 < PT_FT ? wg[set][1] : wd[set][1];
         mf(a00, w00.x, xa[0]); mf(a01, w01.x, xa[0]); mf(a10, w10.x, xb[0]); mf(a11, w11.x, xb[0]);
         mf(a00, w00.y, xa[1]); mf(a01, w01.y, xa[1]); mf(a10, w10.y, xb[1]); mf(a11, w11.y, xb[1]);
-        mf(a00, w00.z, xa[2]); mf(a01, w01.z, xa[2]); mf(a10, w10.z, xb[2]); mf(a11, w11.z, xb[2]);
-        mf(a00, w00.w, xa[3]); mf(a01, w01.w, xa[3]); mf(a10, w10.w, xb[3]); mf(a11, w11.w, xb[3]);
       } else {
         mf(a00, w00.x, xa[0]); mf(a01, w01.x, xa[0]);
         mf(a00, w00.y, xa[1]); mf(a01, w01.y, xa[1]);
-        mf(a00, w00.z, xa[2]); mf(a01, w01.z, xa[2]);
-        mf(a00, w00.w, xa[3]); mf(a01, w01.w, xa[3]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #ifndef OFFK_K16_NO_DMA
-      if (u < 4) dma_issue(u, st ^ 1);              // every wave has left stage st ^ 1 at the last barrier
+      if (uu == 0) dma_issue(qd, st ^ 1);            // every wave has left stage st ^ 1 at the last barrier
 #else
-      if (u < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(wg[0]) : "v"(wlane), "s"(wdesc));   // timing only: keeps the counts
+      if (uu == 0) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "+v"(wg[set][0]) : "v"(wlane), "s"(wdesc));   // timing only: keeps the counts
 #endif
+      // the set is free: quarter qd + 2 of this tile, or quarter qd - 2 of the next one
 #ifndef OFFK_K16_NO_W
-      if (uu == NU - 1) load_w(hf, ktn);
+      if (uu == NU - 1) { if (qd < 2) load_w(set, qd + 2, kt); else load_w(set, qd - 2, ktn); }
 #else
-      if (uu == NU - 1) load_w(hf, 0);              // timing only: the same (cached) tile every time
+      if (uu == NU - 1) load_w(set, qd & 1, 0);      // timing only: the same (cached) tile every time
 #endif
     }
   };
@@ -689,16 +690,16 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
   auto step = [&](int kt, const int st) {
     OFFK_STAMP(tm_mma, dma_prep(min(kt + 1, nkt - 1));
     __builtin_amdgcn_sched_barrier(0);
-    mma(st, min(kt + 1, nkt - 1)))
-    OFFK_STAMP(tm_wait, asm volatile("s_waitcnt vmcnt(8)" ::: "memory"))   // this wave's DMAs of the step have landed
+    mma(st, kt, min(kt + 1, nkt - 1)))
+    OFFK_STAMP(tm_wait, asm volatile("s_waitcnt vmcnt(4)" ::: "memory"))   // this wave's DMAs of the step have landed
     OFFK_STAMP(tm_bar, __syncthreads())
   };
   dma_prep(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) dma_issue(i, 0);
-  load_w(0, 0);
-  load_w(1, 0);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  load_w(0, 0, 0);
+  load_w(1, 1, 0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the tile and the first quarter's weights (the loop's first wait assumes it)
   __syncthreads();
 #ifdef OFFK_PT_TIMING
   const unsigned long long tm_loop = __builtin_readcyclecounter();
@@ -714,16 +715,19 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
 #endif
 #undef OFFK_STAMP
   // nothing may still be landing when the LDS is handed on; the weight registers stay allocated until their last load returned
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0]), "+v"(wg[1]), "+v"(wg[2]), "+v"(wg[3]), "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(wd[3]) :: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0][0]), "+v"(wg[0][1]), "+v"(wg[1][0]), "+v"(wg[1][1]), "+v"(wd[0][0]), "+v"(wd[0][1]), "+v"(wd[1][0]), "+v"(wd[1][1]) :: "memory");
 #undef OFFK_WAIT16
 
   // ---- epilogue: lane = (pixel li, channels 4 kq .. + 3 of a channel tile): G = relu(acc + bias), T = G[j + 1] - G[j]; D ----
-  const int bl = b + (li >> rsh), pixl = q0 + (li & rmask);
+  // (li / kq are re-derived from the execution mask here: kept from the prologue they are two more registers live across the K loop)
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int li_e = lane_e & 15, kq_e = lane_e >> 4;
+  const int bl = b + (li_e >> rsh), pixl = q0 + (li_e & rmask);
   const size_t pair0 = (size_t)bl * (L - 1) + t0;
   const bool pix_ok = pixl < HW && bl < p.B;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    const f32x4 bg = *reinterpret_cast<const f32x4*>(S.bias + wave * 32 + 16 * ct + 4 * kq);
+    const f32x4 bg = *reinterpret_cast<const f32x4*>(S.bias + wave * 32 + 16 * ct + 4 * kq_e);
     f32x4 g[PT_FT];
 #pragma unroll
     for (int j = 0; j < PT_FT; ++j) {
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
 #pragma unroll
     for (int j = 0; j + 1 < PT_FT; ++j)
       if (j + 1 < nf && pix_ok)
-        *reinterpret_cast<f32x4*>(S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 16 * ct + 4 * kq) = g[j + 1] - g[j];
+        *reinterpret_cast<f32x4*>(S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 16 * ct + 4 * kq_e) = g[j + 1] - g[j];
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -743,8 +747,8 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
       if (dr >= 0) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 bd = *reinterpret_cast<const f32x4*>(S.bias_down + 16 * ct + 4 * kq);
-          *reinterpret_cast<f32x4*>(S.D + ((size_t)dr * HW + pixl) * kDownCh + 16 * ct + 4 * kq) = ad[half][ct] + bd;
+          const f32x4 bd = *reinterpret_cast<const f32x4*>(S.bias_down + 16 * ct + 4 * kq_e);
+          *reinterpret_cast<f32x4*>(S.D + ((size_t)dr * HW + pixl) * kDownCh + 16 * ct + 4 * kq_e) = ad[half][ct] + bd;
         }
       }
     }
@@ -760,20 +764,20 @@ __global__ __launch_bounds__(256, 3) void pw_tdiff16_kernel(PtParams p) {
 #endif
 }
 
-// Operand-order image for pw_tdiff16_kernel: one 16-byte item per (K-tile, slab of 32 rows, channel tile ct, k half hf, lane):
-//   W[slab * 32 + 16 ct + li][kt * 32 + 16 hf + 4 e + kq], e = 0..3   (li = lane & 15, kq = lane >> 4)
-__global__ void pw_pack_direct16_kernel(const float* __restrict__ w, int C, float4* __restrict__ out) {
+// Operand-order image for pw_tdiff16_kernel: one 8-byte item per (K-tile, slab of 32 rows, channel tile ct, k quarter qd, lane):
+//   W[slab * 32 + 16 ct + li][kt * 32 + 8 qd + 4 e + kq], e = 0, 1   (li = lane & 15, kq = lane >> 4)
+__global__ void pw_pack_direct16_kernel(const float* __restrict__ w, int C, float2* __restrict__ out) {
   const int item = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nitems = (C / BK) * 5 * 2 * 2 * 64;
+  const int nitems = (C / BK) * 5 * 2 * 4 * 64;
   if (item >= nitems) return;
-  const int lane = item & 63, hf = (item >> 6) & 1, ct = (item >> 7) & 1, slab = (item >> 8) % 5, kt = (item >> 8) / 5;
+  const int lane = item & 63, qd = (item >> 6) & 3, ct = (item >> 8) & 1, slab = (item >> 9) % 5, kt = (item >> 9) / 5;
   const int li = lane & 15, kq = lane >> 4;
-  const float* row = w + (size_t)(slab * 32 + 16 * ct + li) * C + kt * BK + 16 * hf + kq;
-  out[item] = make_float4(row[0], row[4], row[8], row[12]);
+  const float* row = w + (size_t)(slab * 32 + 16 * ct + li) * C + kt * BK + 8 * qd + kq;
+  out[item] = make_float2(row[0], row[4]);
 }
 hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStream_t st) {
-  const int nitems = (C / BK) * 5 * 2 * 2 * 64;
-  hipLaunchKernelGGL(pw_pack_direct16_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, w160, C, reinterpret_cast<float4*>(out));
+  const int nitems = (C / BK) * 5 * 2 * 4 * 64;
+  hipLaunchKernelGGL(pw_pack_direct16_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, w160, C, reinterpret_cast<float2*>(out));
   return hipGetLastError();
 }
 

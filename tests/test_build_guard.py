@@ -23,7 +23,7 @@ def test_guarded_kernels_have_no_spills_and_fit_their_budget(build_mod):
     table = build_mod.resource_table()
     assert set(table) == {"pw_tdiff.hip", "chain_fused.hip", "conv_igemm.hip"}
     k16 = [k for k in table["pw_tdiff.hip"] if "pw_tdiff16_kernel" in k["name"]]
-    assert len(k16) == 1 and k16[0]["vgpr_count"] <= 168
+    assert len(k16) == 1 and k16[0]["vgpr_count"] <= 128          # four blocks per CU
     chains = [k for k in table["chain_fused.hip"] if "chain14_kernel" in k["name"]]
     assert len(chains) == 3 and all(k["vgpr_count"] <= 168 for k in chains)
     dflt = [k for k in table["conv_igemm.hip"] if ", 1, 1, 2, 2, 4>" in k["name"]]
@@ -31,16 +31,20 @@ def test_guarded_kernels_have_no_spills_and_fit_their_budget(build_mod):
     for rows in table.values():
         for k in rows:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
-    for k in k16 + chains + dflt:
+    for k in chains + dflt:          # (pw_tdiff16_kernel parks five loop-invariant scalars in VGPR lanes in front of its K loop)
         assert k["sgpr_spill_count"] == 0, k
 
 
 def test_guard_fires(build_mod):
-    ok = {"name": "offk::pw_tdiff16_kernel(offk::PtParams)", "vgpr_count": 152, "agpr_count": 0, "vgpr_spill_count": 0,
+    ok = {"name": "offk::pw_tdiff16_kernel(offk::PtParams)", "vgpr_count": 128, "agpr_count": 0, "vgpr_spill_count": 0,
           "sgpr_spill_count": 0, "private_segment_fixed_size": 0}
     assert build_mod.check_resources("pw_tdiff.hip", [ok]) == [ok]
-    for bad in ({"vgpr_spill_count": 2, "private_segment_fixed_size": 12}, {"vgpr_count": 176}, {"sgpr_spill_count": 3}):
+    for bad in ({"vgpr_spill_count": 2, "private_segment_fixed_size": 12}, {"vgpr_count": 136}):
         with pytest.raises(RuntimeError, match="resource guard failed"):
             build_mod.check_resources("pw_tdiff.hip", [dict(ok, **bad)])
+    chain = dict(ok, name="void offk::chain14_kernel<4, true>(offk::ChainArgs)", vgpr_count=152)
+    assert build_mod.check_resources("chain_fused.hip", [chain]) == [chain]
+    with pytest.raises(RuntimeError, match="resource guard failed"):
+        build_mod.check_resources("chain_fused.hip", [dict(chain, sgpr_spill_count=3)])
     with pytest.raises(RuntimeError, match="no kernel of pw_tdiff.hip matches"):
         build_mod.check_resources("pw_tdiff.hip", [dict(ok, name="offk::renamed_kernel(offk::PtParams)")])
