@@ -317,7 +317,20 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             key = name.split(" ")[0]
             co, ci, ksz = next((c, i, kk) for k_, c, i, kk, _s, _p in spec.FUSION_CONVS if k_ == key)
             T = 9 * P if ksz == 7 else P
-            if ksz == 7 and "GEMMs" not in name:
+            if "between]" in name:
+                # wino_mid.hip: "<conv A> out + [<1x1 conv> +] <conv B> in": reads conv A's GEMM output M [121][P][Co_A], stores conv
+                # A's activation where a later conv needs it (when a 1x1 conv sits in between) and writes conv B's GEMM input
+                # V [121][P][Cmid]; the 1x1 conv's FLOPs ride along (0.6 / 2.5 GFLOP): bandwidth / latency bound
+                parts = [q.strip().split(" ")[0] for q in name.split("[")[0].split("+")]
+                mid_keys = parts[1:-1]
+                cmid = next(c for k_, c, _i, _kk, _s, _p in spec.FUSION_CONVS if k_ == mid_keys[0]) if mid_keys else co
+                nbytes = (121 * P * co + (P * 49 * co if mid_keys else 0) + 121 * P * cmid) * 4
+                rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
+                if mid_keys:
+                    rec["flops_riding_along"] = work[mid_keys[0]]
+                small_ms += avg
+                small_fl += work[mid_keys[0]] if mid_keys else 0.0
+            elif ksz == 7 and "GEMMs" not in name:
                 # F(5x5, 4x4), four 14x14 phase images: 225 transformed floats per (tile, channel); 64 GEMM outputs per (tile, co)
                 nbytes = (T * 225 * ci + P * 784 * ci) * 4 if "input" in name else (64 * T * co + P * 196 * co) * 4
                 rec.update(bound="hbm", algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)

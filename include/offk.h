@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 7
+#define OFFK_ABI_VERSION 8
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -263,6 +263,19 @@ int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_c
 int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
                             const float* w_packed, const float* bias, int Co, int flags,
                             float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats);
+
+/* What sits BETWEEN two convolutions on the Winograd path at 7x7 maps, in one launch (wino_mid.hip; ABI v8).  Replaces, for the runs
+ * 3x3 -> 1x1 -> 3x3 of RGB_OFF.py:762-767 (x1 -> motion_conv1_trans_14a -> motion_conv2_trans_14a) and :833-838 (x2 ->
+ * motion_conv1_trans -> motion_conv2_trans), the output transform of the first conv, the 1x1 conv and the input transform of the
+ * last one; with w1 == NULL, for :775-780 (motion_conv2_trans_14b -> motion_conv3_trans_14b), the two transforms alone.
+ *   M      GEMM output of the conv in front in the Winograd domain, [121][n_img][Cin] (point order: phases_in = 1 a 3x3 / stride 1
+ *          conv, 4 the polyphase 5x5 / stride 2 conv); bias_in [Cin] its bias (nullable); ReLU is applied behind it
+ *   x      nullable: relu(A^T M A + bias_in) is also stored there, channels-last rows [n_img * 49][x_cstride] at x_coff
+ *   w1     1x1 conv [Cmid][Cin] with bias b1 [Cmid] and ReLU behind it; NULL: none (Cmid == Cin)
+ *   V      GEMM input of the conv behind, [121][n_img][Cmid]
+ * Shapes built: (Cin, Cmid) = (128, 128) and (256, 256); without w1 also Cin = 128 / 256. */
+int offk_winograd_between(void* stream, const float* M, const float* bias_in, int phases_in, int n_img, int Cin,
+                          float* x, int x_cstride, int x_coff, const float* w1, const float* b1, int Cmid, float* V);
 
 /* K5. Replaces motion_pool_trans_28 / global_pool / squeeze / fc_action_motion*
  * (RGB_OFF.py:782-787, 789-793, 843-847): optional MaxPool(3,2,ceil) then global

@@ -65,6 +65,7 @@ SIGNATURES = {
     "offk_winograd_conv3x3": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t, _F]),
     "offk_winograd_conv5x5s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_winograd_conv7x7s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
+    "offk_winograd_between": (_I, [_P, _F, _F, _I, _I, _I, _F, _I, _I, _F, _F, _I, _F]),
     "offk_split_bf16x3": (_I, [_P, _F, _c.c_size_t, _F]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),
@@ -101,7 +102,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 7:
+    if lib.offk_abi_version() != 8:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

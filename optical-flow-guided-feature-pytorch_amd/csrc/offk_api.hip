@@ -151,6 +151,8 @@ struct offk_handle {
   bool wino_dirty = true;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
+  bool wino_mid = true;          // fp32 + Winograd: output transform + 1x1 conv + input transform between two Winograd convs in one launch
+                                 // (wino_mid.hip); OFFK_WINO_MID=0 at offk_create: three launches
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
   int chain_min_p = 72;          // ... from this many pairs (OFFK_CHAIN=<n> with n > 1 at offk_create: tests / tools)
   size_t train_ws_bytes = 0;
@@ -729,9 +731,12 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   //   OFFK_WINOGRAD_5X5  ... of the 5x5 / stride 2 conv (default: from P = 40)     OFFK_WINOGRAD_7X7  ... of the 7x7 / stride 2 conv (from P = 12)
   //   OFFK_CHAIN         one launch per bottleneck chain of fusion@28 (chain_fused.hip; from P = 72)
   //   OFFK_FOLD_POOL     7- / 14-head average pools taken in the producing conv's epilogue; 0: pool + fc kernels
+  //   OFFK_WINO_MID      what sits between two Winograd convs on 7x7 maps (output transform, 1x1 conv, input transform) in one launch
+  //                      (wino_mid.hip); 0: three launches
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_WINO_MID"); h->wino_mid = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
   { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino5_min_p = atoi(e); }
   { const char* e = getenv("OFFK_WINOGRAD_7X7"); h->wino_7x7 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino7_min_p = atoi(e); }
@@ -1116,20 +1121,47 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   const bool wino = h->winograd && h->cfg.precision == OFFK_PRECISION_FP32;
   float* const wino_V = wino ? region(h, ws, "wino_v") : nullptr;
   float* const wino_M = wino ? region(h, ws, "wino_m") : nullptr;
-  auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
-                       int y_coff, float* pool_t) -> int {
+  // the three steps of a conv on that path: V = B^T x B (wino_V), M = V U per point (wino_M), y = epilogue(A^T M A)
+  auto wino_in = [&](ConvId id, View x) -> int {
     const ConvSpec& c = kConvs[id];
-    const int phases = c.K == 5 ? 4 : 1;          // rows of a batch entry: one per image
     TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
-    HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, phases, wino_V, s));
-    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 121 GEMMs]").c_str()));
-    WinoGroup grp[4];
-    const int ngrp = wino_groups(phases, n, c.Ci, c.Co, grp);
-    TRY(wino_gemms(c.key, grp, ngrp, kWinoPoints, n, c.Ci, c.Co, wino_V, h->wino_u[uidx], wino_M));
-    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()));
-    HIP_TRY(h, wino_output_launch(wino_M, n, c.Co, phases, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
+    HIP_TRY(h, wino_input_launch(x.p, x.cs, x.coff, n, c.Ci, c.K == 5 ? 4 : 1, wino_V, s));
     return OFFK_OK;
   };
+  auto wino_mm = [&](ConvId id, int uidx) -> int {
+    const ConvSpec& c = kConvs[id];
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 121 GEMMs]").c_str()));
+    WinoGroup grp[4];
+    const int ngrp = wino_groups(c.K == 5 ? 4 : 1, n, c.Ci, c.Co, grp);
+    return wino_gemms(c.key, grp, ngrp, kWinoPoints, n, c.Ci, c.Co, wino_V, h->wino_u[uidx], wino_M);
+  };
+  auto wino_out = [&](ConvId id, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs, int y_coff, float* pool_t) -> int {
+    const ConvSpec& c = kConvs[id];
+    TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: output transform]").c_str()));
+    HIP_TRY(h, wino_output_launch(wino_M, n, c.Co, c.K == 5 ? 4 : 1, h->conv_b[id], res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t, s));
+    return OFFK_OK;
+  };
+  auto wino_conv = [&](ConvId id, int uidx, View x, const float* res, int res_cs, int res_coff, int flags, float* y, int y_cs,
+                       int y_coff, float* pool_t) -> int {
+    TRY(wino_in(id, x));
+    TRY(wino_mm(id, uidx));
+    return wino_out(id, res, res_cs, res_coff, flags, y, y_cs, y_coff, pool_t);
+  };
+  // What sits between two convs on that path, in ONE launch (wino_mid.hip): the output transform (+ bias, ReLU) of conv `a` from
+  // wino_M, optionally the 1x1 conv `mid` (+ bias, ReLU), the input transform of the conv behind into wino_V.  xa: where the
+  // activation of conv `a` is ALSO stored (the merged convs read x1 / x2 from there later); nullptr: nowhere.
+  auto wino_between = [&](ConvId a, const ConvId* mid, float* xa, int xa_cs, int xa_coff, const char* name) -> int {
+    WinoMidArgs m;
+    m.M = wino_M; m.bias_in = h->conv_b[a]; m.phases_in = kConvs[a].K == 5 ? 4 : 1;
+    m.x = xa; m.x_cs = xa_cs; m.x_coff = xa_coff;
+    m.w1 = mid ? h->conv_w[*mid] : nullptr; m.b1 = mid ? h->conv_b[*mid] : nullptr;
+    m.Cin = kConvs[a].Co; m.Cmid = mid ? kConvs[*mid].Co : kConvs[a].Co; m.n_img = n;
+    m.V = wino_V;
+    TRY(trace_mark(h, s, name));
+    HIP_TRY(h, wino_mid_launch(m, s));
+    return OFFK_OK;
+  };
+  const bool mid = wino && h->wino_mid;
   // ---- fusion @28 -> 14x14 (RGB_OFF.py:655-685) -----------------------------------
   // xt = [t2 | x0] per pixel: c3(t2) + branch(x0) (:663-666) is then ONE 1x1 conv over 128 channels
   // :657 x0, pre-ReLU kept for the branch.  fp32: polyphase Winograd F(5x5, 4x4) (winograd7.hip) -- input transform, 64 batched
@@ -1200,14 +1232,28 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   // ---- fusion @14 -> 7x7 (RGB_OFF.py:759-780) ---------------------------------------
   // (from P = 40 pairs: below, its 132-K-tile GEMMs have too few row tiles to fill the chip and the split-K direct conv wins --
   // B = 1: 0.435 vs 0.50 ms, B = 4: 0.672 vs 0.695, B = 8: 0.892 vs 0.874, B = 12: 1.157 vs 1.12; OFFK_WINOGRAD_5X5=<pairs> moves the gate)
-  if (wino && h->wino_5x5 && P >= h->wino5_min_p) TRY(wino_conv(C_T14, 5, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128, nullptr));   // :762-763 x1 (polyphase)
-  else TRY(conv(h, s, C_T14, n, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128));        // :762-763 x1
-  TRY(conv(h, s, C1_14A, n, 7, View{xu, 256, 128}, nullptr, 0, 0, RP, u1, 128, 0));               // :764-765
-  if (wino) TRY(wino_conv(C2_14A, 3, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0, nullptr));  // :766-767 u2
-  else TRY(conv(h, s, C2_14A, n, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));            // :766-767 u2
+  const bool w5 = wino && h->wino_5x5 && P >= h->wino5_min_p;
+  if (w5 && mid) {      // :762-767: x1 = relu(conv5x5(F14)) -> c1_14a -> c2_14a, the 1x1 conv between the two Winograd GEMM launches
+    const ConvId c1 = C1_14A;
+    TRY(wino_in(C_T14, View{F14, 1056, 0}));
+    TRY(wino_mm(C_T14, 5));
+    TRY(wino_between(C_T14, &c1, xu, 256, 128, "motion_conv_trans_14 out + motion_conv1_trans_14a + motion_conv2_trans_14a in [winograd: between]"));
+    TRY(wino_mm(C2_14A, 3));
+    TRY(wino_out(C2_14A, nullptr, 0, 0, RP, xu, 256, 0, nullptr));                                 // :766-767 u2
+  } else {
+    if (w5) TRY(wino_conv(C_T14, 5, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128, nullptr));   // :762-763 x1 (polyphase)
+    else TRY(conv(h, s, C_T14, n, 14, View{F14, 1056, 0}, nullptr, 0, 0, RP, xu, 256, 128));      // :762-763 x1
+    TRY(conv(h, s, C1_14A, n, 7, View{xu, 256, 128}, nullptr, 0, 0, RP, u1, 128, 0));             // :764-765
+    if (wino) TRY(wino_conv(C2_14A, 3, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0, nullptr));  // :766-767 u2
+    else TRY(conv(h, s, C2_14A, n, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));          // :766-767 u2
+  }
   TRY(conv_merged(h, s, 1, n, 7, View{xu, 256, 0}, RO, s14, 512, 0));                              // :768-771
   TRY(conv(h, s, C1_14B, n, 7, View{s14, 512, 0}, nullptr, 0, 0, RP, u1, 128, 0));                // :773-774
-  if (wino) TRY(wino_conv(C2_14B, 4, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0, nullptr));  // :775-776
+  if (mid) {            // :775-780: c2_14b's output feeds c3_14b alone -- output transform, ReLU and input transform in one launch
+    TRY(wino_in(C2_14B, View{u1, 128, 0}));
+    TRY(wino_mm(C2_14B, 4));
+    TRY(wino_between(C2_14B, nullptr, nullptr, 0, 0, "motion_conv2_trans_14b out + motion_conv3_trans_14b in [winograd: between]"));
+  } else if (wino) TRY(wino_conv(C2_14B, 4, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0, nullptr));  // :775-776
   else TRY(conv(h, s, C2_14B, n, 7, View{u1, 128, 0}, nullptr, 0, 0, RP, xu, 256, 0));            // :775-776
   // (fold: the conv's epilogue also leaves per-slab column sums of sum_14b: the 14-head's average pool)
   auto generic = [](int cfg) { return cfg != 6 && cfg != 7 && cfg != 10; };      // the LDS-patch kernels have no pooling epilogue
@@ -1216,7 +1262,10 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   float* pp7 = region(h, ws, "poolpart_7");
   float* pp14t = wino ? region(h, ws, "poolpart_14t") : nullptr;
   const bool fold14t = wino && h->fold_pool;
-  if (wino) {
+  if (mid) {
+    TRY(wino_mm(C3_14B, 0));
+    TRY(wino_out(C3_14B, s14, 512, 0, RP | RO, F7, 832, 320, fold14t ? pp14t : nullptr));          // :777-780 -> cat at :832
+  } else if (wino) {
     TRY(wino_conv(C3_14B, 0, View{xu, 256, 0}, s14, 512, 0, RP | RO, F7, 832, 320, fold14t ? pp14t : nullptr));   // :777-780 -> cat at :832
   } else {
     h->cur_pool_part = fold ? pp14 : nullptr;
@@ -1236,11 +1285,20 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     TRY(run_head(2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));
   }
   // ---- fusion @7 (RGB_OFF.py:831-841) -------------------------------------------------
-  if (wino) TRY(wino_conv(C_T7, 1, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256, nullptr));  // :833-834 x2
-  else TRY(conv(h, s, C_T7, n, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256));            // :833-834 x2
-  TRY(conv(h, s, C1_7, n, 7, View{xv, 512, 256}, nullptr, 0, 0, RP, v1, 256, 0));                 // :835-836
-  if (wino) TRY(wino_conv(C2_7, 2, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0, nullptr));    // :837-838 v2
-  else TRY(conv(h, s, C2_7, n, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0));              // :837-838 v2
+  if (mid) {            // :833-838: x2 = relu(conv3x3(F7)) -> c1 -> c2, as fusion@14's first three convs
+    const ConvId c1 = C1_7;
+    TRY(wino_in(C_T7, View{F7, 832, 0}));
+    TRY(wino_mm(C_T7, 1));
+    TRY(wino_between(C_T7, &c1, xv, 512, 256, "motion_conv_trans out + motion_conv1_trans + motion_conv2_trans in [winograd: between]"));
+    TRY(wino_mm(C2_7, 2));
+    TRY(wino_out(C2_7, nullptr, 0, 0, RP, xv, 512, 0, nullptr));                                   // :837-838 v2
+  } else {
+    if (wino) TRY(wino_conv(C_T7, 1, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256, nullptr));  // :833-834 x2
+    else TRY(conv(h, s, C_T7, n, 7, View{F7, 832, 0}, nullptr, 0, 0, RP, xv, 512, 256));          // :833-834 x2
+    TRY(conv(h, s, C1_7, n, 7, View{xv, 512, 256}, nullptr, 0, 0, RP, v1, 256, 0));               // :835-836
+    if (wino) TRY(wino_conv(C2_7, 2, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0, nullptr));  // :837-838 v2
+    else TRY(conv(h, s, C2_7, n, 7, View{v1, 256, 0}, nullptr, 0, 0, RP, xv, 512, 0));            // :837-838 v2
+  }
   h->cur_pool_part = fold ? pp7 : nullptr;
   { int rc_ = conv_merged(h, s, 2, n, 7, View{xv, 512, 0}, 0, s7, 1024, 0);                        // :839-841 (no ReLU)
     h->cur_pool_part = nullptr;
@@ -1531,6 +1589,21 @@ int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_c
     if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
   }
   e = wino7_output_launch(M, n_img, Co, bias, flags, y, y_cstride, y_coff, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  return OFFK_OK;
+}
+
+int offk_winograd_between(void* stream, const float* M, const float* bias_in, int phases_in, int n_img, int Cin, float* x,
+                          int x_cstride, int x_coff, const float* w1, const float* b1, int Cmid, float* V) {
+  const char* who = "offk_winograd_between";
+  if (!M || !V || n_img < 1 || (w1 && !b1) || (x && (x_cstride < x_coff + Cin || (x_cstride & 3) || (x_coff & 3) || x_coff < 0)))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument");
+  if (!wino_mid_supported(Cin, Cmid, w1 != nullptr, phases_in))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": shape not built ((Cin, Cmid) = (128, 128) / (256, 256); phases_in 1, or 4 with Cin 128)");
+  WinoMidArgs m;
+  m.M = M; m.bias_in = bias_in; m.phases_in = phases_in; m.x = x; m.x_cs = x_cstride; m.x_coff = x_coff;
+  m.w1 = w1; m.b1 = b1; m.Cin = Cin; m.Cmid = Cmid; m.n_img = n_img; m.V = V;
+  hipError_t e = wino_mid_launch(m, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
   return OFFK_OK;
 }

@@ -73,6 +73,20 @@ hipError_t wino_output_launch(const float* M, int n_img, int Co, int phases, con
 // (81 points K = 4 Ci, 18 + 18 points K = 2 Ci, 4 points K = Ci; winograd.hip).  Offsets in floats for `rows` images / Co output channels.
 struct WinoGroup { int batch, kmul; long long v_off, u_off, m_off; };
 int wino_groups(int phases, long long rows, int Ci, int Co, WinoGroup out[4]);
+// ---- K4m: output transform -> (1x1 conv + ReLU) -> input transform between two Winograd convs on 7x7 maps, one launch (wino_mid.hip)
+struct WinoMidArgs {
+  const float* M;          // GEMM output of the conv in front, Winograd domain: [121][n_img][Cin]
+  const float* bias_in;    // [Cin] bias of that conv (its ReLU is applied here); nullptr: none
+  int phases_in;           // point order of M: 1 = a 3x3 / stride 1 conv, 4 = the polyphase 5x5 / stride 2 conv (winograd.hip)
+  float* x; int x_cs, x_coff;   // != nullptr: also store x = relu(A^T M A + bias) as channels-last rows [n_img * 49][x_cs] at x_coff
+  const float* w1;         // 1x1 conv [Cmid][Cin] and its bias [Cmid] (ReLU behind it); nullptr: no 1x1 conv (Cmid == Cin)
+  const float* b1;
+  int Cin, Cmid, n_img;
+  float* V;                // GEMM input of the conv behind: [121][n_img][Cmid] (3x3 / stride 1 point order)
+  int nsplit = 0;          // blocks per image the 1x1 conv's output channels are split over (0: the default of the shape; tools)
+};
+bool wino_mid_supported(int Cin, int Cmid, bool gemm, int phases_in);
+hipError_t wino_mid_launch(const WinoMidArgs& a, hipStream_t st);
 // ---- K4w7: the 7x7 / stride 2 / pad 3 conv on 28x28 maps in polyphase Winograd form, F(5x5, 4x4) (winograd7.hip): 9 tiles per image,
 // 64 points in four groups (49 points K = 4 Ci, 7 + 7 points K = 2 Ci, 1 point K = Ci): 225 row-Ci units of U / V per output channel / tile
 constexpr int kWino7Units = 225, kWino7Points = 64, kWino7Tiles = 9;

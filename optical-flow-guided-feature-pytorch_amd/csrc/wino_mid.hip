@@ -1,0 +1,251 @@
+// K4m: what sits BETWEEN two Winograd convolutions on 7x7 maps, in one launch (exact fp32).
+//
+// The 7x7-map stages of the fusion network alternate 3x3 convolutions (on the Winograd path: winograd.hip) with 1x1 convolutions
+// (RGB_OFF.py:762-767 x1 -> c1_14a -> c2_14a, :773-780 c1_14b -> c2_14b -> c3_14b, :833-838 x2 -> c1 -> c2).  As separate launches a
+// 3x3 -> 1x1 -> 3x3 run costs an output transform, the 1x1 conv and an input transform: three short launches (10-35 us each at
+// P = 384, most of it launch / drain latency) and two activation round trips through HBM for 0.6 - 2.5 GFLOP of matrix work
+// (profiles/r03/bench_b64_final.json, roofline_in_path).  Here a block owns ONE image and does all of it on chip:
+//   stage A  x = relu(A^T M A + bias)      the output transform of the conv in front, from its GEMM output M [121][P][CIN];
+//                                          x goes to LDS ([64 pixel slots][CIN], 16-byte chunks XOR-swizzled by the slot) and,
+//                                          where a later conv reads it, to its channel slice in HBM (x1 / x2 of the merged convs)
+//   stage B  t = relu(W1 x + b1)           the 1x1 conv: v_mfma_f32_16x16x4_f32, weights = A operand straight from L2 (a lane ends
+//                                          with four consecutive channels of one pixel), pixels = B operand from LDS; t -> LDS
+//   stage C  V = B^T t B                   the input transform of the conv behind, to its GEMM input V [121][P][CMID]
+// GEMM = false drops stage B: output transform + ReLU + input transform between two 3x3 convs that follow each other
+// (motion_conv2_trans_14b -> motion_conv3_trans_14b).
+// The transforms are the arithmetic of wino_output_kernel / wino_input_kernel element for element; only the 1x1 conv's summation
+// order differs from the generic kernel's (k in steps of 4 instead of 2).
+#include "offk_common.h"
+#include "offk_internal.h"
+#include "winograd_common.h"
+
+namespace offk {
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// byte offset of channel c of pixel slot px in a [slot][C] tile whose 16-byte chunks are XOR-swizzled by the slot: a ds_read_b128 of
+// (16 slots, one k quad) and a ds_write / ds_read_b32 of 64 consecutive channels of one slot are both conflict-free
+template <int C>
+__device__ __forceinline__ int tile_off(int px, int c) { return px * (C * 4) + ((((c >> 2) ^ (px & 15))) << 4) + (c & 3) * 4; }
+
+// stage A for one class: M -> relu(A^T M A + bias) -> LDS tile (+ HBM), lane = channel within a group of 64.  TWO channel groups at
+// a time: their 2 x NY x NX loads -- every one a 256-byte row of a different point plane -- are in flight together (one group at a
+// time, the four groups of a 256-channel image were four exposed HBM latencies per block: the first version's 60 us at P = 384).
+template <int NPH, int CY, int CX, int CIN>
+__device__ __forceinline__ void mid_out_class(const WinoMidArgs& a, int img, int lane, char* xt, float* xg) {
+  constexpr int NY = CY ? 5 : 6, NX = CX ? 5 : 6, OY = CY ? 3 : 4, OX = CX ? 3 : 4, oy = CY ? 4 : 0, ox = CX ? 4 : 0;
+  const size_t pstride = (size_t)a.n_img * CIN;
+#pragma unroll
+  for (int g0 = 0; g0 < CIN / 64; g0 += 2) {
+    float m[2][NY][NX];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float* mp = a.M + (size_t)img * CIN + (g0 + u) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+#pragma unroll
+        for (int i = 0; i < NY; ++i) m[u][i][j] = mp[(size_t)wino_mindex<NPH, CY, CX>(i, j) * pstride];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = (g0 + u) * 64 + lane;
+      float s[OY][NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        float col[NY], sc[OY];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) col[i] = m[u][i][j];
+        wat(col, sc);
+#pragma unroll
+        for (int i = 0; i < OY; ++i) s[i][j] = sc[i];
+      }
+      const float bv = a.bias_in ? a.bias_in[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < OY; ++i) {
+        float yv[OX];
+        wat(s[i], yv);
+#pragma unroll
+        for (int j = 0; j < OX; ++j) {
+          const int px = (oy + i) * 7 + ox + j;
+          const float v = fmaxf(yv[j] + bv, 0.f);
+          *reinterpret_cast<float*>(xt + tile_off<CIN>(px, c)) = v;
+          if (xg) xg[((size_t)img * 49 + px) * a.x_cs + a.x_coff + c] = v;
+        }
+      }
+    }
+  }
+}
+
+// stage C for one class: LDS tile -> B^T t B -> V, lane = channel within a group of 64 of the block's C channels (V has CV)
+template <int CY, int CX, int C, int CV>
+__device__ __forceinline__ void mid_in_class(const WinoMidArgs& a, int img, int lane, int c_first, const char* ot) {
+  constexpr int NY = CY ? 5 : 6, NX = CX ? 5 : 6;
+  constexpr int oy = CY ? 4 : 0, ox = CX ? 4 : 0;          // output origin; the window starts one sample up / left of it
+  const size_t pstride = (size_t)a.n_img * CV;
+#pragma unroll
+  for (int g = 0; g < C / 64; ++g) {
+    const int c = g * 64 + lane;
+    float t[NY][NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+#pragma unroll
+      for (int i = 0; i < NY; ++i) {
+        const int row = oy - 1 + i, col = ox - 1 + j;          // (compile-time: which samples are the zero padding)
+        t[i][j] = row >= 0 && row < 7 && col >= 0 && col < 7 ? *reinterpret_cast<const float*>(ot + tile_off<C>(row * 7 + col, c)) : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      float d[NY], tc[NY];
+#pragma unroll
+      for (int i = 0; i < NY; ++i) d[i] = t[i][j];
+      wbt(d, tc);
+#pragma unroll
+      for (int i = 0; i < NY; ++i) t[i][j] = tc[i];
+    }
+    float* vp = a.V + (size_t)img * CV + c_first + c;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      float v[NX];
+      wbt(t[i], v);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) vp[(size_t)wino_mindex<1, CY, CX>(i, j) * pstride] = v[j];
+    }
+  }
+}
+}  // namespace
+
+// NPH: point order of M (1: a 3x3 / stride 1 conv in front, 4: the polyphase 5x5 / stride 2 conv).  NS: the 1x1 conv's output
+// channels are split over NS blocks per image (blockIdx.y), each of which repeats stage A for all CIN channels (M comes out of L2 the
+// second time): P = 384 images alone are 1.5 blocks per CU, and a 256 -> 256 block is 33 k cycles of MFMAs per wave.
+template <int CIN, int CMID, bool GEMM, int NPH, int NS>
+__global__ __launch_bounds__(256, 2) void wino_mid_kernel(WinoMidArgs a) {
+  static_assert(CIN % 64 == 0 && CMID % (64 * NS) == 0 && (GEMM || (CIN == CMID && NS == 1)), "whole waves of channels");
+  constexpr int CM = CMID / NS;                                   // output channels of this block
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // [64 slots][max(CIN, CM)] fp32: x, then t in the same place
+  const int img = blockIdx.x;
+  const int c_first = (int)blockIdx.y * CM;                       // first output channel of this block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- stage A: wave w = class w (its 6x6 / 6x5 / 5x6 / 5x5 points), every channel group; the activation goes to HBM from the first
+  //      of the NS blocks ----
+  float* const xg = blockIdx.y == 0 ? a.x : nullptr;
+  switch (wave) {
+    case 0: mid_out_class<NPH, 0, 0, CIN>(a, img, lane, lds, xg); break;
+    case 1: mid_out_class<NPH, 0, 1, CIN>(a, img, lane, lds, xg); break;
+    case 2: mid_out_class<NPH, 1, 0, CIN>(a, img, lane, lds, xg); break;
+    default: mid_out_class<NPH, 1, 1, CIN>(a, img, lane, lds, xg); break;
+  }
+  __syncthreads();
+
+  if constexpr (GEMM) {
+    // ---- stage B: t[ch][px] = relu(sum_k W1[ch][k] x[px][k] + b1[ch]); wave w owns the block's channels [w CM / 4, (w + 1) CM / 4) ----
+    constexpr int CT = CM / 64, PT = 4, KS = CIN / 16;              // channel tiles per wave, pixel tiles (49 of 64 slots used), k steps
+    const int li = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1), 0, CMID * CIN * 4, 0x00020000);
+    const int wvoff = ((c_first + wave * (CM / 4) + li) * CIN + 4 * kq) * 4;
+    auto w_load = [&](f32x4 (&w)[CT], const int s) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (16 * ct * CIN + 16 * s) * 4, 0);
+        w[ct] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      }
+    };
+    const char* const xrd = lds + li * (CIN * 4);                   // + pt * 16 rows, + chunk (4 s + kq) ^ li
+    auto x_load = [&](f32x4 (&x)[PT], const int s) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+        x[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * (CIN * 4) + (((4 * s + kq) ^ li) << 4));
+    };
+    f32x4 acc[PT][CT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wq[3][CT], xv[2][PT];
+    w_load(wq[0], 0);
+    if (KS > 1) w_load(wq[1], 1);
+    x_load(xv[0], 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 2 < KS) w_load(wq[(s + 2) % 3], s + 2);               // weights two steps ahead of their MFMAs (L2 latency)
+      if (s + 1 < KS) x_load(xv[(s + 1) & 1], s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 (&w)[CT] = wq[s % 3];
+      const f32x4 (&x)[PT] = xv[s & 1];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].x, x[pt].x, acc[pt][ct], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].y, x[pt].y, acc[pt][ct], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].z, x[pt].z, acc[pt][ct], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].w, x[pt].w, acc[pt][ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                                // every wave has read x: t takes its place
+    // lane = (pixel slot li of tile pt, channels ch0 + 16 ct + 4 kq .. + 3)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int ch = wave * (CM / 4) + 16 * ct + 4 * kq;             // channel within the block's slice
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + c_first + ch);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int px = 16 * pt + li;
+        const f32x4 v = acc[pt][ct] + bb;
+        if (px < 49)
+          *reinterpret_cast<f32x4*>(lds + tile_off<CM>(px, ch)) = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- stage C: wave w = class w, the block's CM channels (tile channel c <-> V channel c_first + c) ----
+  switch (wave) {
+    case 0: mid_in_class<0, 0, CM, CMID>(a, img, lane, c_first, lds); break;
+    case 1: mid_in_class<0, 1, CM, CMID>(a, img, lane, c_first, lds); break;
+    case 2: mid_in_class<1, 0, CM, CMID>(a, img, lane, c_first, lds); break;
+    default: mid_in_class<1, 1, CM, CMID>(a, img, lane, c_first, lds); break;
+  }
+}
+
+bool wino_mid_supported(int Cin, int Cmid, bool gemm, int phases_in) {
+  if (gemm) return (Cin == 128 && Cmid == 128 && (phases_in == 4 || phases_in == 1)) || (Cin == 256 && Cmid == 256 && phases_in == 1);
+  return Cin == Cmid && (Cin == 128 || Cin == 256) && phases_in == 1;
+}
+
+hipError_t wino_mid_launch(const WinoMidArgs& a, hipStream_t st) {
+  const bool gemm = a.w1 != nullptr;
+  if (!wino_mid_supported(a.Cin, a.Cmid, gemm, a.phases_in) || a.n_img < 1 || !a.M || !a.V || (gemm && !a.b1) ||
+      (a.x && (a.x_cs % 4 || a.x_coff % 4)))
+    return hipErrorInvalidValue;
+#define OFFK_MID_LAUNCH(CI, CM, G, PH, NSP)                                                                        \
+  {                                                                                                                \
+    constexpr int kLds = 64 * (CI > CM / NSP ? CI : CM / NSP) * 4;                                                 \
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_mid_kernel<CI, CM, G, PH, NSP>), kLds);        \
+    if (e != hipSuccess) return e;                                                                                 \
+    hipLaunchKernelGGL((wino_mid_kernel<CI, CM, G, PH, NSP>), dim3(a.n_img, NSP), dim3(256), kLds, st, a);         \
+  }
+  // blocks per image (tools/bench_between.py, P = 384, device time): 128 -> 128: 20.8 us with one block per image, 18.7 with two;
+  // 256 -> 256: 56.8 / 60.1 / 61.3 us with 1 / 2 / 4 (its x tile is 64 KB whatever the split: two blocks per CU either way)
+  const int ns = a.nsplit > 0 ? a.nsplit : (gemm && a.Cin == 128 ? 2 : 1);
+  if (gemm && a.Cin == 128 && a.phases_in == 4) { if (ns == 2) OFFK_MID_LAUNCH(128, 128, true, 4, 2) else OFFK_MID_LAUNCH(128, 128, true, 4, 1) }
+  else if (gemm && a.Cin == 128) { if (ns == 2) OFFK_MID_LAUNCH(128, 128, true, 1, 2) else OFFK_MID_LAUNCH(128, 128, true, 1, 1) }
+  else if (gemm) { if (ns == 4) OFFK_MID_LAUNCH(256, 256, true, 1, 4) else if (ns == 2) OFFK_MID_LAUNCH(256, 256, true, 1, 2) else OFFK_MID_LAUNCH(256, 256, true, 1, 1) }
+  else if (a.Cin == 128) OFFK_MID_LAUNCH(128, 128, false, 1, 1)
+  else OFFK_MID_LAUNCH(256, 256, false, 1, 1)
+#undef OFFK_MID_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace offk

@@ -22,94 +22,11 @@
 // OFFK_WINOGRAD=0 at offk_create keeps the direct kernels.
 #include "offk_common.h"
 #include "offk_internal.h"
+#include "winograd_common.h"
 
 namespace offk {
 
 namespace {
-// 1-D input transform B^T (6 -> 6)
-__device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
-  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-  t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-  t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-  t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-}
-// 1-D output transform A^T (6 -> 4)
-__device__ __forceinline__ void at4(const float (&m)[6], float (&s)[4]) {
-  const float a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
-  s[0] = m[0] + a + c;
-  s[1] = b + 2.f * e;
-  s[2] = a + 4.f * c;
-  s[3] = b + 8.f * e + m[5];
-}
-// 1-D weight transform G (3 -> 6)
-__device__ __forceinline__ void g6(const float (&g)[3], float (&u)[6]) {
-  u[0] = g[0] * 0.25f;
-  u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
-  u[2] = (-g[0] + g[1] - g[2]) * (1.f / 6.f);
-  u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
-  u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
-  u[5] = g[2];
-}
-// generated by tools/gen_winograd_f54.py -- F(3, 3), points 0, 1, -1, 2, infinity
-__device__ __forceinline__ void bt5(const float (&d)[5], float (&t)[5]) {
-  t[0] = fmaf(-2.0f, d[2], 2.0f * d[0] - d[1]) + d[3];
-  t[1] = -2.0f * d[1] - d[2] + d[3];
-  t[2] = fmaf(-3.0f, d[2], 2.0f * d[1]) + d[3];
-  t[3] = -d[1] + d[3];
-  t[4] = fmaf(-2.0f, d[3], 2.0f * d[1] - d[2]) + d[4];
-}
-__device__ __forceinline__ void at3(const float (&m)[5], float (&s)[3]) {
-  s[0] = m[0] + m[1] + m[2] + m[3];
-  s[1] = fmaf(2.0f, m[3], m[1] - m[2]);
-  s[2] = fmaf(4.0f, m[3], m[1] + m[2]) + m[4];
-}
-__device__ __forceinline__ void g5(const float (&g)[3], float (&u)[5]) {
-  u[0] = 0.5f * g[0];
-  u[1] = fmaf(-0.5f, g[2], fmaf(-0.5f, g[1], -0.5f * g[0]));
-  u[2] = fmaf((float)-0.16666666666666666, g[2], fmaf((float)0.16666666666666666, g[1], (float)-0.16666666666666666 * g[0]));
-  u[3] = fmaf((float)0.6666666666666666, g[2], fmaf((float)0.3333333333333333, g[1], (float)0.16666666666666666 * g[0]));
-  u[4] = g[2];
-}
-
-// overloads by point count: N = 6 -> F(4, 3), N = 5 -> F(3, 3)
-__device__ __forceinline__ void wbt(const float (&d)[6], float (&t)[6]) { bt6(d, t); }
-__device__ __forceinline__ void wbt(const float (&d)[5], float (&t)[5]) { bt5(d, t); }
-__device__ __forceinline__ void wat(const float (&m)[6], float (&s)[4]) { at4(m, s); }
-__device__ __forceinline__ void wat(const float (&m)[5], float (&s)[3]) { at3(m, s); }
-__device__ __forceinline__ void wg(const float (&g)[3], float (&u)[6]) { g6(g, u); }
-__device__ __forceinline__ void wg(const float (&g)[3], float (&u)[5]) { g5(g, u); }
-
-// Batch (point) numbering.  NPH = 1: b = {0, 36, 66, 96}[cls] + i * nx + j (121 batches, K = Ci).
-// Polyphase form (NPH = 4): a phase kernel with a == 1 (b == 1) has two taps, its transform is zero at the point "infinity" (the
-// last row / column of the class's point grid).  Those (point, phase) products are skipped: the 81 points with neither index at
-// infinity contract all four phases (K = 4 Ci), the 18 of the last rows only the phases with a == 0, the 18 of the last columns
-// those with b == 0 (K = 2 Ci), the four corners phase 0 alone (K = Ci): 400 instead of 484 phase-points per image.  Points are
-// stored group by group, class-major inside a group; each group with its own K.
-// place(): the group's first float in units of rows * Ci, the point's index inside the group, the group's K in units of Ci and
-// the phase's slot in it; false if the product is identically zero.
-struct WinoPlace { int base_ci, idx, kmul, slot; };
-template <int CY, int CX>
-__device__ __forceinline__ bool wino_place4(int i, int j, int pa, int pb, WinoPlace& o) {
-  constexpr int NY = CY ? 5 : 6, NX = CX ? 5 : 6, cls = 2 * CY + CX;
-  constexpr int offA[4] = {0, 25, 45, 65}, offB[4] = {0, 5, 9, 14}, offC[4] = {0, 5, 10, 14};
-  if (i < NY - 1 && j < NX - 1) { o = WinoPlace{0, offA[cls] + i * (NX - 1) + j, 4, 2 * pa + pb}; return true; }
-  if (i == NY - 1 && j < NX - 1) { o = WinoPlace{324, offB[cls] + j, 2, pb}; return pa == 0; }     // group A holds 81 * 4 row-Ci units
-  if (j == NX - 1 && i < NY - 1) { o = WinoPlace{360, offC[cls] + i, 2, pa}; return pb == 0; }     // + 18 * 2
-  o = WinoPlace{396, cls, 1, 0};                                                                     // + 18 * 2
-  return pa == 0 && pb == 0;
-}
-// index of point (i, j) of class (CY, CX) in the GEMM-output array M [121][rows][Co]
-template <int NPH, int CY, int CX>
-__device__ __forceinline__ constexpr int wino_mindex(int i, int j) {
-  constexpr int NY = CY ? 5 : 6, NX = CX ? 5 : 6, cls = 2 * CY + CX;
-  constexpr int off1[4] = {0, 36, 66, 96}, offA[4] = {0, 25, 45, 65}, offB[4] = {0, 5, 9, 14}, offC[4] = {0, 5, 10, 14};
-  if (NPH == 1) return off1[cls] + i * NX + j;
-  return i < NY - 1 && j < NX - 1 ? offA[cls] + i * (NX - 1) + j
-       : (i == NY - 1 && j < NX - 1 ? 81 + offB[cls] + j : (j == NX - 1 && i < NY - 1 ? 99 + offC[cls] + i : 117 + cls));
-}
-
 // one (class, image, phase) for 64 channels: load the NY x NX window, transform, store
 template <int NPH, int CY, int CX>
 __device__ __forceinline__ void wino_input_tile(const float* __restrict__ xi, int x_cs, int R, int img, int Ci, int pa, int pb,

@@ -282,3 +282,106 @@ def test_single_rank_rccl_smoke():
     assert line["collective_backend"] == "nccl" and line["n_ranks_seen"] == 1 and line["exchange_ok"] is True
     assert "SINGLE-RANK RCCL SMOKE" in line["config"]["workload"] and line["single_rank_rccl_smoke"]["world_size"] == 1
 
+
+
+# ---- round 4: what sits between two Winograd convs (wino_mid.hip) through its C-ABI entry point ----------------------------------
+
+# the 1-D transforms of winograd.hip as matrices: F(4, 3) (points 0, +-1, +-2, inf) and F(3, 3) (points 0, 1, -1, 2, inf)
+_AT = {4: np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64),
+       3: np.array([[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 1]], dtype=np.float64)}
+_BT = {6: np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=np.float64),
+       5: np.array([[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]], dtype=np.float64)}
+
+
+def _mindex(phases, cy, cx, i, j):
+    """Point numbering of winograd.hip (wino_mindex): class (cy, cx) has NY x NX points."""
+    ny, nx, cls = (5 if cy else 6), (5 if cx else 6), 2 * cy + cx
+    if phases == 1:
+        return (0, 36, 66, 96)[cls] + i * nx + j
+    offa, offb, offc = (0, 25, 45, 65), (0, 5, 9, 14), (0, 5, 10, 14)
+    if i < ny - 1 and j < nx - 1:
+        return offa[cls] + i * (nx - 1) + j
+    if i == ny - 1 and j < nx - 1:
+        return 81 + offb[cls] + j
+    if j == nx - 1 and i < ny - 1:
+        return 99 + offc[cls] + i
+    return 117 + cls
+
+
+def _between_reference(M, bias, phases, w1, b1):
+    """fp64 restatement: x = relu(A^T M A + bias) per class -> [n, 7, 7, Cin]; t = relu(x W1^T + b1); V = B^T t B per class."""
+    _pts, n, cin = M.shape
+    x = np.zeros((n, 7, 7, cin))
+    for cy in (0, 1):
+        for cx in (0, 1):
+            ny, nx = (5 if cy else 6), (5 if cx else 6)
+            m = np.stack([np.stack([M[_mindex(phases, cy, cx, i, j)] for j in range(nx)], 0) for i in range(ny)], 0)   # [ny, nx, n, c]
+            y = np.einsum("oi,ijnc,pj->opnc", _AT[3 if cy else 4], m, _AT[3 if cx else 4])
+            oy, ox = (4 if cy else 0), (4 if cx else 0)
+            x[:, oy:oy + y.shape[0], ox:ox + y.shape[1]] = np.transpose(y, (2, 0, 1, 3))
+    x = np.maximum(x + bias, 0.0)
+    t = np.maximum(x @ w1.T + b1, 0.0) if w1 is not None else x
+    cm = t.shape[-1]
+    tp = np.zeros((n, 9, 9, cm))
+    tp[:, 1:8, 1:8] = t                                     # zero padding 1
+    V = np.zeros((121, n, cm))
+    for cy in (0, 1):
+        for cx in (0, 1):
+            ny, nx = (5 if cy else 6), (5 if cx else 6)
+            oy, ox = (4 if cy else 0), (4 if cx else 0)
+            d = tp[:, oy:oy + ny, ox:ox + nx]                # window rows oy - 1 .. (padded index = image index + 1)
+            v = np.einsum("pi,nijc,qj->pqnc", _BT[ny], d, _BT[nx])
+            for i in range(ny):
+                for j in range(nx):
+                    V[_mindex(1, cy, cx, i, j)] = v[i, j]
+    return x, V
+
+
+@pytest.mark.parametrize("cin,phases,gemm", [(128, 4, True), (128, 1, True), (256, 1, True), (128, 1, False), (256, 1, False)])
+@pytest.mark.parametrize("n", [1, 5])
+def test_winograd_between_vs_fp64(rt, cin, phases, gemm, n):
+    """offk_winograd_between (wino_mid.hip: output transform + ReLU [+ 1x1 conv + ReLU] + input transform in one launch) against an
+    fp64 restatement with the transform matrices written out, for the five instantiations the forward uses
+    (RGB_OFF.py:762-767, :775-780, :833-838), including the store of the first conv's activation into a channel slice."""
+    g = np.random.default_rng(1000 * cin + 10 * phases + n)
+    M = g.standard_normal((121, n, cin)).astype(np.float32)
+    bias = (g.standard_normal(cin) * 0.5).astype(np.float32)
+    w1 = (g.standard_normal((cin, cin)) / cin ** 0.5).astype(np.float32) if gemm else None
+    b1 = (g.standard_normal(cin) * 0.1).astype(np.float32) if gemm else None
+    xbuf = torch.full((n, 7, 7, cin + 64), -3.0, device="cuda")
+    V = rt.winograd_between(dev(M), dev(bias), phases, dev(w1) if gemm else None, dev(b1) if gemm else None, x=xbuf, x_coff=32)
+    torch.cuda.synchronize()
+    x_ref, v_ref = _between_reference(M.astype(np.float64), bias.astype(np.float64), phases,
+                                      w1.astype(np.float64) if gemm else None, b1.astype(np.float64) if gemm else None)
+    ex = rel_err(xbuf[..., 32:32 + cin], x_ref)
+    ev = rel_err(V, v_ref)
+    print("winograd between Cin %d phases %d gemm %d n %d: x %.2e V %.2e" % (cin, phases, gemm, n, ex, ev))
+    assert ex < 1e-5 and ev < 2e-5
+    assert torch.all(xbuf[..., :32] == -3.0) and torch.all(xbuf[..., 32 + cin:] == -3.0)
+    V2 = rt.winograd_between(dev(M), dev(bias), phases, dev(w1) if gemm else None, dev(b1) if gemm else None)     # no x store
+    assert torch.equal(V, V2)
+
+
+def test_winograd_between_off_matches_on(rt, monkeypatch):
+    """OFFK_WINO_MID=0 at offk_create keeps the three-launch form: same transforms, the generic 1x1 kernel in between.  Logits agree
+    to fp32 summation-order noise, every stage tensor against the oracle in both forms."""
+    B, L = 12, 7
+    feats_np = synth.make_features(B, L, 2)
+    feats = [dev(f) for f in feats_np]
+    h1, w = make_handle(rt, B, L, spec.VARIANT_RGB)
+    names = launches_of(h1, feats)
+    assert sum("[winograd: between]" in n for n in names) == 3, names
+    monkeypatch.setenv("OFFK_WINO_MID", "0")
+    h0, _ = make_handle(rt, B, L, spec.VARIANT_RGB)
+    monkeypatch.delenv("OFFK_WINO_MID")
+    assert not any("[winograd: between]" in n for n in launches_of(h0, feats))
+    a, b = h1.forward(feats), h0.forward(feats)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert rel_err(x, y.cpu()) < 5e-6
+    with torch.no_grad():
+        _want, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, spec.VARIANT_RGB, orc.SLICE_FLAT, return_stages=True)
+    for h in (h1, h0):
+        errs = stage_errs(h, st, B * (L - 1))
+        assert max(errs.values()) < RTOL, errs

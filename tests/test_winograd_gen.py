@@ -38,7 +38,7 @@ def test_cook_toom_is_a_correlation(m, r, pts):
     assert np.abs(G[0, 1:]).max() == 0 and np.abs(G[n - 1, :r - 1]).max() == 0      # what the zero-skipping of the polyphase forms uses
 
 
-@pytest.mark.parametrize("which,src", [(None, "winograd7.hip"), ("f33", "winograd.hip")])
+@pytest.mark.parametrize("which,src", [(None, "winograd7.hip"), ("f33", "winograd_common.h")])
 def test_generated_transforms_in_tree(which, src):
     g = _gen()
     buf = io.StringIO()
@@ -75,6 +75,6 @@ def test_hand_written_f43_matches_cook_toom():
         d, k = rng.standard_normal(6), rng.standard_normal(3)
         want = np.array([sum(k[u] * d[o + u] for u in range(3)) for o in range(4)])
         assert np.allclose(at4(g6(k) * bt6(d)), want, atol=1e-11)          # the hand-written set is a correlation too
-    text = open(os.path.join(CSRC, "winograd.hip")).read()
+    text = open(os.path.join(CSRC, "winograd_common.h")).read()
     for frag in ("t[0] = 4.f * d[0] - 5.f * d[2] + d[4];", "s[3] = b + 8.f * e + m[5];", "u[5] = g[2];"):
         assert frag in text
