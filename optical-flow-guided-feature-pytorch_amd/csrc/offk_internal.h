@@ -154,6 +154,9 @@ struct PtSite {
   int chunks;           // pixel chunks of 32 per clip (packed: floor, else ceil)
   int nrem;             // leftover blocks per temporal group (0: none)
   int rsh;              // log2(leftover pixels per clip) in a packed leftover block; 5: one clip per block
+  int qpc;              // 16-pixel form, > 0: "quad stream" -- the site's blocks take four consecutive pixel quads each from the
+                        // sequence (clip, quad) with qpc = ceil(HW / 4) quads per clip (7x7: 13, the last one holding one pixel):
+                        // 49 of 52 lanes of work instead of 49 of 64 with four 16-pixel chunks per clip
   int blk_begin;
 };
 struct PtParams {

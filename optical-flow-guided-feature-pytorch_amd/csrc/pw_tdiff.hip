@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, 4) void pw_tdiff16_kernel(PtParams p) {
   PtSite S;
   S.bias = S0.bias; S.D = S0.D; S.M = S0.M; S.m_cs = S0.m_cs; S.bias_down = S0.bias_down; S.wt = S0.wt16;
   S.m_coff = S0.m_coff; S.C = S0.C; S.HW = S0.HW; S.chunks = S0.chunks; S.nrem = S0.nrem; S.rsh = S0.rsh;
-  S.blk_begin = S0.blk_begin; S.nparts = S0.nparts;
+  S.blk_begin = S0.blk_begin; S.nparts = S0.nparts; S.qpc = S0.qpc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { S.xp[q] = S0.xp[q]; S.cp[q] = S0.cp[q]; }
   const int nblk_site = (si + 1 < p.nsites ? p.s[si + 1].blk_begin : p.total_blocks) - S.blk_begin;
@@ -540,7 +540,11 @@ __global__ __launch_bounds__(256, 4) void pw_tdiff16_kernel(PtParams p) {
   const int nfull = p.B * S.chunks;
   const bool leftover = local >= nfull;
   const int rsh = leftover ? S.rsh : 4, rmask = (1 << rsh) - 1;
-  const int b = leftover ? (local - nfull) << (4 - rsh) : local / S.chunks;
+  // quad stream (S.qpc > 0, every block is a "leftover" block): quads 4 local .. + 3 of the sequence (clip, quad in clip); four
+  // consecutive quads cross at most one clip boundary (qpc >= 4): quad pq is quad qr0 + pq of clip b, or that minus qpc of clip b + 1
+  const int qpc = S.qpc;
+  const int b = qpc ? (4 * local) / qpc : leftover ? (local - nfull) << (4 - rsh) : local / S.chunks;
+  const int qr0 = qpc ? 4 * local - b * qpc : 0;
   const int q0 = (leftover ? S.chunks : local - b * S.chunks) * 16;
   const int t0 = tg * (PT_FT - 1);
   const int nf = min(PT_FT, L - t0);
@@ -553,8 +557,9 @@ __global__ __launch_bounds__(256, 4) void pw_tdiff16_kernel(PtParams p) {
   //      slots 14, 15 (waves 2, 3, i = 3) go to the dummy KB.  q & 1 == wave & 1 for every i: ONE per-lane offset register serves
   //      the four slots, the frame rides on the scalar offset (round 3 kept four 64-bit offset pairs: eight registers) ----
   const int pq = lane & 3;
-  const int cq = (4 * pq) >> rsh;                                  // clip of the quad within the block (0 unless packed)
-  const int k0px = q0 + ((4 * pq) & rmask);
+  const bool qnext = qpc && qr0 + pq >= qpc;
+  const int cq = qpc ? (int)qnext : (4 * pq) >> rsh;               // clip of the quad within the block (0 unless packed)
+  const int k0px = qpc ? 4 * (qr0 + pq - (qnext ? qpc : 0)) : q0 + ((4 * pq) & rmask);
   const bool px_ok = k0px < HW && b + cq < p.B;
   // byte offset of (k row, pixel quad) inside a frame's K-tile; bit 31 (= past every descriptor) where the quad lies outside
   const int vrow0 = px_ok ? ((16 * (wave & 1) + (lane >> 2)) * HW + k0px) * 4 : (int)0x80000000;
@@ -722,7 +727,9 @@ __global__ __launch_bounds__(256, 4) void pw_tdiff16_kernel(PtParams p) {
   // (li / kq are re-derived from the execution mask here: kept from the prologue they are two more registers live across the K loop)
   const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int li_e = lane_e & 15, kq_e = lane_e >> 4;
-  const int bl = b + (li_e >> rsh), pixl = q0 + (li_e & rmask);
+  const int qe = qr0 + (li_e >> 2);                                 // quad stream: the lane's quad, counted from clip b's first
+  const bool qn_e = qpc && qe >= qpc;
+  const int bl = qpc ? b + (int)qn_e : b + (li_e >> rsh), pixl = qpc ? 4 * (qe - (qn_e ? qpc : 0)) + (li_e & 3) : q0 + (li_e & rmask);
   const size_t pair0 = (size_t)bl * (L - 1) + t0;
   const bool pix_ok = pixl < HW && bl < p.B;
 #pragma unroll
@@ -814,6 +821,12 @@ hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float*
 hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   PtParams p = p_in;
   if (p.nsites <= 0 || p.B <= 0) return hipSuccess;
+  // (Sites in descending order of C -- longest blocks first, so that the launch does not drain on the 32-tile blocks of the two 7x7
+  //  sites -- measured no different from the network order: 1.270 / 1.270 ms, profiles/r04/ab_k1t_quad_stream.txt.)
+  bool qstream = true;
+#ifdef OFFK_TUNING_KNOBS
+  { const char* se = getenv("OFFK_PW_STREAM"); if (se && *se == '0') qstream = false; }
+#endif
 #ifdef OFFK_PT_TIMING
   {
     static unsigned long long* dbg = nullptr;
@@ -870,9 +883,13 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
         PtSite& o = p.s[i];
         const int rem = o.HW % 16;
         const bool packed = rem == 4 || rem == 8;        // 14x14: four clips' four leftover pixels per block
-        o.chunks = packed ? o.HW / 16 : (o.HW + 15) / 16;
+        const int qpc = (o.HW + 3) / 4;
+        // 7x7: 49 = 3 x 16 + 1 -- a fourth chunk per clip would multiply one pixel; as a stream of quads 64 clips are 208 blocks, not 256
+        const bool stream = qstream && !packed && rem != 0 && qpc >= 4 && (long long)p.B * qpc < (1 << 22);
+        o.qpc = stream ? qpc : 0;
+        o.chunks = stream ? 0 : packed ? o.HW / 16 : (o.HW + 15) / 16;
         o.rsh = packed ? (rem == 4 ? 2 : 3) : 4;
-        o.nrem = packed ? (p.B + (16 >> o.rsh) - 1) / (16 >> o.rsh) : 0;
+        o.nrem = stream ? (p.B * qpc + 3) / 4 : packed ? (p.B + (16 >> o.rsh) - 1) / (16 >> o.rsh) : 0;
         o.blk_begin = blk;
         blk += (p.B * o.chunks + o.nrem) * p.tgroups;
       }
@@ -889,6 +906,7 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
       o.chunks = packed ? o.HW / 32 : (o.HW + 31) / 32;
       o.rsh = packed ? (rem == 4 ? 2 : rem == 8 ? 3 : 4) : 5;
       o.nrem = packed ? (p.B + (32 >> o.rsh) - 1) / (32 >> o.rsh) : 0;
+      o.qpc = 0;
       o.blk_begin = blk;
       blk += (p.B * o.chunks + o.nrem) * p.tgroups;
     }

@@ -13,7 +13,7 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 
 name, defs = sys.argv[1], sys.argv[2:]
-out_dir = os.path.join(ROOT, "tools", "_bin")
+out_dir = os.path.join(ROOT, "tools", os.environ.get("OFFK_VARIANT_DIR", "_bin"))
 obj_dir = os.path.join(out_dir, name + "_obj")
 os.makedirs(obj_dir, exist_ok=True)
 
