@@ -64,8 +64,9 @@ __device__ __forceinline__ void wino_input_tile(const float* __restrict__ xi, in
         *reinterpret_cast<float*>(reinterpret_cast<char*>(V + ((size_t)wino_mindex<1, CY, CX>(i, j) * R + img) * K) + c4) = v[j];
       } else {
         WinoPlace pl;
-        if (wino_place4<CY, CX>(i, j, pa, pb, pl))
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(V + ((size_t)pl.base_ci * R + ((size_t)pl.idx * R + img) * pl.kmul + pl.slot) * Ci) + c4) = v[j];
+        if (wino_place4<CY, CX>(i, j, pa, pb, pl))     // V of the polyphase conv (0.63 GB at P = 384) is written once and read once, by
+                                                       // the GEMMs: non-temporal (the 7x7-map convs' V fits the caches and stays temporal)
+          __builtin_nontemporal_store(v[j], reinterpret_cast<float*>(reinterpret_cast<char*>(V + ((size_t)pl.base_ci * R + ((size_t)pl.idx * R + img) * pl.kmul + pl.slot) * Ci) + c4));
       }
     }
   }
