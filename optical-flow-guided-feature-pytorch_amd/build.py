@@ -101,8 +101,8 @@ def check_isa(obj, code_objects):
 ASM_SCHEDULED_KERNELS = (
     ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 128, True, "four blocks per CU (4 waves / SIMD x 128 = 512; 4 x 29 KB of LDS)"),
     ("chain_fused.hip", r"^void offk::chain14_kernel<", 168, False, "three blocks per CU (52.5 KB of LDS each)"),
-    ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 96, False,
-     "the default 64x64 tile: five blocks per CU (32 KB of LDS each, 5 waves / SIMD x 96 <= 512)"),
+    ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 128, False,
+     "the default 64x64 tile: four blocks per CU (32 KB of LDS each -- 32768 B is 26 granules of 1280 B, five do not fit; 4 waves / SIMD x 128 = 512)"),
     ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<.*, 4>\(", 512, True, "the other LDS-DMA tiles (set_conv_plan / tools only)"),
 )
 

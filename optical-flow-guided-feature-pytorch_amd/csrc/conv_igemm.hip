@@ -88,6 +88,10 @@ template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 // (the 128x128 tile compiled to 131 and ran one block per CU)
 __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr bool F32 = !(PREC & 1), LEAN = PREC >= 2;      // PREC 3: the bf16x3 core with the same buffer-addressed loader
+#ifdef OFFK_CONV_TIMING
+  const unsigned long long tm_t0 = __builtin_readcyclecounter();
+  unsigned long long tm_t1 = 0, tm_t2 = 0, tm_ta = 0;
+#endif
   if (p.ngroups > 0) {          // grouped batch: this block's group and its problem inside the group (static indices: scalar code)
     int b = blockIdx.y, ci = p.g_Ci[0], first = 0;
     long long gx = p.g_x[0], gw = p.g_w[0], gy = p.g_y[0];
@@ -136,10 +140,15 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
 
   int hi0[NRA], wi0[NRA];
   int pix0[NRA];      // image * H * W (fits: M and the feature maps are < 2^31 elements)
+  // 1x1 / stride 1 / no padding (every 1x1 conv of the network and the batched Winograd GEMMs): the input pixel of output row m IS m --
+  // no (image, row, column) split, i.e. none of the four integer divisions per thread below (round 4: the set-up of a block was
+  // 6-9 k cycles of its ~140 k, and co-resident blocks run in step, so nobody multiplies meanwhile; tools/conv_dma_timing.py)
+  const bool flat = TAPS == 1 && S == 1 && p.pad == 0 && LEAN;
 #pragma unroll
   for (int r = 0; r < NRA; ++r) {
     int m = m0 + (tid >> RSH) + RSTEP * r;
     bool ok = m < p.M;
+    if (flat) { hi0[r] = ok ? 0 : -100000; wi0[r] = 0; pix0[r] = ok ? m : 0; continue; }
     int mm = ok ? m : 0;
     int img = mm / (p.Ho * p.Wo);
     int rem = mm - img * (p.Ho * p.Wo);
@@ -167,7 +176,8 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 #pragma unroll
     for (int r = 0; r < NRA; ++r) {    // hi0 + pad = ho * S, wi0 + pad = wo * S
-      rowoff[r] = hi0[r] < -50000 ? 0 : ((pix0[r] + (hi0[r] + p.pad) * p.W + (wi0[r] + p.pad)) * p.x_cs + kpos) * 4;   // rows past M: never valid
+      rowoff[r] = hi0[r] < -50000 ? 0 : flat ? (pix0[r] * p.x_cs + kpos) * 4
+                                             : ((pix0[r] + (hi0[r] + p.pad) * p.W + (wi0[r] + p.pad)) * p.x_cs + kpos) * 4;   // rows past M: never valid
       // tap validity, separable: bit kh = input row hi0 + kh outside the image, bit 16 + kw = input column outside.
       // Per K-tile the test is then two shifts and an and-or (the fp32 MFMA shares its lanes with the VALU: every
       // vector instruction in this loop is matrix time), against two adds, two compares and a select.
@@ -176,6 +186,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       for (int kh = 0; kh < KH; ++kh) m |= (unsigned)(hi0[r] + kh) >= (unsigned)p.H ? 1u << kh : 0u;
 #pragma unroll
       for (int kw = 0; kw < KW; ++kw) m |= (unsigned)(wi0[r] + kw) >= (unsigned)p.W ? 0x10000u << kw : 0u;
+      if (flat) m = hi0[r] < -50000 ? 1u : 0u;
       inv[r] = m;
       if constexpr (TAPS == 1) rowoff[r] = m ? (int)0x80000000 : rowoff[r];
     }
@@ -410,10 +421,16 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     // s_waitcnt vmcnt(n): all but this thread's newest n DMA loads have landed (gfx9 encoding: vmcnt = bits 3:0 and 15:14)
     constexpr int NL = NRA + NRB;
     constexpr int kWaitTile = DST == 3 ? (0x0F70 | (NL & 15) | ((NL >> 4) << 14)) : 0x0F70;
+#ifdef OFFK_CONV_TIMING
+    tm_ta = __builtin_readcyclecounter();
+#endif
     dma_tile(kt_begin, 0);
     if constexpr (DST == 3) dma_tile(min(kt_begin + 1, kt_end - 1), 1);
     __builtin_amdgcn_s_waitcnt(kWaitTile);   // the first tile is in LDS
     __syncthreads();
+#ifdef OFFK_CONV_TIMING
+    tm_t1 = __builtin_readcyclecounter();
+#endif
     // one K-tile: the load unit fills the stage every wave left at the last barrier with tile kt + DST - 1 while the MFMAs
     // read stage st (a literal: the loop is unrolled by DST)
     auto step = [&](int kt, const int st) {
@@ -445,6 +462,13 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       if (kt < kt_end) step(kt, 0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // nothing of this block may still be landing when its LDS is handed on
+    // (Round 4 tried to hide the next block's first-tile latency -- co-resident blocks run in step, so nobody multiplies while they
+    //  wait ~10 k cycles for their first tiles: a block touched the first K-tiles of the block 1024 positions later in launch order,
+    //  the next occupant of its slot on the same XCD, before its epilogue.  Every launch got SLOWER, 1-20 %: the loads keep the wave
+    //  alive until they return.  profiles/r04/conv_block_cycle_split.txt)
+#ifdef OFFK_CONV_TIMING
+    tm_t2 = __builtin_readcyclecounter();
+#endif
   } else if constexpr (F32) {
     load_tile(rg0, okm0, kt_begin);
     store_tile(rg0, okm0, 0);
@@ -563,6 +587,35 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   }
   // epilogue: y = post( pre(acc + bias) + res )
   const bool relu_pre = p.flags & OFFK_CONV_RELU_PRE_, relu_post = p.flags & OFFK_CONV_RELU_POST_;
+  // No residual, no pooled sums and y well below 2^31 bytes (the batched Winograd GEMMs, conv1 of a bottleneck): stores through a buffer
+  // descriptor that ends behind row M - 1 -- a row past M falls outside and is dropped by the hardware: ONE per-lane offset per
+  // accumulator tile plus a scalar per register, no compare / exec mask / 64-bit address per store (the pointer form spent ~11 k cycles
+  // issuing a block's 16 stores per wave, with every co-resident block in its epilogue at the same time: tools/conv_dma_timing.py)
+  const unsigned long long ybytes = ((unsigned long long)(p.M > 0 ? p.M - 1 : 0) * p.y_cs + p.y_coff + p.co_limit) * 4ull;
+  const bool fast_store = LEAN && F32 && !p.res && !p.pool_part && p.M > 0 && ybytes < 0x7f000000ull;
+  if (fast_store) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
+    const int ycs4 = p.y_cs * 4;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int co = n0 + wn * 32 * TN + tn * 32 + r32;
+      const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int mb = m0 + wm * 32 * TM + tm * 32;                      // (scalar) first row of the tile
+        // (the row goes into the per-lane offset, not the scalar one: only the former is compared with the descriptor's size.  Staging the
+        //  tile through LDS to leave in four 16-byte stores per lane instead of sixteen dwords measured no better: 6.8 k vs 7.9 k cycles to
+        //  the last store's issue, most of which is the SIMD's queue of MFMAs draining -- profiles/r04/conv_block_cycle_split.txt)
+        const int voff = co < p.co_limit ? (4 * h * p.y_cs + p.y_coff + co) * 4 : (int)0x80000000;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          float v = acc.acc[tm][tn][reg] + bv;
+          if (relu_pre || relu_post) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, voff + (mb + (reg & 3) + 8 * (reg >> 2)) * ycs4, 0, 0);
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int co = n0 + wn * 32 * TN + tn * 32 + r32;
@@ -622,6 +675,19 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       }
     }
   }
+  }
+#ifdef OFFK_CONV_TIMING
+  if constexpr (DMA) {      // LDS-DMA form, wave 0 of every block: prologue (entry -> first tile in LDS), K loop, epilogue (incl. its stores' drain)
+    const unsigned long long tm_te = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.dbg && threadIdx.x == 0) {
+      const unsigned long long tm_t3 = __builtin_readcyclecounter();
+      atomicAdd(p.dbg + 8, tm_t1 - tm_t0); atomicAdd(p.dbg + 9, tm_t2 - tm_t1); atomicAdd(p.dbg + 10, tm_t3 - tm_t2);
+      atomicAdd(p.dbg + 13, tm_ta - tm_t0); atomicAdd(p.dbg + 14, tm_te - tm_t2);
+      atomicAdd(p.dbg + 11, 1ull); atomicAdd(p.dbg + 12, (unsigned long long)(kt_end - kt_begin));
+    }
+  }
+#endif
 }
 
 // sum of the split-K slabs in split order, then the conv epilogue; 4 channels per thread
@@ -1378,13 +1444,17 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
 #ifdef OFFK_CONV_TIMING
   {
     static unsigned long long* dbg = nullptr;
-    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64); (void)hipMemset(dbg, 0, 64); }
+    if (!dbg) { (void)hipMalloc(reinterpret_cast<void**>(&dbg), 128); (void)hipMemset(dbg, 0, 128); }
     a.dbg = dbg;
     if (getenv("OFFK_CONV_TIMING_DUMP")) {
-      unsigned long long h[8];
-      (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+      unsigned long long h[16];
+      (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
       fprintf(stderr, "[conv timing] consumer mma %llu barrier %llu ktiles %llu | producer store %llu load-issue %llu barrier %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-      (void)hipMemset(dbg, 0, 64);
+      if (h[11])
+        fprintf(stderr, "[conv timing, LDS-DMA form, wave 0, cycles per block] prologue %.0f (setup %.0f, first tile %.0f)  K loop %.0f (%.1f K-tiles: %.0f per tile)  epilogue %.0f (to the last store's issue %.0f, drain %.0f) | blocks %llu\n",
+                (double)h[8] / h[11], (double)h[13] / h[11], (double)(h[8] - h[13]) / h[11], (double)h[9] / h[11], (double)h[12] / h[11], (double)h[9] / (double)h[12],
+                (double)h[10] / h[11], (double)h[14] / h[11], (double)(h[10] - h[14]) / h[11], h[11]);
+      (void)hipMemset(dbg, 0, 128);
     }
   }
 #endif

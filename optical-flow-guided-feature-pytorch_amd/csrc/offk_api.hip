@@ -1103,6 +1103,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
     d.y = M; d.y_cs = Co; d.y_coff = 0;
     d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+#ifdef OFFK_TUNING_KNOBS
+    { const char* e = getenv("OFFK_WINO_CFG"); if (e && (Co % 128 == 0 || atoi(e) == 1 || atoi(e) == 2)) d.tile_cfg = atoi(e); }     // tools: one tile for every Winograd GEMM launch
+#endif
     d.batch = npoints; d.x_bstride = (long long)rows * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)rows * Co;
     if (ngrp > 1) {
       d.ngroups = ngrp;
