@@ -125,7 +125,9 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   constexpr int TAPS = KH * KW;
   const int K = TAPS * p.Ci;
   const int nkt_all = TAPS * (p.Ci / BK);
-  const int kt_begin = (int)((long long)nkt_all * zs / p.splitk), kt_end = (int)((long long)nkt_all * (zs + 1) / p.splitk);
+  // (unsplit: no 64-bit divisions in the block's set-up -- the set-up runs with every co-resident block in it at the same time)
+  const int kt_begin = p.splitk == 1 ? 0 : (int)((long long)nkt_all * zs / p.splitk);
+  const int kt_end = p.splitk == 1 ? nkt_all : (int)((long long)nkt_all * (zs + 1) / p.splitk);
 
   // Loader mapping (both precisions): thread = (row (tid>>3) + 32*r, 16-B chunk tid&7), so every load
   // instruction of a wave reads eight whole 128-B lines (the texture-address path works per line; an
@@ -425,8 +427,13 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
     tm_ta = __builtin_readcyclecounter();
 #endif
     dma_tile(kt_begin, 0);
-    if constexpr (DST == 3) dma_tile(min(kt_begin + 1, kt_end - 1), 1);
-    __builtin_amdgcn_s_waitcnt(kWaitTile);   // the first tile is in LDS
+    // Two stages: the SECOND tile goes out here as well (both stages are free), not from inside the first step -- the blocks of a CU start
+    // together, so the first step's MFMAs (4 x 1024 cycles per SIMD) do not cover a cold tile's ~10 k cycles; in flight beside the first
+    // tile it costs no latency of its own.  The first step then issues nothing (peeled below).
+    constexpr bool PEEL = DST == 2;
+    if constexpr (DST == 3 || PEEL) dma_tile(min(kt_begin + 1, kt_end - 1), 1);
+    constexpr int kWaitFirst = (DST == 3 || PEEL) ? (0x0F70 | (NL & 15) | ((NL >> 4) << 14)) : 0x0F70;
+    __builtin_amdgcn_s_waitcnt(kWaitFirst);   // the first tile is in LDS (all but this thread's newest NL loads have landed)
     __syncthreads();
 #ifdef OFFK_CONV_TIMING
     tm_t1 = __builtin_readcyclecounter();
@@ -455,11 +462,16 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       if (kt < kt_end) step(kt, 0);
       if (kt + 1 < kt_end) step(kt + 1, 1);
     } else {
+      // peeled first step: tile kt_begin + 1 is already on its way into stage 1
+      mma(0, -1);
+      __builtin_amdgcn_s_waitcnt(kWaitTile);
+      __syncthreads();
+      ++kt;
       for (; kt + 1 < kt_end; kt += 2) {
-        step(kt, 0);
-        step(kt + 1, 1);
+        step(kt, 1);
+        step(kt + 1, 0);
       }
-      if (kt < kt_end) step(kt, 0);
+      if (kt < kt_end) step(kt, 1);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // nothing of this block may still be landing when its LDS is handed on
     // (Round 4 tried to hide the next block's first-tile latency -- co-resident blocks run in step, so nobody multiplies while they
