@@ -16,14 +16,12 @@
  *  - the caller owns every data buffer (device pointers, e.g. torch tensor.data_ptr());
  *    the library owns the handle and its packed weight copies only.
  *  - all work is enqueued asynchronously on the hipStream_t passed as `void* stream`
- *    (NULL = default stream); there is no implicit synchronisation.  With OFFK_SIDE_STREAM=1 in the
- *    environment at offk_create, offk_forward forks its two side heads onto a stream the handle owns
- *    (event fork / event join, both inside the call): seen from the caller everything is still ordered
- *    on `stream`, and the call can be stream-captured.  Default: everything on `stream`.
+ *    (NULL = default stream); there is no implicit synchronisation and no other stream: every launch of a call goes to
+ *    `stream` in order, so the call can be stream-captured (ABI v8: the handle-owned side stream of v5 - v7 is gone).
  *  - offk_forward runs the units as ONE kernel that fuses the 1x1 reduces with the temporal difference (the gen output G
  *    never goes to HBM) plus the spatial half of K2; OFFK_FUSED_UNITS=0 in the environment at offk_create selects the
  *    two-kernel form (K1 then K2), which offk_off_units / offk_off_units_train always use (the backward needs G).  Both
- *    give the same bits (to 2e-6 in fp32, whose default fused kernel groups k differently: OFFK_PW_DMA).
+ *    give the same values (to 2e-6 in fp32: the fused kernel sums k in another grouping).
  *  - a handle is not thread-safe; distinct handles are independent.
  *  - fp32 everywhere.  Boundary tensors are NCHW contiguous exactly as the reference
  *    backbone produces them; INTERNAL activations (workspace, stage entry points) are
@@ -160,7 +158,7 @@ int offk_set_profiling(offk_handle* h, int enable);   /* 0 off, 1 per-stage even
 int offk_stage_times(offk_handle* h, double ms[OFFK_NUM_STAGES], int64_t calls[OFFK_NUM_STAGES], int reset);
 /* Per-launch trace (offk_set_profiling(h, 2)): offk_forward records one HIP event on the caller's stream in front of every
  * launch group -- the units kernels, each fusion conv by its state_dict name (a split-K conv includes its reduction), each
- * head, the consensus -- with the side-stream heads folded back in line.  Returns the number of distinct groups seen since
+ * head, the consensus.  Returns the number of distinct groups seen since
  * the last reset; the first min(n, max_entries) are written: names as one '\n'-separated string into `names`, accumulated
  * milliseconds and call counts into `ms` / `calls`.  An event between two short kernels costs a few microseconds of
  * command-processor time: use rocprofv3's kernel trace for absolute times of the small launches. */
