@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "liboffk.so")
 SOURCES = ("offk_api.hip", "pw_reduce.hip", "sobel_tdiff.hip", "conv_igemm.hip", "heads.hip", "units_bwd.hip", "pw_tdiff.hip",
-           "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "winograd7_fused.hip")
+           "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "winograd7_fused.hip")
 HEADERS = ("offk_common.h", "offk_internal.h", "winograd_common.h", os.path.join("..", "..", "include", "offk.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
@@ -101,6 +101,7 @@ def check_isa(obj, code_objects):
 ASM_SCHEDULED_KERNELS = (
     ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 128, True, "four blocks per CU (4 waves / SIMD x 128 = 512; 4 x 29 KB of LDS)"),
     ("chain_fused.hip", r"^void offk::chain14_kernel<", 168, False, "three blocks per CU (52.5 KB of LDS each)"),
+    ("wino_gemm.hip", r"^offk::wino_gemm_kernel\(", 128, True, "four blocks per CU (32 KB of LDS each); counts its epilogue's sixteen stores (vmcnt(16))"),
     ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 128, False,
      "the default 64x64 tile: four blocks per CU (32 KB of LDS each -- 32768 B is 26 granules of 1280 B, five do not fit; 4 waves / SIMD x 128 = 512)"),
     ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<.*, 4>\(", 512, True, "the other LDS-DMA tiles (set_conv_plan / tools only)"),

@@ -15,6 +15,47 @@
 
 using namespace offk;
 
+// The batched GEMMs of a conv on a Winograd path (M[point] = V[point] . U[point]^T): one persistent launch of wino_gemm_kernel
+// (wino_gemm.hip), or -- persistent == false, OFFK_WINO_GEMM=0 -- gridDim.y problems of the generic 1x1 kernel (conv_igemm.hip, 64 x 64
+// LDS-DMA tile).  Bit-identical.  grp / ngrp: winograd.hip's wino_groups / winograd7.hip's wino7_groups; rows = rows of every V[point].
+static hipError_t wino_gemms_launch(const WinoGroup* grp, int ngrp, int npoints, int rows, int Ci, int Co, const float* V, const float* U,
+                                    float* M, bool persistent, hipStream_t s, const char** why) {
+  if (persistent) {
+    WinoGemmArgs a{};
+    a.x = V; a.w = U; a.y = M; a.M = rows; a.Co = Co; a.ngroups = ngrp;
+    for (int gi = 0; gi < ngrp; ++gi) {
+      a.g_batch[gi] = grp[gi].batch; a.g_K[gi] = grp[gi].kmul * Ci;
+      a.g_x[gi] = grp[gi].v_off; a.g_w[gi] = grp[gi].u_off; a.g_y[gi] = grp[gi].m_off;
+    }
+    hipError_t e = wino_gemm_launch(a, s);
+    if (e != hipErrorInvalidValue) return e;      // a shape the persistent kernel does not take: the generic one
+  }
+  const int K0 = grp[0].kmul * Ci;
+  ConvDesc d;
+  d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = rows; d.H = 1; d.W = 1; d.Ci = K0;
+  d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+  d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
+  d.y = M; d.y_cs = Co; d.y_coff = 0;
+  d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
+#ifdef OFFK_TUNING_KNOBS
+  { const char* e = getenv("OFFK_WINO_CFG"); if (e && (Co % 128 == 0 || atoi(e) == 1 || atoi(e) == 2)) d.tile_cfg = atoi(e); }     // tools: one tile for every Winograd GEMM launch
+#endif
+  d.batch = npoints; d.x_bstride = (long long)rows * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)rows * Co;
+  if (ngrp > 1) {
+    d.ngroups = ngrp;
+    for (int gi = 0; gi < ngrp; ++gi) {
+      d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
+      d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
+    }
+  }
+  return conv2d_launch(d, s, why);
+}
+// stage entry points have no handle: OFFK_WINO_GEMM is read once per process for them (offk_create reads it per handle)
+static bool wino_gemm_stage_default() {
+  static const bool on = [] { const char* e = getenv("OFFK_WINO_GEMM"); return !(e && *e == '0'); }();
+  return on;
+}
+
 namespace {
 
 struct SiteSpec { const char* name; int C, H; };
@@ -151,6 +192,7 @@ struct offk_handle {
   bool wino_dirty = true;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
+  bool wino_gemm = true;         // the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); false: the generic 1x1 kernel
   bool wino_mid = true;          // fp32 + Winograd: output transform + 1x1 conv + input transform between two Winograd convs in one launch
                                  // (wino_mid.hip); OFFK_WINO_MID=0 at offk_create: three launches
   bool chain = true;             // fp32: one launch per bottleneck chain of fusion@28 (chain_fused.hip); OFFK_CHAIN=0 at offk_create: three convs
@@ -737,6 +779,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINO_MID"); h->wino_mid = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_WINO_GEMM"); h->wino_gemm = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINOGRAD"); h->winograd = !(e && *e == '0') && cfg->precision == OFFK_PRECISION_FP32; }
   { const char* e = getenv("OFFK_WINOGRAD_5X5"); h->wino_5x5 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino5_min_p = atoi(e); }
   { const char* e = getenv("OFFK_WINOGRAD_7X7"); h->wino_7x7 = !(e && *e == '0'); if (e && atoi(e) > 1) h->wino7_min_p = atoi(e); }
@@ -1096,26 +1139,8 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   // left the short groups alone on the chip: slower than not skipping their zero products)
   auto wino_gemms = [&](const char* key, const WinoGroup* grp, int ngrp, int npoints, int rows, int Ci, int Co, const float* V,
                         const float* U, float* M) -> int {
-    const int K0 = grp[0].kmul * Ci;
-    ConvDesc d;
-    d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = rows; d.H = 1; d.W = 1; d.Ci = K0;
-    d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-    d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-    d.y = M; d.y_cs = Co; d.y_coff = 0;
-    d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
-#ifdef OFFK_TUNING_KNOBS
-    { const char* e = getenv("OFFK_WINO_CFG"); if (e && (Co % 128 == 0 || atoi(e) == 1 || atoi(e) == 2)) d.tile_cfg = atoi(e); }     // tools: one tile for every Winograd GEMM launch
-#endif
-    d.batch = npoints; d.x_bstride = (long long)rows * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)rows * Co;
-    if (ngrp > 1) {
-      d.ngroups = ngrp;
-      for (int gi = 0; gi < ngrp; ++gi) {
-        d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
-        d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
-      }
-    }
     const char* why = nullptr;
-    hipError_t e = conv2d_launch(d, s, &why);
+    hipError_t e = wino_gemms_launch(grp, ngrp, npoints, rows, Ci, Co, V, U, M, h->wino_gemm, s, &why);
     if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
     return OFFK_OK;
   };
@@ -1518,23 +1543,8 @@ int winograd_entry(const char* who, void* stream, const float* x, int x_cstride,
   WinoGroup grp[4];
   const int ngrp = wino_groups(phases, (long long)T, Ci, Co, grp);
   {
-    const int K0 = grp[0].kmul * Ci;
-    ConvDesc d;
-    d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = K0;
-    d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-    d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-    d.y = M; d.y_cs = Co; d.y_coff = 0;
-    d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
-    d.batch = kWinoPoints; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)T * Co;
-    if (ngrp > 1) {
-      d.ngroups = ngrp;
-      for (int gi = 0; gi < ngrp; ++gi) {
-        d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
-        d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
-      }
-    }
     const char* why = nullptr;
-    e = conv2d_launch(d, st, &why);
+    e = wino_gemms_launch(grp, ngrp, kWinoPoints, (int)T, Ci, Co, V, U, M, wino_gemm_stage_default(), st, &why);
     if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
   }
   e = wino_output_launch(M, n_img, Co, phases, bias, res, res_cstride, res_coff, flags, y, y_cstride, y_coff, pool_part, st);
@@ -1582,21 +1592,8 @@ int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_c
   WinoGroup grp[4];
   const int ngrp = wino7_groups((long long)T, Ci, Co, grp);
   if (!fused) {
-    const int K0 = grp[0].kmul * Ci;
-    ConvDesc d;
-    d.x = V; d.x_cs = K0; d.x_coff = 0; d.n_img = (int)T; d.H = 1; d.W = 1; d.Ci = K0;
-    d.w = U; d.bias = nullptr; d.Co = Co; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-    d.res = nullptr; d.res_cs = 0; d.res_coff = 0; d.flags = 0;
-    d.y = M; d.y_cs = Co; d.y_coff = 0;
-    d.tile_cfg = 3; d.splitk = 1; d.precision = 0;
-    d.batch = kWino7Points; d.x_bstride = (long long)T * K0; d.w_bstride = (long long)Co * K0; d.y_bstride = (long long)T * Co;
-    d.ngroups = ngrp;
-    for (int gi = 0; gi < ngrp; ++gi) {
-      d.g_batch[gi] = grp[gi].batch; d.g_Ci[gi] = grp[gi].kmul * Ci;
-      d.g_x[gi] = grp[gi].v_off; d.g_w[gi] = grp[gi].u_off; d.g_y[gi] = grp[gi].m_off;
-    }
     const char* why = nullptr;
-    e = conv2d_launch(d, st, &why);
+    e = wino_gemms_launch(grp, ngrp, kWino7Points, (int)T, Ci, Co, V, U, M, wino_gemm_stage_default(), st, &why);
     if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
   }
   e = wino7_output_launch(M, n_img, Co, bias, flags, y, y_cstride, y_coff, st);

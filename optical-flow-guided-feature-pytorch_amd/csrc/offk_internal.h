@@ -73,6 +73,16 @@ hipError_t wino_output_launch(const float* M, int n_img, int Co, int phases, con
 // (81 points K = 4 Ci, 18 + 18 points K = 2 Ci, 4 points K = Ci; winograd.hip).  Offsets in floats for `rows` images / Co output channels.
 struct WinoGroup { int batch, kmul; long long v_off, u_off, m_off; };
 int wino_groups(int phases, long long rows, int Ci, int Co, WinoGroup out[4]);
+// ---- K4g: the batched GEMMs of a conv on a Winograd path as one persistent launch (wino_gemm.hip).  Group g: g_batch[g] problems
+//      [M x g_K[g]] . [Co x g_K[g]]^T -> [M x Co], packed one behind the other from x + g_x[g] / w + g_w[g] / y + g_y[g] (floats)
+struct WinoGemmArgs {
+  const float* x; const float* w; float* y;
+  int M, Co;
+  int ngroups, g_batch[4], g_K[4];
+  long long g_x[4], g_w[4], g_y[4];
+  int gm, gn, total_items;     // filled by wino_gemm_launch
+};
+hipError_t wino_gemm_launch(const WinoGemmArgs& a, hipStream_t st);
 // ---- K4m: output transform -> (1x1 conv + ReLU) -> input transform between two Winograd convs on 7x7 maps, one launch (wino_mid.hip)
 struct WinoMidArgs {
   const float* M;          // GEMM output of the conv in front, Winograd domain: [121][n_img][Cin]

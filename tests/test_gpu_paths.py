@@ -387,6 +387,29 @@ def test_winograd_between_off_matches_on(rt, monkeypatch):
         assert max(errs.values()) < RTOL, errs
 
 
+@pytest.mark.parametrize("B", [3, 12, 64])
+def test_wino_gemm_persistent_matches_generic(rt, monkeypatch, B):
+    """The batched GEMMs of every Winograd conv as one persistent launch (wino_gemm.hip: a block works through its tiles as one stream
+    of K-tiles) against OFFK_WINO_GEMM=0 (one block of the generic 1x1 kernel per tile): same tile, same MFMA sequence, same k order --
+    logits and every stage tensor must be BIT-identical, with every gate forced open.  B = 3: fewer items than resident blocks; 12:
+    a few per block; 64: the benchmark shape, grouped launches with three K lengths."""
+    L = 7
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    h1, _ = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    monkeypatch.setenv("OFFK_WINO_GEMM", "0")
+    h0, _ = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    monkeypatch.delenv("OFFK_WINO_GEMM")
+    a, b = h1.forward(feats), h0.forward(feats)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    P = B * (L - 1)
+    for name, ch, H in STAGES:
+        assert torch.equal(h1.region(name, ch), h0.region(name, ch)), name
+    for name in ("wino_m",):       # the GEMM output of the last Winograd conv of the forward itself
+        assert torch.equal(h1.region(name, 1), h0.region(name, 1)), name
+
+
 @pytest.mark.parametrize("ci,n,relu", [(32, 1, False), (320, 3, False), (64, 5, True), (320, 8, False)])
 def test_winograd_conv7x7s2_fused_vs_torch(rt, ci, n, relu):
     """offk_winograd_conv7x7s2 with OFFK_CONV_WINO7_FUSED (winograd7_fused.hip: the input transform inside the GEMM kernel, the
