@@ -11,6 +11,8 @@
 //     never waits for a cold tile; the next item's addresses are scalar work beside the MFMAs;
 //   * an item's epilogue is sixteen accumulator reads and sixteen buffer stores issued in front of the step's wait, which lets the
 //     newest sixteen operations (the stores) stay in flight (s_waitcnt vmcnt(16)): they drain under the next item's first step.
+// (Also built: the A operand in THREE stages, two tiles ahead -- four blocks per CU may use 40 KB each, 32 granules -- correct, 1 - 2 %
+//  slower on every launch: the wait per K-tile is not an HBM latency one more tile of distance would cover.  Git history.)
 // Same tile, same LDS image, same MFMA sequence and k order as conv_igemm_kernel's LDS-DMA form (PREC 4): results are bit-identical
 // (tests/test_gpu_paths.py); item l of the launch is the tile block l of the generic launch worked on (same XCD: the grid is a
 // multiple of 8).
@@ -127,15 +129,16 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoGemmArgs p) {
         b[(g + 1) & 1] = *reinterpret_cast<const float4*>(base + boff[g + 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (issue && g < 2) {        // an A and a B piece of the next tile in front of each of the first two k-groups (behind all four: the
+        dma_piece(ld, g, ld_t, st ^ 1);          // last piece went out right in front of the wait for it; -1 .. -3 % per launch)
+        dma_piece(ld, g + 2, ld_t, st ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1].x, b[g & 1].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1].y, b[g & 1].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1].z, b[g & 1].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1].w, b[g & 1].w, acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (issue) {
-        dma_piece(ld, g, ld_t, st ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
     asm volatile("" : "+a"(acc));      // the tile lives in accumulator registers across the loop (hipcc parked it in vector registers at
                                        // the back edge: sixteen v_accvgpr_write in front of every K-tile's MFMAs, sixteen reads behind)
