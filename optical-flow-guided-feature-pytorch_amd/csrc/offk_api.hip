@@ -775,6 +775,8 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   //   OFFK_FOLD_POOL     7- / 14-head average pools taken in the producing conv's epilogue; 0: pool + fc kernels
   //   OFFK_WINO_MID      what sits between two Winograd convs on 7x7 maps (output transform, 1x1 conv, input transform) in one launch
   //                      (wino_mid.hip); 0: three launches
+  //   OFFK_WINO_GEMM     the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); 0: one block of the generic 1x1 kernel per
+  //                      tile (bit-identical).  The handle-less stage entry points read it once per process.
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
