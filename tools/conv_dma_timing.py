@@ -1,5 +1,8 @@
-"""Per-block cycle split of the LDS-DMA GEMM kernel on the batched Winograd launches of the forward (timing build:
-OFFK_VARIANT_DIR=_ab python tools/build_variant.py ctiming -DOFFK_CONV_TIMING; OFFK_LIB=tools/_ab/liboffk_ctiming.so python tools/conv_dma_timing.py)."""
+"""Per-block cycle split of the generic 1x1 kernel's LDS-DMA form (conv_igemm.hip) on the batched Winograd launches of the forward:
+    OFFK_VARIANT_DIR=_ab python tools/build_variant.py ctiming -DOFFK_CONV_TIMING
+    OFFK_WINO_GEMM=0 OFFK_LIB=tools/_ab/liboffk_ctiming.so python tools/conv_dma_timing.py
+(OFFK_WINO_GEMM=0: since round 4 these launches run in wino_gemm.hip's persistent kernel by default; profiles/r04/conv_block_cycle_split.txt
+and wino_gemm_persistent.txt hold the outputs.)"""
 import os
 import sys
 
