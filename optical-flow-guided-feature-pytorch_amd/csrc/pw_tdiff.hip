@@ -732,20 +732,25 @@ __global__ __launch_bounds__(256, 4) void pw_tdiff16_kernel(PtParams p) {
   const int bl = qpc ? b + (int)qn_e : b + (li_e >> rsh), pixl = qpc ? 4 * (qe - (qn_e ? qpc : 0)) + (li_e & 3) : q0 + (li_e & rmask);
   const size_t pair0 = (size_t)bl * (L - 1) + t0;
   const bool pix_ok = pixl < HW && bl < p.B;
+  // G in place of the accumulators (both channel tiles), then T pair by pair with the two channel tiles' stores back to back: a pixel's
+  // 32 channels of this wave are one 128-byte line, written as two 64-byte halves -- issued next to each other they merge in L2
+  // (channel tile by channel tile the second half came six stores later)
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const f32x4 bg = *reinterpret_cast<const f32x4*>(S.bias + wave * 32 + 16 * ct + 4 * kq_e);
-    f32x4 g[PT_FT];
 #pragma unroll
     for (int j = 0; j < PT_FT; ++j) {
       const f32x4 v = ag[j][ct] + bg;
-      g[j] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      ag[j][ct] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
     }
-#pragma unroll
-    for (int j = 0; j + 1 < PT_FT; ++j)
-      if (j + 1 < nf && pix_ok)
-        *reinterpret_cast<f32x4*>(S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 16 * ct + 4 * kq_e) = g[j + 1] - g[j];
   }
+#pragma unroll
+  for (int j = 0; j + 1 < PT_FT; ++j)
+    if (j + 1 < nf && pix_ok) {
+      float* const trow = S.M + ((pair0 + j) * HW + pixl) * S.m_cs + S.m_coff + kDownCh + wave * 32 + 4 * kq_e;
+      *reinterpret_cast<f32x4*>(trow) = ag[j + 1][0] - ag[j][0];
+      *reinterpret_cast<f32x4*>(trow + 16) = ag[j + 1][1] - ag[j][1];
+    }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int j = wave + 4 * half;                 // (wave 3, half 1: j = 7 >= nf -- its duplicate tile is dropped here)
