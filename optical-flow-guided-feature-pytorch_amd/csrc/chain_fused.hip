@@ -65,7 +65,8 @@ __device__ __forceinline__ int t1_swz(int sl) { return (int)((0x1e2d57216aed598a
 }  // namespace
 
 // NKT1 = Cin / 16 (4 or 16); MERGED: c3 contracts [t2 | x] (28a: the branch conv on the pre-ReLU chain input folded in)
-template <int NKT1, bool MERGED>
+// WINO: phase 2 in Winograd F(2x2, 3x3) form (see there)
+template <int NKT1, bool MERGED, bool WINO>
 __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
@@ -205,7 +206,81 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
   auto pass = [&](const int r0, auto nr_tag) {
     constexpr int NR = decltype(nr_tag)::value;
     // ---- phase 2: t2 = relu(W2 * t1 + b2) ----
-    {
+    if constexpr (WINO) {
+      // Winograd F(2x2, 3x3): the pass's four output rows x 14 columns are 2 x 7 tiles of 2 x 2 outputs (tile n = 8 ty + tx: one
+      // 16-wide MFMA tile with n = 7, 15 idle); sixteen points (p, q), per point a GEMM [16 channels of this wave] x [64 k] x
+      // [16 tiles]: 256 MFMAs per wave and pass instead of 576 / 432.  Point row p at a time (V of four points = 16 KB = the ring /
+      // t2 region): every thread transforms one (tile, 4-channel chunk) of t1 -- B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], two
+      // window rows per p -- the waves multiply, and the output transform A^T = [1 1 1 0; 0 1 -1 -1] is folded into the
+      // accumulation over p (Y[i][j] += A^T[i][p] * (M[p] A)[j]): sixteen registers of Y, no M in memory.
+      const int tn = threadIdx.x >> 4, tc = threadIdx.x & 15;          // transform item: tile tn, channel chunk tc
+      const int tty = tn >> 3, ttx = tn & 7;
+      const bool t_ok = ttx < 7;
+      // t1 address of window (row a, slot b): row r0 + 2 ty + a (clamped to the region's last row: only feeds the discarded row 7)
+      auto t1_at = [&](const int a_, const int b_) {
+        const int row = min(r0 + 2 * tty + a_, kT1Rows - 1), sl = 2 * ttx + b_;
+        return *reinterpret_cast<const f32x4*>(lds + kT1Off + (row * 16 + sl) * kSlot + ((tc ^ t1_swz(sl)) << 4));
+      };
+      char* const vwr = lds + kR2Off + tn * kSlot + ((tc ^ tn) << 4);                 // + q * 4096
+      const float* const u2r = a.u2 + (size_t)(16 * wave + li) * 64 + 4 * kq;        // + point * 4096 + 16 s
+      f32x4 Y[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { Y[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Y[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        // weights of the point row's first three (q, s) steps go out in front of the transform
+        f32x4 wq[4];
+        auto u_load = [&](const int step) { return *reinterpret_cast<const f32x4*>(u2r + (size_t)(4 * p + (step >> 2)) * 4096 + 16 * (step & 3)); };
+#pragma unroll
+        for (int st = 0; st < 3; ++st) wq[st] = u_load(st);
+        if (t_ok) {
+          constexpr int ra[4] = {0, 1, 2, 1}, rb[4] = {2, 2, 1, 3};
+          constexpr float sb[4] = {-1.f, 1.f, -1.f, -1.f};
+          f32x4 r[4];
+#pragma unroll
+          for (int b_ = 0; b_ < 4; ++b_) r[b_] = t1_at(ra[p], b_) + sb[p] * t1_at(rb[p], b_);
+          *reinterpret_cast<f32x4*>(vwr + 0 * 4096) = r[0] - r[2];
+          *reinterpret_cast<f32x4*>(vwr + 1 * 4096) = r[1] + r[2];
+          *reinterpret_cast<f32x4*>(vwr + 2 * 4096) = r[2] - r[1];
+          *reinterpret_cast<f32x4*>(vwr + 3 * 4096) = r[1] - r[3];
+        }
+        __syncthreads();
+        f32x4 M[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int step = 0; step < 16; ++step) {          // (q, s): point 4 p + q, channel step s
+          const int q = step >> 2, sq = step & 3;
+          if (step + 3 < 16) wq[(step + 3) & 3] = u_load(step + 3);
+          const f32x4 x = *reinterpret_cast<const f32x4*>(lds + t2rd[sq] + q * 4096);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 w = wq[step & 3];
+          M[q] = mfma4(w.x, x.x, M[q]);
+          M[q] = mfma4(w.y, x.y, M[q]);
+          M[q] = mfma4(w.z, x.z, M[q]);
+          M[q] = mfma4(w.w, x.w, M[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const f32x4 T0 = (M[0] + M[1]) + M[2], T1 = (M[1] - M[2]) - M[3];
+        if (p < 3) { Y[0][0] += T0; Y[0][1] += T1; }
+        if (p == 1) { Y[1][0] += T0; Y[1][1] += T1; }
+        if (p >= 2) { Y[1][0] -= T0; Y[1][1] -= T1; }
+        __syncthreads();          // V of this point row is overwritten by the next one / by t2
+      }
+      // t2[row 2 ty + i][slot 1 + 2 tx + j]: lane li is tile n = li
+      const int oty = li >> 3, otx = li & 7;
+      if (otx < 7) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int sl = 1 + 2 * otx + j;
+            const f32x4 v = Y[i][j] + b2;
+            *reinterpret_cast<f32x4*>(lds + kR2Off + ((2 * oty + i) * 16 + sl) * kSlot + (((4 * wave + kq) ^ sl) << 4)) =
+                f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+          }
+      }
+    } else {
       f32x4 acc[NR];
 #pragma unroll
       for (int m = 0; m < NR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -340,6 +415,36 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
 #undef OFFK_LAP
 }
 
+// U[4 p + q][co][ci] = sum_ab G[p][a] G[q][b] w[co][ci][a][b], G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1] (F(2, 3), points 0, 1, -1, inf)
+__global__ void chain_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (co, ci)
+  if (i >= 64 * 64) return;
+  const int co = i >> 6, ci = i & 63;
+  float g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = w[((co * 2 + (ci >> 5)) * 9 + t) * 32 + (ci & 31)];
+  float h[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    h[0][b] = g[0][b];
+    h[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+    h[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+    h[3][b] = g[2][b];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float u0 = h[p][0], u1 = 0.5f * ((h[p][0] + h[p][1]) + h[p][2]), u2 = 0.5f * ((h[p][0] - h[p][1]) + h[p][2]), u3 = h[p][2];
+    U[(size_t)(4 * p + 0) * 4096 + i] = u0;
+    U[(size_t)(4 * p + 1) * 4096 + i] = u1;
+    U[(size_t)(4 * p + 2) * 4096 + i] = u2;
+    U[(size_t)(4 * p + 3) * 4096 + i] = u3;
+  }
+}
+hipError_t chain_wino_weight_launch(const float* w2_packed, float* U, hipStream_t st) {
+  hipLaunchKernelGGL(chain_wino_weight_kernel, dim3(16), dim3(256), 0, st, w2_packed, U);
+  return hipGetLastError();
+}
+
 hipError_t chain14_launch(const ChainArgs& a_in, hipStream_t st, const char** why) {
   ChainArgs a = a_in;
   *why = nullptr;
@@ -364,16 +469,18 @@ hipError_t chain14_launch(const ChainArgs& a_in, hipStream_t st, const char** wh
   }
   if (!a.x_bytes) { *why = "chain14: input beyond 31-bit byte offsets"; return hipErrorInvalidValue; }
   const int blocks = (a.n_img + 7) / 8 * 16;
-#define OFFK_CHAIN_LAUNCH(NKT, MRG)                                                                                   \
+#define OFFK_CHAIN_LAUNCH_W(NKT, MRG, WN)                                                                             \
   {                                                                                                                   \
-    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(chain14_kernel<NKT, MRG>), kChainLds);                 \
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(chain14_kernel<NKT, MRG, WN>), kChainLds);             \
     if (e != hipSuccess) return e;                                                                                    \
-    hipLaunchKernelGGL((chain14_kernel<NKT, MRG>), dim3(blocks), dim3(256), kChainLds, st, a);                        \
+    hipLaunchKernelGGL((chain14_kernel<NKT, MRG, WN>), dim3(blocks), dim3(256), kChainLds, st, a);                    \
   }
+#define OFFK_CHAIN_LAUNCH(NKT, MRG) { if (a.u2) OFFK_CHAIN_LAUNCH_W(NKT, MRG, true) else OFFK_CHAIN_LAUNCH_W(NKT, MRG, false) }
   if (a.Cin == 64 && a.K3 == 128) OFFK_CHAIN_LAUNCH(4, true)
   else if (a.Cin == 64) OFFK_CHAIN_LAUNCH(4, false)
   else OFFK_CHAIN_LAUNCH(16, false)
 #undef OFFK_CHAIN_LAUNCH
+#undef OFFK_CHAIN_LAUNCH_W
   return hipGetLastError();
 }
 

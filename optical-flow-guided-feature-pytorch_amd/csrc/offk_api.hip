@@ -190,6 +190,8 @@ struct offk_handle {
   int wino7_min_p = 12;          // ... from this many pairs (OFFK_WINOGRAD_7X7=<n> with n > 1 at offk_create: tools)
   float* wino_u[6] = {};         // transformed weights [121][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; 400 x Co x Ci floats of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
+  float* chain_u2[3] = {};       // F(2x2, 3x3) weights [16][64][64] of the chains' 3x3 convs C2_28A / B / C (chain_fused.hip, OFFK_CHAIN_WINO)
+  bool chain_wino = false;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
   bool wino_5x5 = true;          // the 5x5 / stride 2 conv of fusion@14 in polyphase Winograd form (OFFK_WINOGRAD_5X5=0: direct)
   bool wino_gemm = true;         // the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); false: the generic 1x1 kernel
@@ -658,6 +660,11 @@ int finalize_wino(offk_handle* h, hipStream_t st) {
   for (int k = 0; k < 6; ++k)
     HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, k == 5 ? 4 : 1, h->wino_u[k], st));
   if (h->wino_u7) HIP_TRY(h, wino7_weight_launch(h->conv_w[C_T28], kConvs[C_T28].Co, kConvs[C_T28].Ci, h->wino_u7, st));
+  {
+    const ConvId c2[3] = {C2_28A, C2_28B, C2_28C};
+    for (int k = 0; k < 3; ++k)
+      if (h->chain_u2[k]) HIP_TRY(h, chain_wino_weight_launch(h->conv_w[c2[k]], h->chain_u2[k], st));
+  }
   h->wino_dirty = false;
   return OFFK_OK;
 }
@@ -790,6 +797,10 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     for (int k = 0; k < 6; ++k)
       if (dev_alloc(h, &h->wino_u[k], (size_t)(k == 5 ? kWinoUnits4 : kWinoPoints) * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    { const char* e = getenv("OFFK_CHAIN_WINO"); h->chain_wino = h->chain && (e && *e == '1'); }
+    if (h->chain_wino)
+      for (int k = 0; k < 3; ++k)
+        if (dev_alloc(h, &h->chain_u2[k], (size_t)16 * 64 * 64) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
   }
   plan_workspace(h);
   *out = h;
@@ -1219,6 +1230,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     ChainArgs a;
     a.x = x; a.x_cs = x_cs; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in;
     a.w1 = h->conv_w[c1]; a.b1 = h->conv_b[c1]; a.w2 = h->conv_w[c2]; a.b2 = h->conv_b[c2];
+    a.u2 = h->chain_wino ? h->chain_u2[c2 == C2_28A ? 0 : c2 == C2_28B ? 1 : 2] : nullptr;
     a.w3 = w3; a.b3 = b3; a.K3 = K3;
     a.res = res; a.res_cs = 256; a.res_coff = 0;
     a.y = y; a.y_cs = y_cs; a.y_coff = y_coff;
@@ -1513,6 +1525,7 @@ int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_c
   if (!x || !w1 || !b1 || !w2_packed || !b2 || !w3 || !b3 || !y || n_img < 1)
     return fail(nullptr, OFFK_ERR_INVALID, "offk_bottleneck_chain14: bad argument");
   ChainArgs a;
+  a.u2 = nullptr;     // (the stage entry point runs the direct 3x3: it has no place for transformed weights)
   a.x = x; a.x_cs = x_cstride; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in ? 1 : 0;
   a.w1 = w1; a.b1 = b1; a.w2 = w2_packed; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.K3 = K3;
   a.res = res; a.res_cs = res_cstride; a.res_coff = res_coff; a.y = y; a.y_cs = y_cstride; a.y_coff = y_coff;

@@ -49,6 +49,8 @@ struct ChainArgs {
   int relu_in;                            // c1 reads relu(x) (28a: x is the pre-ReLU 7x7 output)
   const float* w1; const float* b1;       // c1 [64][Cin], [64]
   const float* w2; const float* b2;       // c2 3x3 64 -> 64 in the library's packed K order [64][2][9][32], [64]
+  const float* u2;                        // != nullptr: c2 in Winograd F(2x2, 3x3) form inside the kernel -- its transformed weights
+                                          // [16 points][64 co][64 ci] (chain_wino_weight_launch); nullptr: the direct form
   const float* w3; const float* b3;       // c3 [256][K3], [256]
   int K3;                                 // 64, or 128: c3 contracts [t2 | x] (the branch 1x1 on the chain input merged in)
   const float* res; int res_cs, res_coff; // residual (256 channels) or nullptr
@@ -60,6 +62,8 @@ struct ChainArgs {
 #endif
 };
 hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
+// U[4 p + q][co][ci] = sum_ab G[p][a] G[q][b] w[co][ci][a][b] from the packed 3x3 weights [64][2][9][32] (16 * 64 * 64 floats)
+hipError_t chain_wino_weight_launch(const float* w2_packed, float* U, hipStream_t st);
 
 // ---- K4w: Winograd for the 3x3 / stride 1 convs on 7x7 maps (winograd.hip): a map = four tiles, F(4, 3) x F(3, 3) per axis ----
 // phases = 1: 3x3 / stride 1 on 7x7 maps: 121 points (batches) per image; phases = 4: the polyphase form of a 5x5 / stride 2 / pad 2

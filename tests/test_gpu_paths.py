@@ -387,6 +387,34 @@ def test_winograd_between_off_matches_on(rt, monkeypatch):
         assert max(errs.values()) < RTOL, errs
 
 
+@pytest.mark.parametrize("B,kind", [(3, None), (12, None), (12, "heavy_tail"), (64, None)])
+def test_chain_winograd_3x3_vs_direct_and_oracle(rt, monkeypatch, B, kind):
+    """OFFK_CHAIN_WINO=1: the 3x3 conv inside chain14_kernel in Winograd F(2x2, 3x3) form (transformed weights re-made by the
+    weight finaliser) against the direct form and against the oracle's stage tensors, gates forced open."""
+    L = 7
+    feats_np = synth.make_features(B, L, 2) if kind is None else synth.make_features_kind(B, L, 3, kind)
+    feats = [dev(f) for f in feats_np]
+    h0, w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    monkeypatch.setenv("OFFK_CHAIN_WINO", "1")
+    h1, _ = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    monkeypatch.delenv("OFFK_CHAIN_WINO")
+    a, b = h1.forward(feats), h0.forward(feats)
+    torch.cuda.synchronize()
+    P = B * (L - 1)
+    f1 = h1.region("fusion_14", 1056).view(P, 14, 14, 1056)[..., 800:]
+    f0 = h0.region("fusion_14", 1056).view(P, 14, 14, 1056)[..., 800:]
+    e_chain = rel_err(f1, f0.cpu())
+    e_logit = max(rel_err(x, y.cpu()) for x, y in zip(a, b))
+    print("chain winograd vs direct (B = %d, %s): sum_28c %.2e, logits %.2e" % (B, kind, e_chain, e_logit))
+    assert 0 < e_chain < 2e-5 and e_logit < 2e-5
+    if B <= 12:
+        with torch.no_grad():
+            want, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, spec.VARIANT_RGB, orc.SLICE_FLAT, return_stages=True)
+        errs = stage_errs(h1, st, P)
+        assert max(errs.values()) < RTOL, errs
+        assert signal_err(a[0], want[0]) < RTOL_NORTH_STAR
+
+
 @pytest.mark.parametrize("B", [3, 12, 64])
 def test_wino_gemm_persistent_matches_generic(rt, monkeypatch, B):
     """The batched GEMMs of every Winograd conv as one persistent launch (wino_gemm.hip: a block works through its tiles as one stream
