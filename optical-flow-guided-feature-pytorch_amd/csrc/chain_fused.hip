@@ -206,81 +206,7 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
   auto pass = [&](const int r0, auto nr_tag) {
     constexpr int NR = decltype(nr_tag)::value;
     // ---- phase 2: t2 = relu(W2 * t1 + b2) ----
-    if constexpr (WINO) {
-      // Winograd F(2x2, 3x3): the pass's four output rows x 14 columns are 2 x 7 tiles of 2 x 2 outputs (tile n = 8 ty + tx: one
-      // 16-wide MFMA tile with n = 7, 15 idle); sixteen points (p, q), per point a GEMM [16 channels of this wave] x [64 k] x
-      // [16 tiles]: 256 MFMAs per wave and pass instead of 576 / 432.  Point row p at a time (V of four points = 16 KB = the ring /
-      // t2 region): every thread transforms one (tile, 4-channel chunk) of t1 -- B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], two
-      // window rows per p -- the waves multiply, and the output transform A^T = [1 1 1 0; 0 1 -1 -1] is folded into the
-      // accumulation over p (Y[i][j] += A^T[i][p] * (M[p] A)[j]): sixteen registers of Y, no M in memory.
-      const int tn = threadIdx.x >> 4, tc = threadIdx.x & 15;          // transform item: tile tn, channel chunk tc
-      const int tty = tn >> 3, ttx = tn & 7;
-      const bool t_ok = ttx < 7;
-      // t1 address of window (row a, slot b): row r0 + 2 ty + a (clamped to the region's last row: only feeds the discarded row 7)
-      auto t1_at = [&](const int a_, const int b_) {
-        const int row = min(r0 + 2 * tty + a_, kT1Rows - 1), sl = 2 * ttx + b_;
-        return *reinterpret_cast<const f32x4*>(lds + kT1Off + (row * 16 + sl) * kSlot + ((tc ^ t1_swz(sl)) << 4));
-      };
-      char* const vwr = lds + kR2Off + tn * kSlot + ((tc ^ tn) << 4);                 // + q * 4096
-      const float* const u2r = a.u2 + (size_t)(16 * wave + li) * 64 + 4 * kq;        // + point * 4096 + 16 s
-      f32x4 Y[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { Y[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Y[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        // weights of the point row's first three (q, s) steps go out in front of the transform
-        f32x4 wq[4];
-        auto u_load = [&](const int step) { return *reinterpret_cast<const f32x4*>(u2r + (size_t)(4 * p + (step >> 2)) * 4096 + 16 * (step & 3)); };
-#pragma unroll
-        for (int st = 0; st < 3; ++st) wq[st] = u_load(st);
-        if (t_ok) {
-          constexpr int ra[4] = {0, 1, 2, 1}, rb[4] = {2, 2, 1, 3};
-          constexpr float sb[4] = {-1.f, 1.f, -1.f, -1.f};
-          f32x4 r[4];
-#pragma unroll
-          for (int b_ = 0; b_ < 4; ++b_) r[b_] = t1_at(ra[p], b_) + sb[p] * t1_at(rb[p], b_);
-          *reinterpret_cast<f32x4*>(vwr + 0 * 4096) = r[0] - r[2];
-          *reinterpret_cast<f32x4*>(vwr + 1 * 4096) = r[1] + r[2];
-          *reinterpret_cast<f32x4*>(vwr + 2 * 4096) = r[2] - r[1];
-          *reinterpret_cast<f32x4*>(vwr + 3 * 4096) = r[1] - r[3];
-        }
-        __syncthreads();
-        f32x4 M[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) M[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int step = 0; step < 16; ++step) {          // (q, s): point 4 p + q, channel step s
-          const int q = step >> 2, sq = step & 3;
-          if (step + 3 < 16) wq[(step + 3) & 3] = u_load(step + 3);
-          const f32x4 x = *reinterpret_cast<const f32x4*>(lds + t2rd[sq] + q * 4096);
-          __builtin_amdgcn_sched_barrier(0);
-          const f32x4 w = wq[step & 3];
-          M[q] = mfma4(w.x, x.x, M[q]);
-          M[q] = mfma4(w.y, x.y, M[q]);
-          M[q] = mfma4(w.z, x.z, M[q]);
-          M[q] = mfma4(w.w, x.w, M[q]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        const f32x4 T0 = (M[0] + M[1]) + M[2], T1 = (M[1] - M[2]) - M[3];
-        if (p < 3) { Y[0][0] += T0; Y[0][1] += T1; }
-        if (p == 1) { Y[1][0] += T0; Y[1][1] += T1; }
-        if (p >= 2) { Y[1][0] -= T0; Y[1][1] -= T1; }
-        __syncthreads();          // V of this point row is overwritten by the next one / by t2
-      }
-      // t2[row 2 ty + i][slot 1 + 2 tx + j]: lane li is tile n = li
-      const int oty = li >> 3, otx = li & 7;
-      if (otx < 7) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int sl = 1 + 2 * otx + j;
-            const f32x4 v = Y[i][j] + b2;
-            *reinterpret_cast<f32x4*>(lds + kR2Off + ((2 * oty + i) * 16 + sl) * kSlot + (((4 * wave + kq) ^ sl) << 4)) =
-                f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-          }
-      }
-    } else {
+    if constexpr (!WINO) {
       f32x4 acc[NR];
 #pragma unroll
       for (int m = 0; m < NR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -367,7 +293,7 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
         f32x4 xv[NR];
         if (s < 4) {
 #pragma unroll
-          for (int m = 0; m < NR; ++m) xv[m] = *reinterpret_cast<const f32x4*>(lds + t2rd[s] + m * 16 * kSlot);
+          for (int m = 0; m < NR; ++m) xv[m] = *reinterpret_cast<const f32x4*>(lds + t2rd[s] + (WINO ? (kT1Off - kR2Off) + (r0 + m) * 16 * kSlot : m * 16 * kSlot));
         } else {
 #pragma unroll
           for (int m = 0; m < NR; ++m) xv[m] = xg[m];
@@ -404,6 +330,115 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
     __syncthreads();        // t2 is overwritten by the next pass
     OFFK_LAP(2)
   };
+  if constexpr (WINO) {
+    // ---- phase 2 in Winograd F(2x2, 3x3) form, the block's seven output rows at once ----
+    // 4 x 7 tiles of 2 x 2 outputs (tile n = 8 ty + tx, tx < 7; row 7 of tile row 3 is computed and dropped) = two 16-wide MFMA
+    // column blocks nt = ty >> 1; sixteen points (p, q), per point a GEMM [16 channels of this wave] x [64 k] x [32 tiles]: 512
+    // MFMAs per wave instead of 1008.  Two points (p, 2 h), (p, 2 h + 1) at a time -- their V, 2 x 32 tiles x 256 B, is the 16 KB
+    // ring region: every thread transforms two (tile, 4-channel chunk) items of t1 (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:
+    // two window rows per p), the waves multiply -- a weight quad serves both column blocks -- and the output transform
+    // A^T = [1 1 1 0; 0 1 -1 -1] is folded into the accumulation (T[j] = sum_q M[q] A[q][j], Y[i][j] += A^T[i][p] T[j]): no M in
+    // memory.  t2 then replaces t1 (all eight tile rows), phase 3 reads it from there.
+    const int tn = threadIdx.x >> 4, tc = threadIdx.x & 15;          // transform items: tiles tn and tn + 16, channel chunk tc
+    const int ttx = tn & 7;
+    const bool t_ok = ttx < 7;
+    auto t1_at = [&](const int ty, const int a_, const int b_) {     // window row a, slot b of tile (ty, ttx); past the region: its last row
+      const int row = min(2 * ty + a_, kT1Rows - 1), sl = 2 * ttx + b_;
+      return *reinterpret_cast<const f32x4*>(lds + kT1Off + (row * 16 + sl) * kSlot + ((tc ^ t1_swz(sl)) << 4));
+    };
+    char* const vwr = lds + kR2Off + tn * kSlot + ((tc ^ tn) << 4);                 // + point-in-pair * 8192 + (tile >= 16) * 4096
+    const float* const u2r = a.u2 + (size_t)(16 * wave + li) * 64 + 4 * kq;        // + point * 4096 + 16 s
+    f32x4 Y[2][2][2];                                                                // [i][j][nt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { Y[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Y[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        f32x4 wq[2][2], xq[2][2][2];                // weights [set][point of the pair]; V [set][point][nt]: one channel step ahead
+        auto u_load = [&](f32x4 (&w)[2], const int sq) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) w[e] = *reinterpret_cast<const f32x4*>(u2r + (size_t)(4 * p + 2 * hq + e) * 4096 + 16 * sq);
+        };
+        auto v_load = [&](f32x4 (&x)[2][2], const int sq) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) x[e][nt] = *reinterpret_cast<const f32x4*>(lds + t2rd[sq] + e * 8192 + nt * 4096);
+        };
+        u_load(wq[0], 0);
+        if (t_ok) {
+          constexpr int ra[4] = {0, 1, 2, 1}, rb[4] = {2, 2, 1, 3};
+          constexpr float sb[4] = {-1.f, 1.f, -1.f, -1.f};
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {          // tile rows tn >> 3 and 2 + (tn >> 3)
+            const int ty = (tn >> 3) + 2 * half;
+            f32x4 r[4];
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_) r[b_] = t1_at(ty, ra[p], b_) + sb[p] * t1_at(ty, rb[p], b_);
+            if (hq == 0) {
+              *reinterpret_cast<f32x4*>(vwr + half * 4096) = r[0] - r[2];
+              *reinterpret_cast<f32x4*>(vwr + 8192 + half * 4096) = r[1] + r[2];
+            } else {
+              *reinterpret_cast<f32x4*>(vwr + half * 4096) = r[2] - r[1];
+              *reinterpret_cast<f32x4*>(vwr + 8192 + half * 4096) = r[1] - r[3];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one window at a time in registers
+          }
+        }
+        __syncthreads();
+        f32x4 M[2][2];                              // [point of the pair][nt]
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { M[e][0] = f32x4{0.f, 0.f, 0.f, 0.f}; M[e][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        v_load(xq[0], 0);
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+          if (sq + 1 < 4) { u_load(wq[(sq + 1) & 1], sq + 1); v_load(xq[(sq + 1) & 1], sq + 1); }
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 (&w)[2] = wq[sq & 1];
+          const f32x4 (&x)[2][2] = xq[sq & 1];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { M[e][0] = mfma4(w[e].x, x[e][0].x, M[e][0]); M[e][1] = mfma4(w[e].x, x[e][1].x, M[e][1]); }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { M[e][0] = mfma4(w[e].y, x[e][0].y, M[e][0]); M[e][1] = mfma4(w[e].y, x[e][1].y, M[e][1]); }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { M[e][0] = mfma4(w[e].z, x[e][0].z, M[e][0]); M[e][1] = mfma4(w[e].z, x[e][1].z, M[e][1]); }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { M[e][0] = mfma4(w[e].w, x[e][0].w, M[e][0]); M[e][1] = mfma4(w[e].w, x[e][1].w, M[e][1]); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // (M A)[0] = M0 + M1 + M2, (M A)[1] = M1 - M2 - M3 over the row's four points q, straight into Y[i][j] += A^T[i][p] (M A)[j]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 c0 = hq == 0 ? M[0][nt] + M[1][nt] : M[0][nt];
+          const f32x4 c1 = hq == 0 ? M[1][nt] : f32x4{0.f, 0.f, 0.f, 0.f} - (M[0][nt] + M[1][nt]);
+          if (p < 3) { Y[0][0][nt] += c0; Y[0][1][nt] += c1; }
+          if (p == 1) { Y[1][0][nt] += c0; Y[1][1][nt] += c1; }
+          if (p >= 2) { Y[1][0][nt] -= c0; Y[1][1][nt] -= c1; }
+        }
+        asm volatile("" : "+v"(Y[0][0][0]), "+v"(Y[0][0][1]), "+v"(Y[0][1][0]), "+v"(Y[0][1][1]), "+v"(Y[1][0][0]), "+v"(Y[1][0][1]), "+v"(Y[1][1][0]), "+v"(Y[1][1][1]));
+        __syncthreads();          // this pair's V is overwritten by the next one (and, behind the last, t1 by t2)
+      }
+    }
+    // t2[row 2 ty + i][slot 1 + 2 tx + j] into the t1 region (every wave is past its last window read): lane li is tile 16 nt + li
+    const int otx = li & 7;
+    if (otx < 7) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = 2 * (2 * nt + (li >> 3)) + i, sl = 1 + 2 * otx + j;
+            const f32x4 v = Y[i][j][nt] + b2;
+            *reinterpret_cast<f32x4*>(lds + kT1Off + (row * 16 + sl) * kSlot + (((4 * wave + kq) ^ sl) << 4)) =
+                f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+          }
+    }
+    __syncthreads();
+  }
   pass(0, std::integral_constant<int, 4>());
   pass(4, std::integral_constant<int, 3>());
 #ifdef OFFK_CHAIN_TIMING

@@ -782,6 +782,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   //   OFFK_FOLD_POOL     7- / 14-head average pools taken in the producing conv's epilogue; 0: pool + fc kernels
   //   OFFK_WINO_MID      what sits between two Winograd convs on 7x7 maps (output transform, 1x1 conv, input transform) in one launch
   //                      (wino_mid.hip); 0: three launches
+  //   OFFK_CHAIN_WINO    the 3x3 conv inside a bottleneck chain in Winograd F(2x2, 3x3) form (chain_fused.hip); 0: direct (also with OFFK_WINOGRAD=0)
   //   OFFK_WINO_GEMM     the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); 0: one block of the generic 1x1 kernel per
   //                      tile (bit-identical).  The handle-less stage entry points read it once per process.
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
@@ -797,7 +798,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     for (int k = 0; k < 6; ++k)
       if (dev_alloc(h, &h->wino_u[k], (size_t)(k == 5 ? kWinoUnits4 : kWinoPoints) * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
-    { const char* e = getenv("OFFK_CHAIN_WINO"); h->chain_wino = h->chain && (e && *e == '1'); }
+    { const char* e = getenv("OFFK_CHAIN_WINO"); h->chain_wino = h->chain && !(e && *e == '0'); }
     if (h->chain_wino)
       for (int k = 0; k < 3; ++k)
         if (dev_alloc(h, &h->chain_u2[k], (size_t)16 * 64 * 64) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }

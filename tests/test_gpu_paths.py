@@ -389,14 +389,14 @@ def test_winograd_between_off_matches_on(rt, monkeypatch):
 
 @pytest.mark.parametrize("B,kind", [(3, None), (12, None), (12, "heavy_tail"), (64, None)])
 def test_chain_winograd_3x3_vs_direct_and_oracle(rt, monkeypatch, B, kind):
-    """OFFK_CHAIN_WINO=1: the 3x3 conv inside chain14_kernel in Winograd F(2x2, 3x3) form (transformed weights re-made by the
-    weight finaliser) against the direct form and against the oracle's stage tensors, gates forced open."""
+    """The 3x3 conv inside chain14_kernel in Winograd F(2x2, 3x3) form (the default; transformed weights re-made by the weight
+    finaliser) against the direct form (OFFK_CHAIN_WINO=0) and against the oracle's stage tensors, gates forced open."""
     L = 7
     feats_np = synth.make_features(B, L, 2) if kind is None else synth.make_features_kind(B, L, 3, kind)
     feats = [dev(f) for f in feats_np]
-    h0, w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
-    monkeypatch.setenv("OFFK_CHAIN_WINO", "1")
-    h1, _ = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    h1, w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    monkeypatch.setenv("OFFK_CHAIN_WINO", "0")
+    h0, _ = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
     monkeypatch.delenv("OFFK_CHAIN_WINO")
     a, b = h1.forward(feats), h0.forward(feats)
     torch.cuda.synchronize()
