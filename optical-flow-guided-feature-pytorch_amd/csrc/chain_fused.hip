@@ -27,7 +27,8 @@
 //            of 16 slots x 64 channels (256-byte slot rows, 16-byte chunk c stored at c ^ t1_swz(slot): the 16 lanes of a
 //            ds_read_b128 group hit 16 distinct chunks for all three tap columns)
 //   phase 2  c2 (3x3, 64 -> 64) for 4 (then 3) output rows: A = weights from global four steps ahead, B = shifted t1 tiles;
-//            t2 -> LDS (the ring's 16 KB: 4 rows)
+//            t2 -> LDS (the ring's 16 KB: 4 rows).  [r4] WINO = true (the forward's default; ChainArgs.u2): the same conv in Winograd
+//            F(2x2, 3x3) form over all seven rows at once -- 512 MFMAs per wave instead of 1008, t2 written over t1 -- see there
 //   phase 3  c3 (1x1, 64 -> 256; 28a: 128 -> 256 over [t2 | x0], x0 read from global) + bias + residual + ReLU -> global
 // Phases 2 and 3 run twice (rows 0-3, rows 4-6) so that t2 fits the ring's 16 KB and three blocks fit a CU.
 #include <cstdio>
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
       for (int hq = 0; hq < 2; ++hq) {
-        f32x4 wq[2][2], xq[2][2][2];                // weights [set][point of the pair]; V [set][point][nt]: one channel step ahead
+        f32x4 wq[3][2], xq[2][2][2];                // weights [set][point of the pair] two channel steps ahead; V [set][point][nt] one
         auto u_load = [&](f32x4 (&w)[2], const int sq) {
 #pragma unroll
           for (int e = 0; e < 2; ++e) w[e] = *reinterpret_cast<const f32x4*>(u2r + (size_t)(4 * p + 2 * hq + e) * 4096 + 16 * sq);
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
             for (int nt = 0; nt < 2; ++nt) x[e][nt] = *reinterpret_cast<const f32x4*>(lds + t2rd[sq] + e * 8192 + nt * 4096);
         };
         u_load(wq[0], 0);
+        u_load(wq[1], 1);
         if (t_ok) {
           constexpr int ra[4] = {0, 1, 2, 1}, rb[4] = {2, 2, 1, 3};
           constexpr float sb[4] = {-1.f, 1.f, -1.f, -1.f};
@@ -395,9 +397,10 @@ __global__ __launch_bounds__(256, 3) void chain14_kernel(ChainArgs a) {
         v_load(xq[0], 0);
 #pragma unroll
         for (int sq = 0; sq < 4; ++sq) {
-          if (sq + 1 < 4) { u_load(wq[(sq + 1) & 1], sq + 1); v_load(xq[(sq + 1) & 1], sq + 1); }
+          if (sq + 2 < 4) u_load(wq[(sq + 2) % 3], sq + 2);
+          if (sq + 1 < 4) v_load(xq[(sq + 1) & 1], sq + 1);
           __builtin_amdgcn_sched_barrier(0);
-          const f32x4 (&w)[2] = wq[sq & 1];
+          const f32x4 (&w)[2] = wq[sq % 3];
           const f32x4 (&x)[2][2] = xq[sq & 1];
 #pragma unroll
           for (int e = 0; e < 2; ++e) { M[e][0] = mfma4(w[e].x, x[e][0].x, M[e][0]); M[e][1] = mfma4(w[e].x, x[e][1].x, M[e][1]); }
