@@ -272,7 +272,26 @@ def winograd_saved_flops(P):
     on = [k for k in WINOGRAD_CONVS if not (k == "motion_conv_trans_28" and os.environ.get("OFFK_WINOGRAD_7X7", "1") == "0")
           and not (k == "motion_conv_trans_14" and os.environ.get("OFFK_WINOGRAD_5X5", "1") == "0")
           and not P < POLYPHASE_MIN_PAIRS.get(k, 0)]
-    return sum(w[k] - winograd_gemm_flops(P, k) for k in on)
+    saved = sum(w[k] - winograd_gemm_flops(P, k) for k in on)
+    return saved + sum(w[k] - chain_winograd_flops(P) for k in chain_winograd_convs(P))
+
+
+CHAIN_MIN_PAIRS = 72      # one launch per bottleneck chain of fusion@28 from this many pairs (offk_api.hip, OFFK_CHAIN)
+
+
+def chain_winograd_convs(P):
+    """The 3x3 convs that run in Winograd F(2x2, 3x3) form inside chain14_kernel (chain_fused.hip): the default from the chain gate on."""
+    e = os.environ
+    gate = int(e["OFFK_CHAIN"]) if e.get("OFFK_CHAIN", "").isdigit() and int(e["OFFK_CHAIN"]) > 1 else CHAIN_MIN_PAIRS
+    if e.get("OFFK_CHAIN", "1") == "0" or e.get("OFFK_CHAIN_WINO", "1") == "0" or e.get("OFFK_WINOGRAD", "1") == "0" or P < gate:
+        return ()
+    return ("motion_conv2_trans_28a", "motion_conv2_trans_28b", "motion_conv2_trans_28c")
+
+
+def chain_winograd_flops(P):
+    """FLOPs of the sixteen point GEMMs of a 64 -> 64 3x3 conv on 14x14 maps in F(2x2, 3x3): 7 x 7 tiles per image, 1 / 2.25 of the direct
+    conv's (the kernel multiplies 32 tile slots per half image for its 28 tiles; as everywhere, padding is not counted as work)."""
+    return 2.0 * P * 49 * 16 * 64 * 64
 
 
 def roofline_in_path(h, arr, out, B, L, precision, steps):
@@ -347,8 +366,15 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
         elif name in work or name.split(" ")[0] in work or name.startswith("chain_"):
             fl = work.get(name, work.get(name.split(" ")[0]))
             if fl is None:      # a fused bottleneck chain: "chain_<tag> = convA + convB + ..." (offk_api.hip)
-                fl = sum(work[k.strip()] for k in name.split("=", 1)[1].split("+"))
+                parts = [k.strip() for k in name.split("=", 1)[1].split("+")]
+                fl = sum(work[k] for k in parts)
+                cw = [k for k in parts if k in chain_winograd_convs(P)]
+                if cw:      # its 3x3 conv runs in Winograd form: frac stays on the direct-conv FLOPs (comparable across rounds), the executed ones beside it
+                    rec["direct_conv_flops"] = fl
+                    rec["executed_flops"] = fl - sum(work[k] - chain_winograd_flops(P) for k in cw)
             rec.update(bound="mfma", flops=fl, achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
+            if "executed_flops" in rec:
+                rec["executed_frac"] = rec["executed_flops"] / avg / 1e9 / peak
             if name not in big:
                 small_ms += avg
                 small_fl += fl
@@ -778,7 +804,8 @@ def main():
                      "algorithmic_tflops_over_summed_stage_time": algo_flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else 0.0,
                      "note": "THE fraction to quote is executed_frac_of_peak: the FLOPs the matrix pipe is actually asked for (direct-conv "
                              "FLOPs minus what the Winograd forms save: the 3x3 / stride 1 convs on 7x7 maps run 1 / 3.64 of their multiplies, "
-                             "the polyphase 5x5 / stride 2 conv 1 / 3.06, the polyphase 7x7 / stride 2 conv 1 / 4.7) / the wall-clock "
+                             "the polyphase 5x5 / stride 2 conv 1 / 3.06, the polyphase 7x7 / stride 2 conv 1 / 4.7, the 3x3 inside a bottleneck "
+                             "chain 1 / 2.25) / the wall-clock "
                              "ms_per_step / the dense MFMA peak of the arithmetic (fp32: 157.3 TF; bf16x3: 2.5 PF / 3 products), per GPU.  "
                              "algorithmic_flops_over_peak counts DIRECT-convolution FLOPs instead: a throughput-equivalent, NOT a "
                              "utilisation -- it can exceed 1 under Winograd."},
