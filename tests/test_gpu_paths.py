@@ -245,6 +245,26 @@ def test_mirror_picks_up_fusion_conv_updates_at_winograd_sizes(rt):
     assert not torch.equal(a[0], b[0])
 
 
+def test_chain_winograd_weights_follow_a_weight_update(rt, monkeypatch):
+    """A 3x3 conv of a bottleneck chain written after the first forward must reach its F(2x2, 3x3) weights (chain_u2, re-made by the
+    weight finaliser) before the next forward: gates open (B = 3), against a fresh handle holding the updated weights."""
+    B, L = 3, 7
+    feats = [dev(f) for f in synth.make_features(B, L, 2)]
+    h, _w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+    a = [t.clone() for t in h.forward(feats)]
+    w1 = dict(synth.make_weights(spec.VARIANT_RGB))
+    for i, k in enumerate(("motion_conv2_trans_28a", "motion_conv2_trans_28b", "motion_conv2_trans_28c")):
+        w1[k + ".weight"] = w1[k + ".weight"] * np.float32(1.5 + 0.25 * i)
+        h.set_weight(k + ".weight", torch.from_numpy(w1[k + ".weight"]))
+    b = h.forward(feats)
+    h2, _w2 = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB, weights=w1)
+    c = h2.forward(feats)
+    torch.cuda.synchronize()
+    for x, y in zip(b, c):
+        assert torch.equal(x, y)
+    assert not torch.equal(a[2], b[2])
+
+
 def test_modality_fuse_keeps_the_backbone_score_differentiable(rt):
     """`fc7 + Feature_Generation_Score + fc14` (Flow_OFF.py:881) runs as K7 on raw pointers at inference; when the
     backbone's score requires grad (fine-tuning the TSN stream through the fused score) the sum must stay on the autograd graph:
