@@ -257,9 +257,9 @@ hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, con
 typedef float fcx4 __attribute__((ext_vector_type(4)));
 constexpr int kFcWaves = 8;       // K is split over the block's waves: C / 8 channels each, in batches of four 16-channel steps
 // tiles != 0: part = [n_img * 4][C], one row per 4x4 output tile of the Winograd path (winograd.hip): an image = 4 rows
-__global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* __restrict__ part, int hw, int tiles, int n_img, int C,
-                                                                  const float* __restrict__ fw, const float* __restrict__ fb, int ncls,
-                                                                  float* __restrict__ out) {
+__device__ __forceinline__ void fc_pooled_body(const float* __restrict__ part, int hw, int tiles, int n_img, int C,
+                                               const float* __restrict__ fw, const float* __restrict__ fb, int ncls,
+                                               float* __restrict__ out) {
   __shared__ fcx4 red[kFcWaves][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
   const int img = min((int)blockIdx.x * 16 + li, n_img - 1);
@@ -318,6 +318,24 @@ __global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* _
         if (c + j < ncls) out[(size_t)gi * ncls + c + j] = v[j] * inv + fb[c + j];
     }
   }
+}
+__global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_kernel(const float* __restrict__ part, int hw, int tiles, int n_img, int C,
+                                                                  const float* __restrict__ fw, const float* __restrict__ fb, int ncls,
+                                                                  float* __restrict__ out) {
+  fc_pooled_body(part, hw, tiles, n_img, C, fw, fb, ncls, out);
+}
+// the FCs of up to three heads in ONE launch (blockIdx.z = head): each is a few microseconds of latency-bound work on a (24, 4) grid;
+// one behind the other they cost the sum, side by side the longest (the 1024-channel one)
+__global__ __launch_bounds__(64 * kFcWaves) void fc_pooled_multi_kernel(FcPooledJobs j) {
+  const FcPooledJob& h = j.job[blockIdx.z];
+  fc_pooled_body(h.part, h.hw, h.tiles, j.n_img, h.C, h.fw, h.fb, j.ncls, h.out);
+}
+hipError_t fc_pooled_multi_launch(const FcPooledJobs& j, hipStream_t st) {
+  if (j.njobs < 1 || j.njobs > 3 || j.n_img <= 0 || j.ncls <= 0) return hipErrorInvalidValue;
+  for (int i = 0; i < j.njobs; ++i)
+    if (j.job[i].C % 64 || j.job[i].hw < 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fc_pooled_multi_kernel, dim3((j.n_img + 15) / 16, (j.ncls + 31) / 32, j.njobs), dim3(64 * kFcWaves), 0, st, j);
+  return hipGetLastError();
 }
 hipError_t fc_pooled_launch(const float* part, int hw, int tiles, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
                             hipStream_t st) {

@@ -1145,6 +1145,12 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     if (e != hipSuccess) return fail_hip(h, e, "head");
     return OFFK_OK;
   };
+  // the folded-pool FCs of the heads are collected and launched together behind the last stage (heads.hip: fc_pooled_multi_kernel)
+  FcPooledJobs fcj{};
+  fcj.n_img = n; fcj.ncls = ncls;
+  auto fc_pooled_later = [&](const float* part, int hw, int tiles, int C, int k, float* logits) {
+    fcj.job[fcj.njobs++] = FcPooledJob{part, hw, tiles, C, h->fc_w[k], h->fc_b[k], logits};
+  };
   float *xt = region(h, ws, "xt_28"), *t1 = region(h, ws, "t1_28");
   float *sa = region(h, ws, "sa_28"), *sb = region(h, ws, "sb_28");
   float *xu = region(h, ws, "xu_14"), *u1 = region(h, ws, "u1_14"), *s14 = region(h, ws, "sa_14");   // xu = [u2 | x1]
@@ -1267,9 +1273,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   if (out28) {   // 28-head (:782-787): only reads sum_28c
     if (h->fold_pool) {     // pool-row partial sums + the FC as an MFMA GEMM (heads.hip) instead of pool_kernel + fc_kernel
       float* pp = region(h, ws, "poolpart_28");
-      TRY(trace_mark(h, s, "head_28 (max pool rows + fc)"));
+      TRY(trace_mark(h, s, "head_28 (max pool rows)"));
       HIP_TRY(h, maxpool_rows_launch(F14, 1056, 800, n, 14, 14, 256, pp, s));
-      HIP_TRY(h, fc_pooled_launch(pp, 49, 1, n, 256, h->fc_w[1], h->fc_b[1], ncls, l28, s));
+      fc_pooled_later(pp, 49, 1, 256, 1, l28);
     } else {
       TRY(run_head(1, F14, 1056, 800, 14, 256, 1, "pooled_28", l28));
     }
@@ -1321,11 +1327,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   if (ev) HIP_TRY(h, hipEventRecord(ev[4], s));
   // 14-head (:789-793): only reads sum_14b
   if (fold14t) {
-    TRY(trace_mark(h, s, "head_14 (fc on folded pool)"));
-    HIP_TRY(h, fc_pooled_launch(pp14t, 49, 1, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, s));
+    fc_pooled_later(pp14t, 49, 1, 512, 2, l14);
   } else if (fold && !wino) {
-    TRY(trace_mark(h, s, "head_14 (fc on folded pool)"));
-    HIP_TRY(h, fc_pooled_launch(pp14, 49, 0, n, 512, h->fc_w[2], h->fc_b[2], ncls, l14, s));
+    fc_pooled_later(pp14, 49, 0, 512, 2, l14);
   } else {
     TRY(run_head(2, F7, 832, 320, 7, 512, 0, "pooled_14", l14));
   }
@@ -1351,10 +1355,13 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   if (ev) HIP_TRY(h, hipEventRecord(ev[5], s));
   // ---- 7-head (:843-847)
   if (fold) {
-    TRY(trace_mark(h, s, "head_7 (fc on folded pool)"));
-    HIP_TRY(h, fc_pooled_launch(pp7, 49, 0, n, 1024, h->fc_w[0], h->fc_b[0], ncls, l7, s));
+    fc_pooled_later(pp7, 49, 0, 1024, 0, l7);
   } else {
     TRY(run_head(0, s7, 1024, 0, 7, 1024, 0, "pooled_7", l7));
+  }
+  if (fcj.njobs > 0) {
+    TRY(trace_mark(h, s, "heads (fc on folded pools, one launch)"));
+    HIP_TRY(h, fc_pooled_multi_launch(fcj, s));
   }
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;

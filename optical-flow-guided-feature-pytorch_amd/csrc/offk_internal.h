@@ -296,6 +296,9 @@ hipError_t fc_launch(const float* pooled, int n_img, int C, const float* fw, con
 // FC of a head whose average pool was folded into the producing conv: part = [ceil(n_img * hw / 32)][2][C] (ConvDesc.pool_part)
 // or, tiles != 0, [n_img * 4][C] (the Winograd output transform's per-tile sums)
 hipError_t maxpool_rows_launch(const float* x, int x_cs, int x_coff, int n_img, int H, int W, int C, float* part, hipStream_t st);
+struct FcPooledJob { const float* part; int hw, tiles, C; const float* fw; const float* fb; float* out; };
+struct FcPooledJobs { FcPooledJob job[3]; int njobs, n_img, ncls; };
+hipError_t fc_pooled_multi_launch(const FcPooledJobs& j, hipStream_t st);      // the folded-pool FCs of up to three heads in one launch
 hipError_t fc_pooled_launch(const float* part, int hw, int tiles, int n_img, int C, const float* fw, const float* fb, int ncls, float* out,
                             hipStream_t st);
 hipError_t vec_add_launch(const float* a, const float* b, float* o, int n, hipStream_t st);
