@@ -361,6 +361,22 @@ __global__ void consensus_kernel(const float* __restrict__ x, int T, int C, floa
     out[(size_t)b * C + c] = s / (float)T;
   }
 }
+// the SegmentConsensus of up to three heads in one launch (blockIdx.y = head)
+__global__ void consensus_multi_kernel(const float* x0, const float* x1, const float* x2, int T, int C, float* o0, float* o1, float* o2) {
+  const float* const x = blockIdx.y == 0 ? x0 : blockIdx.y == 1 ? x1 : x2;
+  float* const out = blockIdx.y == 0 ? o0 : blockIdx.y == 1 ? o1 : o2;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[((size_t)b * T + t) * C + c];
+    out[(size_t)b * C + c] = s / (float)T;
+  }
+}
+hipError_t consensus_multi_launch(const float* const x[3], float* const out[3], int nheads, int B, int T, int C, hipStream_t st) {
+  if (nheads < 1 || nheads > 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(consensus_multi_kernel, dim3(B, nheads), dim3(128), 0, st, x[0], x[1], x[2], T, C, out[0], out[1], out[2]);
+  return hipGetLastError();
+}
 hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hipStream_t st) {
   hipLaunchKernelGGL(consensus_kernel, dim3(B), dim3(128), 0, st, x, T, C, out);
   return hipGetLastError();

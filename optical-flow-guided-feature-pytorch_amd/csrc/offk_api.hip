@@ -1366,9 +1366,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   if (cons) {
     const int B = h->cfg.batch, T = h->cfg.length - 1;
     TRY(trace_mark(h, st, "consensus (K6)"));
-    HIP_TRY(h, consensus_launch(l7, B, T, ncls, out7, st));                                       // Flow_OFF.py:874
-    HIP_TRY(h, consensus_launch(l14, B, T, ncls, out14, st));                                     // Flow_OFF.py:876
-    if (out28) HIP_TRY(h, consensus_launch(l28, B, T, ncls, out28, st));                          // Flow_OFF.py:875
+    const float* const cx[3] = {l7, l14, out28 ? l28 : l14};                                      // Flow_OFF.py:874-876, one launch
+    float* const co[3] = {out7, out14, out28 ? out28 : out14};
+    HIP_TRY(h, consensus_multi_launch(cx, co, out28 ? 3 : 2, B, T, ncls, st));
   }
   if (ev) HIP_TRY(h, hipEventRecord(ev[6], st));
   TRY(trace_mark(h, st, nullptr));

@@ -305,6 +305,7 @@ hipError_t vec_add_launch(const float* a, const float* b, float* o, int n, hipSt
 hipError_t score_fusion_launch(const float* const* scores, const float* weights, int n, int videos, int crops, int classes,
                                float* fused, int* pred, hipStream_t st);
 hipError_t consensus_launch(const float* x, int B, int T, int C, float* out, hipStream_t st);
+hipError_t consensus_multi_launch(const float* const x[3], float* const out[3], int nheads, int B, int T, int C, hipStream_t st);
 hipError_t nchw_to_nhwc_launch(const float* src, int n_img, int C, int HW, float* dst, hipStream_t st);
 hipError_t nhwc_to_nchw_launch(const float* src, int cs, int coff, int n_img, int C, int HW, float* dst, hipStream_t st);
 hipError_t repack_dw_launch(const float* w_c33, float* w_tap_c, hipStream_t st);  // [32][1][3][3] -> [9][32]
