@@ -106,8 +106,13 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoGemmArgs p) {
   auto dma_piece = [&](const Item& it, const int i, int t, const int st) {
     const unsigned dst = dma_dst + st * WG_STAGE + (i < 2 ? i * 32 * 128 : WG_BM * 128 + (i - 2) * 32 * 128);
     const int soff = __builtin_amdgcn_readfirstlane(t * 128);
+#ifdef OFFK_WG_ABLATE      /* timing experiments only: 1 = no A pieces, 2 = no B pieces, 3 = neither (the offsets point past the descriptors) */
+    if (i < 2) dma16(it.adesc, dst, (OFFK_WG_ABLATE & 1) ? (int)0x80000000 : it.a_off[i], soff);
+    else dma16(it.bdesc, dst, (OFFK_WG_ABLATE & 2) ? (int)0x80000000 : it.b_off[i - 2], soff);
+#else
     if (i < 2) dma16(it.adesc, dst, it.a_off[i], soff);
     else dma16(it.bdesc, dst, it.b_off[i - 2], soff);
+#endif
   };
 
   f32x16 acc;
