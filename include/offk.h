@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 8
+#define OFFK_ABI_VERSION 9
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -68,9 +68,15 @@ enum offk_feat_layout {
 
 enum offk_precision {
   OFFK_PRECISION_FP32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
-  OFFK_PRECISION_BF16X3 = 1 /* each fp32 operand split into bf16 hi + lo, a*b = a_lo*b_hi + a_hi*b_lo +
+  OFFK_PRECISION_BF16X3 = 1, /* each fp32 operand split into bf16 hi + lo, a*b = a_lo*b_hi + a_hi*b_lo +
                                a_hi*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate: ~1e-5 relative
                                to the fp32 path (budget 1e-3) at 3/16 of its matrix-core cycles */
+  OFFK_PRECISION_F32SPLIT = 2 /* fp32 arithmetic on the bf16 matrix pipe: each fp32 operand cut into THREE bf16 planes
+                               (8 + 8 + 8 significand bits = the fp32 value exactly), the six plane products above
+                               2^-24 of the leading one on v_mfma_f32_16x16x32_bf16, summed per 32-k step from zero
+                               and added to the fp32 accumulator once per step.  Measured error against fp64 no
+                               larger than the fp32 pipe's own on every parity distribution; kernels
+                               that have no split form yet run exactly as in OFFK_PRECISION_FP32. */
 };
 
 typedef struct offk_config {
@@ -189,6 +195,10 @@ int offk_sobel_tdiff_all(offk_handle* h, void* stream, void* workspace, int algo
 
 /* K1+K2 for all nine sites into the workspace fusion buffers (two grouped launches). */
 int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace);
+/* The units exactly as offk_forward runs them (ABI v9): the fused form when OFFK_FUSED_UNITS is on -- the 1x1 reduces with the
+ * temporal difference in one kernel (T and S straight into the fusion_<28|14|7> regions, D_<site> filled, G_<site> NOT) --
+ * in the handle's arithmetic (OFFK_PRECISION_F32SPLIT: the split-fp32 kernel).  For stage tests and profiling. */
+int offk_off_units_fused(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace);
 
 /* K4. Generic channels-last convolution (the fusion convs, RGB_OFF.py:657-685,762-780,
  * 833-841): y = post( pre(conv(in(x)) + bias) + res ).  x,y,res are channel-sliced views

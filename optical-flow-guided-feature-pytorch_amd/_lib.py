@@ -12,7 +12,7 @@ STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7",
 CONV_RELU_IN, CONV_RELU_PRE, CONV_RELU_POST = 1, 2, 4
 CONV_WINO7_FUSED = 256      # offk_winograd_conv7x7s2: the input transform inside the GEMM kernel (winograd7_fused.hip)
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "f32split": 2}
 
 
 class OffkError(RuntimeError):
@@ -59,6 +59,7 @@ SIGNATURES = {
     "offk_sobel_tdiff": (_I, [_P, _P, _I, _F, _F, _F, _I, _I, _I]),
     "offk_sobel_tdiff_all": (_I, [_P, _P, _P, _I]),
     "offk_off_units": (_I, [_P, _P, _c.POINTER(_F), _P]),
+    "offk_off_units_fused": (_I, [_P, _P, _c.POINTER(_F), _P]),
     "offk_conv2d": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I]),
     "offk_conv2d_ex": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I,
                             _I, _I, _F, _c.c_size_t, _I]),
@@ -103,7 +104,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 8:
+    if lib.offk_abi_version() != 9:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

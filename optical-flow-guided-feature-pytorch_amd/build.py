@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "liboffk.so")
 SOURCES = ("offk_api.hip", "pw_reduce.hip", "sobel_tdiff.hip", "conv_igemm.hip", "heads.hip", "units_bwd.hip", "pw_tdiff.hip",
-           "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "winograd7_fused.hip")
+           "pw_tdiff_split.hip", "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "winograd7_fused.hip")
 HEADERS = ("offk_common.h", "offk_internal.h", "winograd_common.h", os.path.join("..", "..", "include", "offk.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
@@ -28,7 +28,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # conv_igemm.hip: its LDS-DMA inline asm writes m0 and says so in the clobber list (the compiler must not assume an m0 value
 # of its own survives the statement); clang answers every such statement with "clobber list contains reserved registers".
 EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"], "units_bwd.hip": ["-fno-slp-vectorize"],
-               "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"],
+               "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"], "pw_tdiff_split.hip": ["-Wno-inline-asm"],
                "chain_fused.hip": ["-Wno-inline-asm"]}
 
 
@@ -113,6 +113,12 @@ def _llvm_readelf():
     return p if os.path.exists(p) else shutil.which("llvm-readelf")
 
 
+def _cxxfilt():
+    """The demangler that ships beside llvm-objdump / llvm-readelf, then whatever PATH has (a bare `c++filt`)."""
+    p = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    return p if os.path.exists(p) else (shutil.which("llvm-cxxfilt") or shutil.which("c++filt"))
+
+
 def kernel_resources(code_object):
     """[{name (demangled), vgpr_count, agpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size}] of one code object."""
     r = subprocess.run([_llvm_readelf(), "--notes", code_object], capture_output=True, text=True)
@@ -126,11 +132,57 @@ def kernel_resources(code_object):
                     "vgpr_spill_count": int(field("vgpr_spill_count")), "sgpr_spill_count": int(field("sgpr_spill_count")),
                     "private_segment_fixed_size": int(field("private_segment_fixed_size"))})
     if out:
-        d = subprocess.run(["c++filt"] + [k["mangled"] for k in out], capture_output=True, text=True)
-        names = d.stdout.splitlines() if d.returncode == 0 else []
+        d = subprocess.run([_cxxfilt()] + [k["mangled"] for k in out], capture_output=True, text=True)
+        names = d.stdout.splitlines()
+        if d.returncode != 0 or len(names) != len(out):
+            raise RuntimeError("%s failed on the kernel names of %s: %s" % (_cxxfilt(), code_object, d.stderr.strip()))
         for i, k in enumerate(out):
-            k["name"] = names[i] if i < len(names) else k["mangled"]
+            k["name"] = names[i]
     return out
+
+
+# ---- counted waits that leave STORES in flight --------------------------------------------------------------------
+# wino_gemm_kernel ends an item with sixteen buffer stores and `s_waitcnt vmcnt(16)`: "everything but my sixteen newest operations has
+# completed" is read as "the next tile's LDS-DMA loads have landed".  That rests on (1) vmcnt counting loads and stores of one wave in
+# issue order and decrementing in that order (CDNA ISA, "Data dependency resolution": memory reads and writes return in the order
+# they were issued for VM_CNT; only loads that return data out of order -- none here: no MUBUF load is in flight behind the stores --
+# break it) and (2) hipcc emitting exactly sixteen VMEM instructions, all of them stores, between the last DMA and the wait.  (2) is
+# checked here on the disassembly: for every `s_waitcnt vmcnt(N)` of a kernel listed below, the N VMEM instructions in front of it
+# must all be buffer stores.
+# (source file, regex on the MANGLED symbol, N)
+COUNTED_STORE_WAITS = (("wino_gemm.hip", r"wino_gemm_kernel", 16),)
+_VMEM_RE = re.compile(r"^\s*(buffer_|global_|flat_|scratch_)\w+")
+
+
+def check_counted_store_waits(src_name, code_objects):
+    rows = []
+    for src, pat, n in COUNTED_STORE_WAITS:
+        if src != src_name:
+            continue
+        found = 0
+        for path in code_objects:
+            d = subprocess.run([_llvm_objdump(), "-d", path], capture_output=True, text=True)
+            body, inside = [], False
+            for ln in d.stdout.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+                if m:
+                    inside = re.search(pat, m.group(1)) is not None
+                    continue
+                if inside:
+                    body.append(ln.split("//")[0].strip())
+            for i, ins in enumerate(body):
+                if not re.match(r"s_waitcnt\b.*vmcnt\(%d\)" % n, ins):
+                    continue
+                found += 1
+                vm = [b for b in body[:i] if _VMEM_RE.match(b)][-n:]
+                bad = [b for b in vm if not b.startswith("buffer_store_dword")]
+                if len(vm) < n or bad:
+                    raise RuntimeError("counted-wait guard failed in %s (%s): the %d VMEM instructions in front of `%s` must all be buffer "
+                                       "stores, found %s" % (src_name, pat, n, ins, bad[:3] or "only %d" % len(vm)))
+        if not found:
+            raise RuntimeError("counted-wait guard: no `s_waitcnt vmcnt(%d)` found in %s of %s (renamed? update COUNTED_STORE_WAITS)" % (n, pat, src_name))
+        rows.append((src, pat, n, found))
+    return rows
 
 
 def check_resources(src_name, kernels):
@@ -161,11 +213,11 @@ def check_resources(src_name, kernels):
 
 def check_object(obj):
     """ISA check + resource guard of one freshly compiled object."""
-    if _llvm_objdump() is None or _llvm_readelf() is None:
+    if _llvm_objdump() is None or _llvm_readelf() is None or _cxxfilt() is None:
         if os.environ.get("OFFK_SKIP_ISA_CHECK") == "1":
-            print("WARNING: llvm-objdump / llvm-readelf not found, checks of %s SKIPPED (OFFK_SKIP_ISA_CHECK=1)" % obj, file=sys.stderr)
+            print("WARNING: llvm-objdump / llvm-readelf / llvm-cxxfilt not found, checks of %s SKIPPED (OFFK_SKIP_ISA_CHECK=1)" % obj, file=sys.stderr)
             return
-        raise RuntimeError("llvm-objdump / llvm-readelf not found: cannot run the op_sel ISA check (DESIGN.md section 8) and the "
+        raise RuntimeError("llvm-objdump / llvm-readelf / llvm-cxxfilt (or c++filt) not found: cannot run the op_sel ISA check and the "
                            "resource guard; OFFK_SKIP_ISA_CHECK=1 builds without them")
     cos = _code_objects(obj)
     try:
@@ -173,6 +225,7 @@ def check_object(obj):
         src = os.path.basename(obj).replace(".o", ".hip")
         kernels = [k for co in cos for k in kernel_resources(co)]
         check_resources(src, kernels)
+        check_counted_store_waits(src, cos)
     finally:
         for path in cos:
             os.remove(path)

@@ -27,8 +27,8 @@ static hipError_t wino_gemms_launch(const WinoGroup* grp, int ngrp, int npoints,
       a.g_batch[gi] = grp[gi].batch; a.g_K[gi] = grp[gi].kmul * Ci;
       a.g_x[gi] = grp[gi].v_off; a.g_w[gi] = grp[gi].u_off; a.g_y[gi] = grp[gi].m_off;
     }
-    hipError_t e = wino_gemm_launch(a, s);
-    if (e != hipErrorInvalidValue) return e;      // a shape the persistent kernel does not take: the generic one
+    if (wino_gemm_supported(a)) return wino_gemm_launch(a, s);     // every error of the launch itself goes to the caller
+    // a shape the persistent kernel does not take: the generic one
   }
   const int K0 = grp[0].kmul * Ci;
   ConvDesc d;
@@ -156,6 +156,9 @@ struct offk_handle {
   float* pw_wb3[kNumSites] = {}; // bf16x3 mode: the same matrix pre-split per K-tile (hi 32 | lo 32)
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
+  float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
+  bool f32split = false;            // created with OFFK_PRECISION_F32SPLIT: cfg.precision is OFFK_PRECISION_FP32 inside the library, the
+                                    // kernels that have a split form take it
   bool pw_dirty = true;
   float* pw_b[kNumSites] = {};   // [160]
   float* dw_w[kNumSites] = {};   // [9][32]
@@ -524,6 +527,8 @@ int finalize_pw(offk_handle* h, hipStream_t st) {
     for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct_launch(h->pw_w[s], kSites[s].C, 1, h->pw_wt[s], st));
   else
     for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16[s], st));
+  if (h->f32split)
+    for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_split16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16s[s], st));
   h->pw_dirty = false;
   return OFFK_OK;
 }
@@ -570,6 +575,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   pt.zeros = h->zero_page;
   // the operand-order weight image is the library's own copy: not with contraction weights bound in place
   pt.bdirect = 1;
+  pt.f32split = h->f32split;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
@@ -583,6 +589,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
     pw_weight_ptrs(h, s, pt.presplit, &o.w, &o.w_down, &o.bias, &o.bias_down);
     o.wt = h->pw_wt[s];
     o.wt16 = h->pw_wt16[s];
+    o.wt16s = h->pw_wt16s[s];
     o.D = region(h, ws, (std::string("D_") + kSites[s].name).c_str());
     o.M = region(h, ws, fus[kSiteFusion[s]]);
     o.m_cs = kFusionC[kSiteFusion[s]]; o.m_coff = kSiteCoff[s];
@@ -690,7 +697,8 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   if (cfg->slice_mode != OFFK_SLICE_REFERENCE_FLAT && cfg->slice_mode != OFFK_SLICE_PER_CLIP) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad slice_mode");
   if (cfg->consensus != OFFK_CONSENSUS_NONE && cfg->consensus != OFFK_CONSENSUS_AVG) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad consensus");
   if (cfg->feat_layout != OFFK_FEAT_NCHW && cfg->feat_layout != OFFK_FEAT_NHWC) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad feat_layout");
-  if (cfg->precision != OFFK_PRECISION_FP32 && cfg->precision != OFFK_PRECISION_BF16X3) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad precision");
+  if (cfg->precision != OFFK_PRECISION_FP32 && cfg->precision != OFFK_PRECISION_BF16X3 && cfg->precision != OFFK_PRECISION_F32SPLIT)
+    return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad precision");
   if (cfg->num_classes < 1 || cfg->num_classes > 4096) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad num_classes");
   if ((long long)cfg->batch * cfg->length * 784 * 320 > 0x7fffffffLL) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: batch*length too large for one call; shard the clips");
   int ndev = 0;
@@ -702,6 +710,9 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
 
   offk_handle* h = new offk_handle();
   h->cfg = *cfg;
+  offk_config cfg_in = *cfg;
+  if (cfg_in.precision == OFFK_PRECISION_F32SPLIT) { h->f32split = true; h->cfg.precision = cfg_in.precision = OFFK_PRECISION_FP32; }
+  cfg = &cfg_in;        // below: the library's own view (split-fp32 = the fp32 plans and buffers + the split kernels' weight images)
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
   for (int c = 0; c < kNumConvs; ++c) {
@@ -728,6 +739,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wb3[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wt[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_FP32) rc = dev_alloc(h, &h->pw_wt16[s], (size_t)kUnitCh * C);
+    if (rc == OFFK_OK && h->f32split) rc = dev_alloc(h, &h->pw_wt16s[s], (size_t)kUnitCh * C * 3 / 2);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
     if (cfg->variant == OFFK_VARIANT_RGB_LEARNED_DW && rc == OFFK_OK) {
       add_slot(h, "motion_spatial_grad_" + n + ".weight", {kDownCh, 1, 3, 3}, SK_DW_W, s);
@@ -1080,6 +1092,19 @@ int offk_off_units(offk_handle* h, void* stream, const float* const feats[OFFK_N
   DeviceGuard guard(h->cfg.device);
   offk_feat_parts parts[kNumSites];
   for (int s = 0; s < kNumSites; ++s) parts[s] = whole_map(s, feats[s]);
+  return run_off_units(h, static_cast<hipStream_t>(stream), parts, workspace, nullptr);
+}
+
+int offk_off_units_fused(offk_handle* h, void* stream, const float* const feats[OFFK_NUM_SITES], void* workspace) {
+  if (!h || !feats || !workspace) return fail(h, OFFK_ERR_INVALID, "offk_off_units_fused: null argument");
+  for (int s = 0; s < kNumSites; ++s) {
+    if (!feats[s]) return fail(h, OFFK_ERR_INVALID, "offk_off_units_fused: null feature map");
+    TRY(site_weights_ready(h, s, true, true));
+  }
+  DeviceGuard guard(h->cfg.device);
+  offk_feat_parts parts[kNumSites];
+  for (int s = 0; s < kNumSites; ++s) parts[s] = whole_map(s, feats[s]);
+  if (h->fused_units && h->cfg.feat_layout != OFFK_FEAT_NHWC) return run_off_units_fused(h, static_cast<hipStream_t>(stream), parts, workspace, nullptr);
   return run_off_units(h, static_cast<hipStream_t>(stream), parts, workspace, nullptr);
 }
 

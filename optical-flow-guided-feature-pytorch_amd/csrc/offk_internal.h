@@ -86,6 +86,7 @@ struct WinoGemmArgs {
   long long g_x[4], g_w[4], g_y[4];
   int gm, gn, total_items;     // filled by wino_gemm_launch
 };
+bool wino_gemm_supported(const WinoGemmArgs& a);
 hipError_t wino_gemm_launch(const WinoGemmArgs& a, hipStream_t st);
 // ---- K4m: output transform -> (1x1 conv + ReLU) -> input transform between two Winograd convs on 7x7 maps, one launch (wino_mid.hip)
 struct WinoMidArgs {
@@ -155,6 +156,7 @@ struct PtSite {
   const float* w_down;  // down rows [32][C]
   const float* wt;      // PtParams.bdirect: all 160 rows packed in MFMA-operand order (pw_pack_direct_launch), read straight into registers
   const float* wt16;    // the same rows in the operand order of the 16-pixel form (pw_pack_direct16_launch)
+  const void* wt16s;    // PtParams.f32split: the rows as three bf16 planes in the operand order of pw_tdiff_split_kernel (pw_pack_split16_launch)
   const float* bias;    // [128]
   const float* bias_down;   // [32]
   float* D;             // [P*HW][32]
@@ -178,6 +180,7 @@ struct PtParams {
   int nsites, total_blocks;
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
+  int f32split;              // precision 0 with bdirect: the split-fp32 form (pw_tdiff_split.hip) instead of pw_tdiff16_kernel
   int bdirect;               // every site carries wt / wt16: the weight operand bypasses LDS.  Exact fp32 then runs the 16-pixel LDS-DMA
                              // form (pw_tdiff16_kernel), bf16x3 the register-staged kernel with two LDS stages for the feature-map tile
   const float* zeros;
@@ -190,6 +193,9 @@ hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);
 // w160: [160][C] fp32 (gen rows, then down rows) -> out (160 * C floats), the operand-order image pw_tdiff reads with bdirect
 hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float* out, hipStream_t st);
 hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStream_t st);
+// pw_tdiff_split.hip: out = 160 * C * 6 bytes; p with the 16-pixel form's block layout (pw_tdiff_launch fills it and calls this)
+hipError_t pw_pack_split16_launch(const float* w160, int C, void* out, hipStream_t st);
+hipError_t pw_tdiff_split_launch(const PtParams& p, hipStream_t st);
 
 // ---- K2 ------------------------------------------------------------------------
 struct StSite {

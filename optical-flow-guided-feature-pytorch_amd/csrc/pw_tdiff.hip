@@ -943,6 +943,7 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); \
   else hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);
 #endif
+  if (form16 && p.f32split) return pw_tdiff_split_launch(p, st);
   if (p.precision == 0) { OFFK_PT_LAUNCH(0, kStage32) } else { OFFK_PT_LAUNCH(1, kStageB3) }
 #undef OFFK_PT_LAUNCH
 #undef OFFK_PT_LAUNCH_BD

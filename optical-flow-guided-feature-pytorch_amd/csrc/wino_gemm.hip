@@ -203,20 +203,28 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(WinoGemmArgs p) {
   }
 }
 
-hipError_t wino_gemm_launch(const WinoGemmArgs& a_in, hipStream_t st) {
-  WinoGemmArgs a = a_in;
-  if (a.M <= 0 || a.Co % WG_BN || a.ngroups < 1 || a.ngroups > 4) return hipErrorInvalidValue;
-  int problems = 0;
+// shapes the persistent kernel takes (everything else goes to the generic kernel -- wino_gemms_launch in offk_api.hip); a HIP error
+// of the launch itself is never read as "unsupported" 
+bool wino_gemm_supported(const WinoGemmArgs& a) {
+  if (a.M <= 0 || a.Co % WG_BN || a.ngroups < 1 || a.ngroups > 4) return false;
+  long long problems = 0;
   for (int g = 0; g < a.ngroups; ++g) {
-    if (a.g_K[g] % 32 || a.g_K[g] <= 0 || (long long)a.M * a.g_K[g] * 4 >= 0x7fffff00ll || (long long)a.Co * a.g_K[g] * 4 >= 0x7fffff00ll) return hipErrorInvalidValue;
+    if (a.g_K[g] % 32 || a.g_K[g] <= 0 || (long long)a.M * a.g_K[g] * 4 >= 0x7fffff00ll || (long long)a.Co * a.g_K[g] * 4 >= 0x7fffff00ll) return false;
     problems += a.g_batch[g];
   }
-  if ((long long)a.M * a.Co * 4 >= 0x7f000000ll) return hipErrorInvalidValue;
+  if ((long long)a.M * a.Co * 4 >= 0x7f000000ll) return false;
+  const long long total = problems * ((a.M + WG_BM - 1) / WG_BM) * (a.Co / WG_BN);
+  return total > 0 && total < (1ll << 30);
+}
+
+hipError_t wino_gemm_launch(const WinoGemmArgs& a_in, hipStream_t st) {
+  WinoGemmArgs a = a_in;
+  if (!wino_gemm_supported(a)) return hipErrorInvalidValue;
+  int problems = 0;
+  for (int g = 0; g < a.ngroups; ++g) problems += a.g_batch[g];
   a.gm = (a.M + WG_BM - 1) / WG_BM;
   a.gn = a.Co / WG_BN;
-  const long long total = (long long)problems * a.gm * a.gn;
-  if (total <= 0 || total >= (1ll << 30)) return hipErrorInvalidValue;
-  a.total_items = (int)total;
+  a.total_items = (int)((long long)problems * a.gm * a.gn);
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_gemm_kernel), WG_LDS);
   if (e != hipSuccess) return e;
   const int grid = a.total_items < WG_RESIDENT ? a.total_items : WG_RESIDENT;

@@ -121,7 +121,8 @@ __device__ __forceinline__ void mid_in_class(const WinoMidArgs& a, int img, int 
 // second time): P = 384 images alone are 1.5 blocks per CU, and a 256 -> 256 block is 33 k cycles of MFMAs per wave.
 template <int CIN, int CMID, bool GEMM, int NPH, int NS>
 __global__ __launch_bounds__(256, 2) void wino_mid_kernel(WinoMidArgs a) {
-  static_assert(CIN % 64 == 0 && CMID % (64 * NS) == 0 && (GEMM || (CIN == CMID && NS == 1)), "whole waves of channels");
+  // (CIN % 128: mid_out_class walks the channel groups of 64 two at a time)
+  static_assert(CIN % 128 == 0 && CMID % (64 * NS) == 0 && (GEMM || (CIN == CMID && NS == 1)), "whole waves of channels");
   constexpr int CM = CMID / NS;                                   // output channels of this block
   extern __shared__ __attribute__((aligned(16))) char lds[];      // [64 slots][max(CIN, CM)] fp32: x, then t in the same place
   const int img = blockIdx.x;
@@ -132,6 +133,11 @@ __global__ __launch_bounds__(256, 2) void wino_mid_kernel(WinoMidArgs a) {
   // ---- stage A: wave w = class w (its 6x6 / 6x5 / 5x6 / 5x5 points), every channel group; the activation goes to HBM from the first
   //      of the NS blocks ----
   float* const xg = blockIdx.y == 0 ? a.x : nullptr;
+  if constexpr (GEMM) {
+    // pixel slots 49 .. 63 of the x tile: stage A never writes them and stage B multiplies them (MFMA columns that are dropped behind
+    // it) -- zeroed so that no uninitialised LDS word is ever read
+    for (int i = tid; i < 15 * CIN / 4; i += 256) reinterpret_cast<f32x4*>(lds + 49 * (CIN * 4))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   switch (wave) {
     case 0: mid_out_class<NPH, 0, 0, CIN>(a, img, lane, lds, xg); break;
     case 1: mid_out_class<NPH, 0, 1, CIN>(a, img, lane, lds, xg); break;

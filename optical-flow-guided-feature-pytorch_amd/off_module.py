@@ -327,7 +327,7 @@ class BNInception_OFF(nn.Module):
         wants_grad = torch.is_grad_enabled() and fgs is not None and fgs.requires_grad
         if fgs is not None and fgs.shape[0] == self.batch * self.length:
             if wants_grad:
-                fgs = fgs.float().view(self.batch, self.length, -1).mean(dim=1)          # basic_ops.py:19-21
+                fgs = fgs.float().reshape(self.batch, self.length, -1).mean(dim=1)          # basic_ops.py:19-21
             else:
                 fgs = runtime.segment_consensus(fgs.contiguous().float(), self.batch)   # Flow_OFF.py:867,873 (K6)
         if self.modality_fuse:

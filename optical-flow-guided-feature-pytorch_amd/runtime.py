@@ -192,6 +192,11 @@ class OffForward:
         arr = self._feat_array(feats)
         _lib.check(self.lib.offk_off_units(self._h, _stream(self.device), arr, _ptr(self.workspace)), self._h)
 
+    def off_units_fused(self, feats):
+        """The units as forward() runs them (fused K1T + S-blocks, the handle's arithmetic); results in the fusion_* / D_* regions."""
+        arr = self._feat_array(feats)
+        _lib.check(self.lib.offk_off_units_fused(self._h, _stream(self.device), arr, _ptr(self.workspace)), self._h)
+
     # ---- training side of the units (SURVEY.md 8(f) rank 4) ----------------------------
     def off_units_train(self, feats, drop_seed=0, drop_p=0.8):
         """K1+K2 in training mode: nn.Dropout(p) (RGB_OFF.py:356, :612) on the spatial gradients with the

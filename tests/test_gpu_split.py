@@ -1,0 +1,156 @@
+"""Split-fp32 arithmetic (OFFK_PRECISION_F32SPLIT, round 5): fp32 operands as three bf16 planes on the bf16 matrix pipe.
+
+The claim these tests pin: the split kernels are fp32 arithmetic in the sense that matters for parity -- against an fp64
+contraction of the same fp32 inputs their error is NO LARGER than the error of the library's own fp32-pipe kernels
+(v_mfma_f32_16x16x4_f32 / 32x32x2_f32: a chain of fp32 FMAs) -- on every input distribution the parity suite uses: the
+synthetic maps, 24-bit mantissas, a heavy tail, and the cancellation case.  Reference arithmetic: RGB_OFF.py:597-610 (fp32
+nn.Conv2d); the tolerance north_star states is 1e-3 relative, both modes sit four orders inside it.
+
+Reported per mode (print, -s shows it; bench.py carries the same numbers in `f32split_mode.error_vs_fp64`):
+    max |err| / max |ref|, rms err / max |ref|, and c of |err| <= c 2^-24 sum_k |w_k x_k| (max and rms over elements).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import offk_amd  # noqa: F401
+from offk_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -24
+KINDS = ["synth", "full_mantissa", "heavy_tail"]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from offk_amd import runtime
+    return runtime
+
+
+def dev(x):
+    return torch.as_tensor(x).to("cuda").contiguous()
+
+
+def make_handle(rt, B, L, precision, weights=None, variant=spec.VARIANT_RGB):
+    h = rt.OffForward(B, L, variant, spec.SLICE_FLAT, None, precision=precision)
+    w = synth.make_weights(variant) if weights is None else weights
+    assert h.load_state_dict(w) == []
+    return h, w
+
+
+def units_reference_fp64(feats, w, B, L):
+    """Per site: (T, magT, D, magD) in fp64.  T[b (L-1) + t] = relu(G)[b L + t + 1] - relu(G)[b L + t]  (RGB_OFF.py:597-604),
+    D = down(X[:P]) (quirk Q1, :609-610); mag = sum_k |w_k x_k| (+ |bias|), for T the two frames' magnitudes added."""
+    out = []
+    P = B * (L - 1)
+    for (name, C, H), x in zip(spec.SITES, feats):
+        xd = torch.from_numpy(x).double()
+        wg = torch.from_numpy(w["motion_conv_gen_%s.weight" % name]).double()
+        bg = torch.from_numpy(w["motion_conv_gen_%s.bias" % name]).double()
+        wd = torch.from_numpy(w["motion_spatial_down_%s.weight" % name]).double()
+        bd = torch.from_numpy(w["motion_spatial_down_%s.bias" % name]).double()
+        G = torch.relu(F.conv2d(xd, wg, bg)).view(B, L, 128, H, H)
+        mG = (F.conv2d(xd.abs(), wg.abs()) + bg.abs().view(1, -1, 1, 1)).view(B, L, 128, H, H)
+        T = (G[:, 1:] - G[:, :-1]).reshape(P, 128, H, H)
+        mT = (mG[:, 1:] + mG[:, :-1]).reshape(P, 128, H, H)
+        D = F.conv2d(xd[:P], wd, bd)
+        mD = F.conv2d(xd[:P].abs(), wd.abs()) + bd.abs().view(1, -1, 1, 1)
+        out.append((T, mT, D, mD))
+    return out
+
+
+def units_outputs(h, B, L):
+    """(T, D) per site as the fused units left them: T in the fusion buffers (channels coff + 32 .. coff + 160), D in D_<site>."""
+    P = B * (L - 1)
+    res = []
+    for fkey, fd in spec.FUSION.items():
+        width = 160 * len(fd["sites"]) + fd["carry"]
+        buf = h.region("fusion_" + fkey, width).view(P, fd["H"], fd["H"], width)
+        for i, sname in enumerate(fd["sites"]):
+            T = buf[..., 160 * i + 32:160 * i + 160].permute(0, 3, 1, 2).double().cpu()
+            D = h.region("D_" + sname, 32).view(P, fd["H"], fd["H"], 32).permute(0, 3, 1, 2).double().cpu()
+            res.append((T, D))
+    return res
+
+
+def error_stats(pairs):
+    """pairs: [(got, ref, mag)] -> dict of the four numbers, over all elements of all tensors (each tensor normalised by its own max)."""
+    mx, cmx, se, sc, n = 0.0, 0.0, 0.0, 0.0, 0
+    for got, ref, mag in pairs:
+        e = (got - ref).abs()
+        s = ref.abs().max().clamp_min(1e-30)
+        c = e / (mag.clamp_min(1e-30) * EPS)
+        mx = max(mx, (e.max() / s).item())
+        cmx = max(cmx, c.max().item())
+        se += ((e / s) ** 2).sum().item()
+        sc += (c ** 2).sum().item()
+        n += e.numel()
+    return {"max_over_max": mx, "rms_over_max": (se / n) ** 0.5, "c_max": cmx, "c_rms": (sc / n) ** 0.5}
+
+
+def run_units(rt, B, L, precision, feats_np, weights=None):
+    h, w = make_handle(rt, B, L, precision, weights)
+    h.off_units_fused([dev(f) for f in feats_np])
+    torch.cuda.synchronize()
+    return units_outputs(h, B, L), w
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind):
+    B, L = 2, 7
+    feats_np = synth.make_features_kind(B, L, 4, kind)
+    stats = {}
+    ref = None
+    for prec in ("fp32", "f32split"):
+        outs, w = run_units(rt, B, L, prec, feats_np)
+        if ref is None:
+            ref = units_reference_fp64(feats_np, w, B, L)
+        pairs = []
+        for (T, D), (Tr, mT, Dr, mD) in zip(outs, ref):
+            pairs += [(T, Tr, mT), (D, Dr, mD)]
+        stats[prec] = error_stats(pairs)
+        print("units %-8s on %-13s maps vs fp64: max %.3e  rms %.3e  c_max %.3f  c_rms %.4f"
+              % (prec, kind, stats[prec]["max_over_max"], stats[prec]["rms_over_max"], stats[prec]["c_max"], stats[prec]["c_rms"]))
+    for key in ("max_over_max", "rms_over_max", "c_max", "c_rms"):
+        assert stats["f32split"][key] <= stats["fp32"][key], (kind, key, stats)
+    assert stats["f32split"]["max_over_max"] < 2e-6 and stats["f32split"]["c_max"] < 16.0
+
+
+def test_units_split_cancellation_case(rt):
+    """tests/test_gpu_parity.py::test_pw_reduce_cancellation_case on the fused kernels: every channel of a pixel carries the
+    same value and every weight row sums to zero -- the exact G is relu(bias), the exact T is 0, the exact D is the bias."""
+    B, L = 2, 7
+    wnp = synth.make_weights(spec.VARIANT_RGB)
+    for name, _C, _H in spec.SITES:
+        for key in ("motion_conv_gen_%s.weight" % name, "motion_spatial_down_%s.weight" % name):
+            wk = wnp[key].astype(np.float64)
+            wnp[key] = (wk - wk.mean(axis=1, keepdims=True)).astype(np.float32)
+    base = synth.make_features_kind(B, L, 4, "heavy_tail")
+    feats_np = [np.ascontiguousarray(np.broadcast_to(f[:, :1] + np.float32(0.5), f.shape)) for f in base]
+    stats, ref = {}, None
+    for prec in ("fp32", "f32split"):
+        outs, w = run_units(rt, B, L, prec, feats_np, wnp)
+        if ref is None:
+            ref = units_reference_fp64(feats_np, w, B, L)
+        pairs = [(D, Dr, mD) for (_T, D), (_Tr, _mT, Dr, mD) in zip(outs, ref)]
+        stats[prec] = error_stats(pairs)
+        print("units %-8s cancellation case (D rows) vs fp64: max err / max|out| %.3e  c_max %.3f  c_rms %.4f"
+              % (prec, stats[prec]["max_over_max"], stats[prec]["c_max"], stats[prec]["c_rms"]))
+    for key in ("max_over_max", "rms_over_max", "c_max", "c_rms"):
+        assert stats["f32split"][key] <= stats["fp32"][key], (key, stats)
+    assert stats["f32split"]["c_max"] < 4.0
+
+
+@pytest.mark.parametrize("B,L", [(1, 2), (3, 3), (2, 9), (5, 7)])
+def test_units_split_shapes(rt, B, L):
+    """Short clips (frames past the group read zeros), two temporal groups (L = 9), odd batches (packed 14x14 leftovers, the 7x7
+    quad stream crossing clip boundaries): every T and D element against fp64."""
+    feats_np = synth.make_features(B, L, 5)
+    outs, w = run_units(rt, B, L, "f32split", feats_np)
+    ref = units_reference_fp64(feats_np, w, B, L)
+    for (name, _C, _H), (T, D), (Tr, _mT, Dr, _mD) in zip(spec.SITES, outs, ref):
+        assert ((T - Tr).abs().max() / Tr.abs().max()).item() < 2e-6, name
+        assert ((D - Dr).abs().max() / Dr.abs().max()).item() < 2e-6, name

@@ -16,7 +16,7 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 pat = sys.argv[4] if len(sys.argv) > 4 else ""
 variant = spec.VARIANT_RGB
-h = runtime.OffForward(B, L, variant)
+h = runtime.OffForward(B, L, variant, precision=os.environ.get("OFFK_PRECISION", "fp32"))
 h.load_state_dict(synth.make_weights(variant))
 feats = [torch.from_numpy(f).cuda() for f in synth.make_features(B, L, 2)]
 arr = h._feat_array(feats)
