@@ -28,7 +28,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # conv_igemm.hip: its LDS-DMA inline asm writes m0 and says so in the clobber list (the compiler must not assume an m0 value
 # of its own survives the statement); clang answers every such statement with "clobber list contains reserved registers".
 EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"], "units_bwd.hip": ["-fno-slp-vectorize"],
-               "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"], "pw_tdiff_split.hip": ["-Wno-inline-asm"],
+               "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"], "pw_tdiff_split.hip": ["-Wno-inline-asm", "-fno-slp-vectorize"],
                "chain_fused.hip": ["-Wno-inline-asm"]}
 
 

@@ -844,6 +844,9 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
               hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
       fprintf(stderr, "[pt timing, dma form, wave 0 cycles] prologue %llu loop %llu epilogue+drain %llu | in loop: dma-issue+mma %llu dma-wait %llu barrier %llu | ktiles %llu blocks %llu\n",
               hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
+      if (hb[18])
+        fprintf(stderr, "[pt timing, split form, wave 0 cycles] prologue %llu loop %llu epilogue+drain %llu | per step: dma-issue %llu wait-Wg %llu gen pass %llu wait-Wd %llu "
+                "down pass + cut %llu barrier %llu | ktiles %llu blocks %llu\n", hb[8], hb[9], hb[10], hb[11], hb[12], hb[13], hb[14], hb[15], hb[16], hb[17], hb[18]);
       (void)hipMemset(dbg, 0, 256);
     }
   }

@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, lg = lane >> 4;
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 8)      /* experiment: every other block of 256 starts half a step late */
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(44);
+#endif
 
   // ---- DMA: slot q = wave + 4 i (i = 0..3) = frame q >> 1, k half q & 1 (= wave & 1); slots 14, 15 read zeros.  Lane l of a piece
   //      fetches k row 4 a + r (a = (l >> 2) & 3, r = l >> 4), pixel quad l & 3: row k sits at [k & 3][k >> 2] of the piece ----
@@ -100,10 +103,17 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   const int vrow0 = px_ok ? ((16 * (wave & 1) + 4 * ((lane >> 2) & 3) + (lane >> 4)) * HW + k0px) * 4 : (int)0x80000000;
   const int vclip = cq * L;
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 1)      /* timing experiment: the pieces as plain loads into a dummy register quad (results wrong) */
+  u32x4 dummy_x = {0u, 0u, 0u, 0u};
+  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dummy_x) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+  };
+#else
   auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
   };
+#endif
   i32x4 dm_desc = {0, 0, 0, 0};
   int dm_fstride = 0, dm_s0 = 0, dm_voff = 0;
   auto dma_prep = [&](int kt) {
@@ -121,13 +131,17 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
     dm_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;
     dm_voff = vrow0 + (int)__umul24((unsigned)vclip, (unsigned)dm_fstride);
   };
-  auto dma_tile = [&](const int rs) {       // the wave's four slots of the prepared K-tile into raw stage rs
+  auto dma_piece = [&](const int i, const int rs) {       // slot i of the wave, of the prepared K-tile, into raw stage rs
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 32)     /* timing experiment: no feature-map loads at all */
+    return;
+#endif
+    const int q = wave + 4 * i, fr = q >> 1;
+    const int voff = fr < nf ? dm_voff : (int)0x80000000;              // (slots 14, 15: fr = 7 >= nf)
+    dma16(dm_desc, lds_base + rs * PS_RAW_STAGE + wave * PS_RAW_WAVE + i * PS_PIECE, voff, dm_s0 + fr * dm_fstride);
+  };
+  auto dma_tile = [&](const int rs) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = wave + 4 * i, fr = q >> 1;
-      const int voff = fr < nf ? dm_voff : (int)0x80000000;            // (slots 14, 15: fr = 7 >= nf)
-      dma16(dm_desc, lds_base + rs * PS_RAW_STAGE + wave * PS_RAW_WAVE + i * PS_PIECE, voff, dm_s0 + fr * dm_fstride);
-    }
+    for (int i = 0; i < 4; ++i) dma_piece(i, rs);
   };
 
   // ---- the cut: lane (pixel li, a = lg) of piece i holds k = 16 (wave & 1) + 4 a + 0..3 of frame (wave + 4 i) >> 1 ----
@@ -135,73 +149,91 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   // planes: g = 2 (wave & 1) + (a >> 1), 8-byte half a & 1 of the lane's 16 B
   char* const pl_wr = planes + (2 * (wave & 1) + (lg >> 1)) * 256 + li * 16 + (lg & 1) * 8;   // + stage, + frame, + plane
   char* const pl_dummy = lds + wave * PS_RAW_WAVE + 3 * PS_PIECE + (pl_wr - planes);     // + raw stage: the wave's own fourth piece
-  auto cut_piece = [&](const int i, const int rs, const int ps) {
+  // half hf of piece i: k rows r = 2 hf, 2 hf + 1 of the lane's four -> one dword per plane
+  auto cut_half = [&](const int i, const int hf, const int rs, const int ps) {
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 4)      /* timing experiment: no cut */
+    if (i < 8) return;
+#endif
     const int fr = (wave + 4 * i) >> 1;      // slots 14, 15 (fr = 7: zeros) are cut like the others -- no branch in the MFMA stream (hipcc sinks
                                              // the accumulator updates across any block boundary) -- and land on the piece itself
-    const char* src = raw_rd + rs * PS_RAW_STAGE + i * PS_PIECE;
-    unsigned x[4], h[4], m[4], l[4];
+    const char* src = raw_rd + rs * PS_RAW_STAGE + i * PS_PIECE + hf * 512;
+    unsigned x[2], h[2], m[2], l[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const unsigned*>(src + r * 256);
+    for (int r = 0; r < 2; ++r) x[r] = *reinterpret_cast<const unsigned*>(src + r * 256);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 2; ++r) {
       h[r] = x[r] & 0xffff0000u;
       const float r1 = __uint_as_float(x[r]) - __uint_as_float(h[r]);
       m[r] = __float_as_uint(r1) & 0xffff0000u;
       l[r] = __float_as_uint(r1 - __uint_as_float(m[r]));               // <= 8 significant bits: its low half is zero
     }
     const bool real = i < 3 || fr < PS_FT;
-    char* dst = real ? pl_wr + ps * PS_PL_STAGE + fr * PS_FRAME : pl_dummy + rs * PS_RAW_STAGE;
+    char* dst = (real ? pl_wr + ps * PS_PL_STAGE + fr * PS_FRAME : pl_dummy + rs * PS_RAW_STAGE) + hf * 4;
     const int pstride = real ? PS_PLANE : 0;
-    *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302), __builtin_amdgcn_perm(h[3], h[2], 0x07060302)};
-    *reinterpret_cast<u32x2*>(dst + pstride) = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302), __builtin_amdgcn_perm(m[3], m[2], 0x07060302)};
-    *reinterpret_cast<u32x2*>(dst + 2 * pstride) = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302), __builtin_amdgcn_perm(l[3], l[2], 0x07060302)};
+    *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(h[1], h[0], 0x07060302);
+    *reinterpret_cast<unsigned*>(dst + pstride) = __builtin_amdgcn_perm(m[1], m[0], 0x07060302);
+    *reinterpret_cast<unsigned*>(dst + 2 * pstride) = __builtin_amdgcn_perm(l[1], l[0], 0x07060302);
   };
+  auto cut_piece = [&](const int i, const int rs, const int ps) { cut_half(i, 0, rs, ps); cut_half(i, 1, rs, ps); };
 
   // ---- weights: image [kt][slab (4 gen + 1 down)][ct][plane][lane] x 16 B (pw_pack_split16_kernel) ----
-  u32x4 wg[2][3], wd[2][3];                // gen [ct][plane], down [ct][plane]
+  u32x4 wg[2][2][3], wd[3];                // gen [set][ct][plane] (set = K-tile parity), down [plane] (the wave's ONE down channel tile)
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int q = 0; q < 3; ++q) {
+    wd[q] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { wg[c][q] = u32x4{0u, 0u, 0u, 0u}; wd[c][q] = u32x4{0u, 0u, 0u, 0u}; }
+    for (int c = 0; c < 2; ++c) { wg[0][c][q] = u32x4{0u, 0u, 0u, 0u}; wg[1][c][q] = u32x4{0u, 0u, 0u, 0u}; }
+  }
   i32x4 wdesc;
   {
     const unsigned long long wa = reinterpret_cast<unsigned long long>(S.wt);
     wdesc = i32x4{(int)(unsigned)wa, (int)(unsigned)(wa >> 32) & 0xffff, kUnitCh * C * 6, 0x00020000};
   }
   const int wlane = lane * 16;
-  auto load_wg = [&](int kt) {
+  // down tiles: wave w owns down channel tile w & 1 of frames (w >> 1) + 2 i, i = 0..3 (waves 2, 3: i = 3 is frame 6 again, never
+  // stored) -- every wave loading BOTH down tiles made the weight stream 48 KB per block and K-tile, 24 KB of it the down rows four times
+  const int ctd = wave & 1, fd0 = wave >> 1;
+  auto load_wg1 = [&](const int set, const int n, int kt) {       // n = ct * 3 + plane
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 2)      /* timing experiment: the same (cached) weight tile every time */
+    kt = 0;
+#endif
+    const int so = ((kt * 5 + wave) * 6 + n) * 1024;
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 16)     /* timing experiment: no weight loads inside the loop at all */
+    if (kt > 0) return;
+#endif
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wg[set][n / 3][n % 3]) : "v"(wlane), "s"(wdesc), "s"(so));
+  };
+  auto load_wg = [&](const int set, int kt) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int so = (((kt * 5 + wave) * 2 + ct) * 3 + q) * 1024;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wg[ct][q]) : "v"(wlane), "s"(wdesc), "s"(so));
-      }
+    for (int n = 0; n < 6; ++n) load_wg1(set, n, kt);
   };
   auto load_wd = [&](int kt) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int so = (((kt * 5 + 4) * 2 + ct) * 3 + q) * 1024;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wd[ct][q]) : "v"(wlane), "s"(wdesc), "s"(so));
-      }
+    for (int q = 0; q < 3; ++q) {
+      const int so = (((kt * 5 + 4) * 2 + ctd) * 3 + q) * 1024;
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 16)
+      if (kt > 0) continue;
+#endif
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wd[q]) : "v"(wlane), "s"(wdesc), "s"(so));
+    }
   };
-#define OFFK_WAIT_WG(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[0][0]), "+v"(wg[0][1]), "+v"(wg[0][2]), \
-                                     "+v"(wg[1][0]), "+v"(wg[1][1]), "+v"(wg[1][2]) :: "memory")
-#define OFFK_WAIT_WD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wd[0][0]), "+v"(wd[0][1]), "+v"(wd[0][2]), \
-                                     "+v"(wd[1][0]), "+v"(wd[1][1]), "+v"(wd[1][2]) :: "memory")
+#define OFFK_WAIT_WG(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[set][0][0]), "+v"(wg[set][0][1]), "+v"(wg[set][0][2]), \
+                                          "+v"(wg[set][1][0]), "+v"(wg[set][1][1]), "+v"(wg[set][1][2]) :: "memory")
+#define OFFK_WAIT_WD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]) :: "memory")
 
-  f32x4 ag[PS_FT][2], ad[2][2];
+  f32x4 ag[PS_FT][2], ad[4];
 #pragma unroll
   for (int j = 0; j < PS_FT; ++j) { ag[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { ad[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ad[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < 4; ++i) ad[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // B operand of frame f out of plane stage st: three ds_read_b128
   const char* const xrd = planes + lg * 256 + li * 16;
-  const int xoffA = wave * PS_FRAME, xoffB = min(wave + 4, PS_FT - 1) * PS_FRAME;
+  const int xoffD = fd0 * PS_FRAME, xoffD3 = min(fd0 + 6, PS_FT - 1) * PS_FRAME;     // down frames: xoffD + 2 i frames, the fourth clamped
   auto rdx = [&](u32x4 (&x)[3], const int st, int foff) {
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 256)    /* timing experiment: no operand reads but the step's first */
+    if (foff != 0) return;
+#endif
 #pragma unroll
     for (int q = 0; q < 3; ++q) x[q] = *reinterpret_cast<const u32x4*>(xrd + st * PS_PL_STAGE + foff + q * PS_PLANE);
   };
@@ -210,7 +242,11 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   };
   // the six products of one (frame, two channel tiles) unit, the two tiles' chains alternating; planes: 0 = h, 1 = m, 2 = l
   auto unit = [&](f32x4& t0, f32x4& t1, const u32x4 (&w0)[3], const u32x4 (&w1)[3], const u32x4 (&x)[3]) {
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 128)    /* timing experiment: the chains start at the scratch tiles' old values and nothing is folded */
+    const f32x4 z = t0;
+#else
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#endif
     t0 = mf(z, w0[2], x[0]);  t1 = mf(z, w1[2], x[0]);
     t0 = mf(t0, w0[0], x[2]); t1 = mf(t1, w1[0], x[2]);
     t0 = mf(t0, w0[1], x[1]); t1 = mf(t1, w1[1], x[1]);
@@ -219,76 +255,177 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
     t0 = mf(t0, w0[0], x[0]); t1 = mf(t1, w1[0], x[0]);
   };
 
+  auto unit1 = [&](f32x4& t0, const u32x4 (&w0)[3], const u32x4 (&x)[3]) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    t0 = mf(z, w0[2], x[0]);
+    t0 = mf(t0, w0[0], x[2]);
+    t0 = mf(t0, w0[1], x[1]);
+    t0 = mf(t0, w0[1], x[0]);
+    t0 = mf(t0, w0[0], x[1]);
+    t0 = mf(t0, w0[0], x[0]);
+  };
+
   const int nkt = C / BK;
-  // one step: tile kt out of plane stage ST; the cut of tile kt + 1 from raw stage ST ^ 1 into plane stage ST ^ 1; DMA of tile kt + 2
-  // into raw stage ST (its tile kt was cut during the last step).  Vector-memory operations per wave and step, in issue order:
-  // DMA(kt + 2) [4], Wg(kt + 1) [6] behind the gen pass, Wd(kt + 1) [6] behind the down pass.
+  // one step: tile kt out of plane stage ST, gen weights of set ST; the cut of tile kt + 1 from raw stage ST ^ 1 into plane stage ST ^ 1
+  // (eight half pieces: one beside each gen unit and the first down unit); DMA of tile kt + 2 into raw stage ST (its tile kt was cut
+  // during the last step).  The step's vector-memory instructions go out ONE OR TWO PER UNIT (all ten at the top of the step cost
+  // ~1200 cycles of issue per step: eight waves' 1-KB requests against the CU's 64 B / clk): DMA(kt + 2) piece j and gen weight
+  // n = j of tile kt + 1 behind unit j, the three down-weight loads behind the last down unit.  4 + 6 + 3 operations per wave and step.
+#ifdef OFFK_PT_TIMING
+  unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tm_c = 0;
+  const unsigned long long tm_begin = __builtin_readcyclecounter();
+#define OFFK_TICK(i) { const unsigned long long c_ = __builtin_readcyclecounter(); tm[i] += c_ - tm_c; tm_c = c_; }
+#else
+#define OFFK_TICK(i)
+#endif
+  // The cut of one half piece in stages of two vector instructions, its operands kept in registers between stages: a stage rides behind
+  // one MFMA (a v_mfma_f32_16x16x32_bf16 holds the SIMD's issue port for 8 of its 16 cycles -- two 4-cycle instructions fit; left to
+  // the compiler the unit came out as twelve MFMAs back to back and the vector work behind them, at its full cost, and the partner wave of
+  // the SIMD -- the CU's other block, in step with this one -- was at the same place at the same time)
+  unsigned cx0 = 0, cx1 = 0, ch0 = 0, ch1 = 0, cm0 = 0, cm1 = 0;
+  float cr0 = 0.f, cr1 = 0.f, cl0 = 0.f, cl1 = 0.f;
+  auto cut_read = [&](const int i, const int hf, const int rs) {
+    const char* src = raw_rd + rs * PS_RAW_STAGE + i * PS_PIECE + hf * 512;
+    cx0 = *reinterpret_cast<const unsigned*>(src);
+    cx1 = *reinterpret_cast<const unsigned*>(src + 256);
+  };
+  auto cut_stage = [&](const int st, const int i, const int hf, const int rs, const int ps) {
+    if (st == 0) { ch0 = cx0 & 0xffff0000u; ch1 = cx1 & 0xffff0000u; }
+    if (st == 1) { cr0 = __uint_as_float(cx0) - __uint_as_float(ch0); cr1 = __uint_as_float(cx1) - __uint_as_float(ch1); }
+    if (st == 2) { cm0 = __float_as_uint(cr0) & 0xffff0000u; cm1 = __float_as_uint(cr1) & 0xffff0000u; }
+    if (st == 3) { cl0 = cr0 - __uint_as_float(cm0); cl1 = cr1 - __uint_as_float(cm1); }      // <= 8 significant bits: the low halves are zero
+    if (st == 4 || st == 5) {
+      const int fr = (wave + 4 * i) >> 1;     // slots 14, 15 (fr = 7: zeros) are cut like the others and land on the piece itself
+      const bool real = i < 3 || fr < PS_FT;
+      char* dst = (real ? pl_wr + ps * PS_PL_STAGE + fr * PS_FRAME : pl_dummy + rs * PS_RAW_STAGE) + hf * 4;
+      const int pstride = real ? PS_PLANE : 0;
+      if (st == 4) {
+        *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(ch1, ch0, 0x07060302);
+        *reinterpret_cast<unsigned*>(dst + pstride) = __builtin_amdgcn_perm(cm1, cm0, 0x07060302);
+      } else {
+        *reinterpret_cast<unsigned*>(dst + 2 * pstride) = __builtin_amdgcn_perm(__float_as_uint(cl1), __float_as_uint(cl0), 0x07060302);
+      }
+    }
+  };
+#define OFFK_SB __builtin_amdgcn_sched_barrier(0)
+  // half of a scratch tile into its accumulator (two v_add_f32)
+  auto fold2 = [&](f32x4& acc, const f32x4& tv, const int hi) {
+    if (hi) { acc.z += tv.z; acc.w += tv.w; } else { acc.x += tv.x; acc.y += tv.y; }
+    asm volatile("" : "+v"(acc));
+  };
   auto step = [&](int kt, const int ST) {
     const int kn = min(kt + 1, nkt - 1);
+#ifdef OFFK_PT_TIMING
+    tm_c = __builtin_readcyclecounter();
+#endif
     dma_prep(min(kt + 2, nkt - 1));
-    dma_tile(ST);
-    __builtin_amdgcn_sched_barrier(0);
+    OFFK_SB;
+    OFFK_TICK(0)
     u32x4 x[2][3];
     f32x4 t[2][2];
     rdx(x[0], ST, 0);
-    OFFK_WAIT_WG(10);                         // Wg(kt): all but Wd(kt) [6] and this step's DMAs [4]
-    // unit j: the B operand of unit j + 1 is read first; the scratch tiles of unit j - 1 are added to their accumulators beside
-    // unit j's MFMAs (an MFMA's result is ~8 issue slots away)
+    // everything but Wd(kt) [3]: the gen weights of tile kt (issued during the last step) and this wave's pieces of tile kt + 1
+    if (ST == 0) OFFK_WAIT_WG(3, 0); else OFFK_WAIT_WG(3, 1);
+    cut_read(0, 0, ST ^ 1);
+    OFFK_TICK(1)
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // gen unit j: twelve MFMAs (the two channel tiles' chains alternating; planes 0 = h, 1 = m, 2 = l, smallest products first); behind
+    // MFMA n: n = 0..3 the scratch tiles of unit j - 1 into their accumulators, 4..9 the cut of half piece j, 10 the raw read of half
+    // piece j + 1; DMA piece j of tile kt + 2 behind MFMA 5, gen weight j of tile kt + 1 behind MFMA 11
 #pragma unroll
     for (int j = 0; j < PS_FT; ++j) {
       if (j + 1 < PS_FT) rdx(x[(j + 1) & 1], ST, (j + 1) * PS_FRAME);
-      else rdx(x[(j + 1) & 1], ST, xoffA);
-      __builtin_amdgcn_sched_barrier(0);
-      unit(t[j & 1][0], t[j & 1][1], wg[0], wg[1], x[j & 1]);
-      if (j > 0) {
-        ag[j - 1][0] += t[(j - 1) & 1][0]; ag[j - 1][1] += t[(j - 1) & 1][1];
-        asm volatile("" : "+v"(ag[j - 1][0]), "+v"(ag[j - 1][1]));       // the update stays here
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      else rdx(x[(j + 1) & 1], ST, xoffD);
+      OFFK_SB;
+      const u32x4 (&w0)[3] = wg[ST][0];
+      const u32x4 (&w1)[3] = wg[ST][1];
+      const u32x4 (&xx)[3] = x[j & 1];
+      f32x4 &t0 = t[j & 1][0], &t1 = t[j & 1][1];
+      const f32x4 &p0 = t[(j - 1) & 1][0], &p1 = t[(j - 1) & 1][1];
+      const int ci = j >> 1, chf = j & 1;
+      t0 = mf(z, w0[2], xx[0]);  if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][0], p0, 0); OFFK_SB;
+      t1 = mf(z, w1[2], xx[0]);  if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][0], p0, 1); OFFK_SB;
+      t0 = mf(t0, w0[0], xx[2]); if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][1], p1, 0); OFFK_SB;
+      t1 = mf(t1, w1[0], xx[2]); if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][1], p1, 1); OFFK_SB;
+      t0 = mf(t0, w0[1], xx[1]); cut_stage(0, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[1], xx[1]); cut_stage(1, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
+      if (j < 4) { dma_piece(j, ST); OFFK_SB; }
+      t0 = mf(t0, w0[1], xx[0]); cut_stage(2, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[1], xx[0]); cut_stage(3, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
+      t0 = mf(t0, w0[0], xx[1]); cut_stage(4, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[0], xx[1]); cut_stage(5, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
+      t0 = mf(t0, w0[0], xx[0]); cut_read((j + 1) >> 1, (j + 1) & 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[0], xx[0]); OFFK_SB;
+      if (j < 6) { load_wg1(ST ^ 1, j, kn); OFFK_SB; }
     }
-    load_wg(kn);
-    // the down tiles: frames `wave` (x[1]) and wave + 4 (wave 3: frame 6 again, never stored); beside them the cut of tile kt + 1
-    OFFK_WAIT_WD(10);                         // Wd(kt): all but this step's DMAs [4] and Wg(kt + 1) [6]; older: DMA(kt + 1) -- landed too
-    rdx(x[0], ST, xoffB);
-    __builtin_amdgcn_sched_barrier(0);
-    unit(t[1][0], t[1][1], wd[0], wd[1], x[1]);
-    ag[PS_FT - 1][0] += t[0][0]; ag[PS_FT - 1][1] += t[0][1];
-    asm volatile("" : "+v"(ag[PS_FT - 1][0]), "+v"(ag[PS_FT - 1][1]));
-    cut_piece(0, ST ^ 1, ST ^ 1);
-    cut_piece(1, ST ^ 1, ST ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    unit(t[0][0], t[0][1], wd[0], wd[1], x[0]);
-    ad[0][0] += t[1][0]; ad[0][1] += t[1][1];
-    asm volatile("" : "+v"(ad[0][0]), "+v"(ad[0][1]));
-    cut_piece(2, ST ^ 1, ST ^ 1);
-    cut_piece(3, ST ^ 1, ST ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    ad[1][0] += t[0][0]; ad[1][1] += t[0][1];
-    asm volatile("" : "+v"(ad[1][0]), "+v"(ad[1][1]));
+    OFFK_TICK(2)
+    // the wave's down tiles: frames fd0 + 2 i (x[1] holds the first): one chain of six MFMAs each; beside them the scratch tiles of gen
+    // unit 6, the cut of the last half piece (read behind gen unit 6), and the down tiles' own scratch tiles
+    OFFK_WAIT_WD(10);                         // Wd(kt): all but DMA(kt + 2) [4] and Wg(kt + 1) [6]
+    OFFK_TICK(3)
+    f32x4 td[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i + 1 < 4) rdx(x[i & 1], ST, i + 1 < 3 ? xoffD + 2 * (i + 1) * PS_FRAME : xoffD3);
+      OFFK_SB;
+      const u32x4 (&xx)[3] = x[(i + 1) & 1];
+      f32x4 &t0 = td[i & 1];
+      const f32x4 &pd = td[(i - 1) & 1];
+      t0 = mf(z, wd[2], xx[0]);
+      if (i == 0) fold2(ag[PS_FT - 1][0], t[0][0], 0); else fold2(ad[i > 0 ? i - 1 : 0], pd, 0);
+      OFFK_SB;
+      t0 = mf(t0, wd[0], xx[2]);
+      if (i == 0) fold2(ag[PS_FT - 1][0], t[0][0], 1); else fold2(ad[i > 0 ? i - 1 : 0], pd, 1);
+      OFFK_SB;
+      t0 = mf(t0, wd[1], xx[1]);
+      if (i == 0) fold2(ag[PS_FT - 1][1], t[0][1], 0); else if (i == 1) cut_stage(2, 3, 1, ST ^ 1, ST ^ 1);
+      OFFK_SB;
+      t0 = mf(t0, wd[1], xx[0]);
+      if (i == 0) fold2(ag[PS_FT - 1][1], t[0][1], 1); else if (i == 1) cut_stage(3, 3, 1, ST ^ 1, ST ^ 1);
+      OFFK_SB;
+      t0 = mf(t0, wd[0], xx[1]);
+      if (i == 0) cut_stage(0, 3, 1, ST ^ 1, ST ^ 1); else if (i == 1) cut_stage(4, 3, 1, ST ^ 1, ST ^ 1);
+      OFFK_SB;
+      t0 = mf(t0, wd[0], xx[0]);
+      if (i == 0) cut_stage(1, 3, 1, ST ^ 1, ST ^ 1); else if (i == 1) cut_stage(5, 3, 1, ST ^ 1, ST ^ 1);
+      OFFK_SB;
+    }
     load_wd(kn);
+    fold2(ad[3], td[1], 0);
+    fold2(ad[3], td[1], 1);
+    OFFK_TICK(4)
     __syncthreads();                         // (the compiler's lgkmcnt(0) in front of it covers the plane writes)
+    OFFK_TICK(5)
   };
+#undef OFFK_SB
 
-  // ---- prologue: DMA(0), DMA(1), Wg(0), Wd(0) -- the order the steps' wait counts assume ----
+  // ---- prologue: DMA(0) [4], Wg(0) [6], DMA(1) [4], Wd(0) [3] ----
   dma_prep(0);
   dma_tile(0);
+  load_wg(0, 0);
   dma_prep(min(1, nkt - 1));
   dma_tile(1);
-  load_wg(0);
   load_wd(0);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // DMA(0)
+  asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // DMA(0)
 #pragma unroll
   for (int i = 0; i < 4; ++i) cut_piece(i, 0, 0);
   __syncthreads();
+#ifdef OFFK_PT_TIMING
+  const unsigned long long tm_loop = __builtin_readcyclecounter();
+#endif
   int kt = 0;
   for (; kt + 1 < nkt; kt += 2) {
     step(kt, 0);
     step(kt + 1, 1);
   }
   if (kt < nkt) step(kt, 0);
+#ifdef OFFK_PT_TIMING
+  const unsigned long long tm_epi = __builtin_readcyclecounter();
+#endif
   // nothing may still be landing when the LDS is handed on; the weight registers stay allocated until their last load returned
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0][0]), "+v"(wg[0][1]), "+v"(wg[0][2]), "+v"(wg[1][0]), "+v"(wg[1][1]), "+v"(wg[1][2]),
-               "+v"(wd[0][0]), "+v"(wd[0][1]), "+v"(wd[0][2]), "+v"(wd[1][0]), "+v"(wd[1][1]), "+v"(wd[1][2]) :: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0][0][0]), "+v"(wg[0][0][1]), "+v"(wg[0][0][2]), "+v"(wg[0][1][0]), "+v"(wg[0][1][1]), "+v"(wg[0][1][2]),
+               "+v"(wg[1][0][0]), "+v"(wg[1][0][1]), "+v"(wg[1][0][2]), "+v"(wg[1][1][0]), "+v"(wg[1][1][1]), "+v"(wg[1][1][2]) :: "memory");
+  asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]));
 #undef OFFK_WAIT_WG
 #undef OFFK_WAIT_WD
 
@@ -299,7 +436,11 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   const bool qn_e = qpc && qe >= qpc;
   const int bl = qpc ? b + (int)qn_e : b + (li_e >> rsh), pixl = qpc ? 4 * (qe - (qn_e ? qpc : 0)) + (li_e & 3) : q0 + (li_e & rmask);
   const size_t pair0 = (size_t)bl * (L - 1) + t0;
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 64)     /* timing experiment: (almost) no stores */
+  const bool pix_ok = pixl < HW && bl < p.B && lane_e == 0 && blockIdx.x == 0;
+#else
   const bool pix_ok = pixl < HW && bl < p.B;
+#endif
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const f32x4 bg = *reinterpret_cast<const f32x4*>(S.bias + wave * 32 + 16 * ct + 4 * kq_e);
@@ -316,20 +457,29 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
       *reinterpret_cast<f32x4*>(trow) = ag[j + 1][0] - ag[j][0];
       *reinterpret_cast<f32x4*>(trow + 16) = ag[j + 1][1] - ag[j][1];
     }
+  {
+    const int ctd_e = wave & 1, fd0_e = wave >> 1;
+    const f32x4 bd = *reinterpret_cast<const f32x4*>(S.bias_down + 16 * ctd_e + 4 * kq_e);
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int j = wave + 4 * half;
-    if (j < nf && (last_group || j < PS_FT - 1) && pix_ok) {
-      const int dr = ps_down_row(bl, t0 + j, L, p.P, p.slice_mode);
-      if (dr >= 0) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 bd = *reinterpret_cast<const f32x4*>(S.bias_down + 16 * ct + 4 * kq_e);
-          *reinterpret_cast<f32x4*>(S.D + ((size_t)dr * HW + pixl) * kDownCh + 16 * ct + 4 * kq_e) = ad[half][ct] + bd;
-        }
+    for (int i = 0; i < 4; ++i) {
+      const int j = fd0_e + 2 * i;                 // (waves 2, 3, i = 3: j = 7 >= nf -- the duplicate tile is dropped here)
+      // the frame shared with the next temporal group belongs to that group
+      if (j < nf && (last_group || j < PS_FT - 1) && pix_ok) {
+        const int dr = ps_down_row(bl, t0 + j, L, p.P, p.slice_mode);
+        if (dr >= 0) *reinterpret_cast<f32x4*>(S.D + ((size_t)dr * HW + pixl) * kDownCh + 16 * ctd_e + 4 * kq_e) = ad[i] + bd;
       }
     }
   }
+#ifdef OFFK_PT_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.dbg && threadIdx.x == 0) {
+    const unsigned long long tm_end = __builtin_readcyclecounter();
+    atomicAdd(p.dbg + 8, tm_loop - tm_begin); atomicAdd(p.dbg + 9, tm_epi - tm_loop); atomicAdd(p.dbg + 10, tm_end - tm_epi);
+    for (int i = 0; i < 6; ++i) atomicAdd(p.dbg + 11 + i, tm[i]);
+    atomicAdd(p.dbg + 17, (unsigned long long)nkt); atomicAdd(p.dbg + 18, 1ull);
+  }
+#endif
+#undef OFFK_TICK
 }
 
 // Plane image of a site's 160 weight rows for pw_tdiff_split_kernel: one 16-byte item per (K-tile, slab of 32 rows, channel tile ct,

@@ -6,7 +6,7 @@ import torch
 import offk_amd
 from offk_amd import runtime, spec, synth
 B, L = 64, 7
-h = runtime.OffForward(B, L, 0, precision=os.environ.get("PT_PREC", "bf16x3")); h.load_state_dict(synth.make_weights(0))
+h = runtime.OffForward(B, L, 0, precision=os.environ.get("PT_PREC", "fp32")); h.load_state_dict(synth.make_weights(0))
 feats = [torch.from_numpy(f).cuda() for f in synth.make_features(B, L, 2)]
 arr = h._feat_array(feats)
 out = [torch.empty(h.out_rows(), 101, device="cuda") for _ in range(3)]
