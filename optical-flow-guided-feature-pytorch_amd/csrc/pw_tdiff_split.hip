@@ -36,18 +36,15 @@ namespace offk {
 
 namespace {
 constexpr int PS_FT = 7;                              // frames per block
-constexpr int PS_PIECE = 1024;                        // raw piece: 16 k rows x 16 pixels fp32
-constexpr int PS_RAW_WAVE = 4 * PS_PIECE;             // a wave's four DMA slots of one K-tile
-constexpr int PS_RAW_STAGE = 4 * PS_RAW_WAVE;         // 16 KB
-constexpr int PS_PLANE = 1024;                        // [4 g][16 px] x 16 B
-constexpr int PS_FRAME = 3 * PS_PLANE;
-constexpr int PS_PL_STAGE = PS_FT * PS_FRAME;         // 21 KB
-constexpr int PS_LDS = 2 * PS_RAW_STAGE + 2 * PS_PL_STAGE;      // 75776 B = 60 granules of 1280 B: two blocks per CU
+constexpr int PS_GS = 272;                            // one k group of a plane: 16 pixels x 16 B (8 bf16 = k 8g .. 8g + 7) + 16 B of padding
+constexpr int PS_PLANE = 4 * PS_GS;                   // 32 k
+constexpr int PS_FRAME = 3 * PS_PLANE;                // planes h, m, l
+constexpr int PS_STAGE = (PS_FT + 1) * PS_FRAME;      // seven frames + the slot wave 3's idle loader half cuts its zeros into
+constexpr int PS_LDS = 2 * PS_STAGE;                  // 52224 B = 41 granules of 1280 B
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int ps_down_row(int b, int t, int L, int P, int slice_mode) {
   if (slice_mode == 0) { const int f = b * L + t; return f < P ? f : -1; }
@@ -56,8 +53,7 @@ __device__ __forceinline__ int ps_down_row(int b, int t, int L, int P, int slice
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];     // raw[2][4 waves][4 pieces] | planes[2][7 frames][3][1 KB]
-  char* const planes = lds + 2 * PS_RAW_STAGE;
+  extern __shared__ __attribute__((aligned(16))) char planes[];     // [2 stages][8 frame slots][3 planes][4 k groups][272 B]
 
   // ---- the block's site and its (clip, pixels, temporal group): as pw_tdiff16_kernel ----
   int si = 0;
@@ -89,34 +85,24 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, lg = lane >> 4;
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 8)      /* experiment: every other block of 256 starts half a step late */
-  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(44);
-#endif
 
-  // ---- DMA: slot q = wave + 4 i (i = 0..3) = frame q >> 1, k half q & 1 (= wave & 1); slots 14, 15 read zeros.  Lane l of a piece
-  //      fetches k row 4 a + r (a = (l >> 2) & 3, r = l >> 4), pixel quad l & 3: row k sits at [k & 3][k >> 2] of the piece ----
-  const int pq = lane & 3;
+  // ---- feature-map loader: wave w loads frames w and w + 4 (slot fs = 0, 1; wave 3's second slot reads zeros); lane (pixel quad pq =
+  //      lane & 3, k pair kp = lane >> 2) holds X[k = 2 kp + e][4 pq .. + 3] of the K-tile, e = 0, 1: two 16-byte loads per frame ----
+  const int pq = lane & 3, kp = lane >> 2;
   const bool qnext = qpc && qr0 + pq >= qpc;
   const int cq = qpc ? (int)qnext : (4 * pq) >> rsh;
   const int k0px = qpc ? 4 * (qr0 + pq - (qnext ? qpc : 0)) : q0 + ((4 * pq) & rmask);
   const bool px_ok = k0px < HW && b + cq < p.B;
-  const int vrow0 = px_ok ? ((16 * (wave & 1) + 4 * ((lane >> 2) & 3) + (lane >> 4)) * HW + k0px) * 4 : (int)0x80000000;
+  const int vrow0 = px_ok ? (2 * kp * HW + k0px) * 4 : (int)0x80000000;        // bit 31: past every descriptor -> zeros
   const int vclip = cq * L;
-  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 1)      /* timing experiment: the pieces as plain loads into a dummy register quad (results wrong) */
-  u32x4 dummy_x = {0u, 0u, 0u, 0u};
-  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dummy_x) : "v"(voff), "s"(desc), "s"(soff) : "memory");
-  };
-#else
-  auto dma16 = [&](const i32x4& desc, unsigned lds_addr, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(desc), "s"(soff) : "memory", "m0");
-  };
-#endif
-  i32x4 dm_desc = {0, 0, 0, 0};
-  int dm_fstride = 0, dm_s0 = 0, dm_voff = 0;
-  auto dma_prep = [&](int kt) {
+  u32x4 xr[2][2][2];                          // [register set = K-tile parity][frame slot][e]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) { xr[a][f][0] = u32x4{0u, 0u, 0u, 0u}; xr[a][f][1] = u32x4{0u, 0u, 0u, 0u}; }
+  i32x4 xd_desc = {0, 0, 0, 0};
+  int xd_fstride = 0, xd_s0 = 0, xd_voff = 0;
+  auto x_prep = [&](int kt) {
     const float* xb = S.xp[0]; int cpart = S.cp[0], kl = kt * BK;
     if (S.nparts > 1 && kl >= S.cp[0]) {
       kl -= S.cp[0]; xb = S.xp[1]; cpart = S.cp[1];
@@ -126,55 +112,49 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
       }
     }
     const unsigned long long xa = reinterpret_cast<unsigned long long>(xb);
-    dm_desc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
-    dm_fstride = cpart * HW * 4;
-    dm_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;
-    dm_voff = vrow0 + (int)__umul24((unsigned)vclip, (unsigned)dm_fstride);
+    xd_desc = i32x4{(int)(unsigned)xa, (int)(unsigned)(xa >> 32) & 0xffff, p.B * L * cpart * HW * 4, 0x00020000};
+    xd_fstride = cpart * HW * 4;
+    xd_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;
+    xd_voff = vrow0 + (int)__umul24((unsigned)vclip, (unsigned)xd_fstride);
   };
-  auto dma_piece = [&](const int i, const int rs) {       // slot i of the wave, of the prepared K-tile, into raw stage rs
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 32)     /* timing experiment: no feature-map loads at all */
-    return;
-#endif
-    const int q = wave + 4 * i, fr = q >> 1;
-    const int voff = fr < nf ? dm_voff : (int)0x80000000;              // (slots 14, 15: fr = 7 >= nf)
-    dma16(dm_desc, lds_base + rs * PS_RAW_STAGE + wave * PS_RAW_WAVE + i * PS_PIECE, voff, dm_s0 + fr * dm_fstride);
-  };
-  auto dma_tile = [&](const int rs) {
+  auto load_x = [&](const int set, const int fs) {      // frame slot fs of the prepared K-tile into register set `set`
+    const int fr = wave + 4 * fs;
+    const int voff = fr < nf ? xd_voff : (int)0x80000000;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(i, rs);
+    for (int e = 0; e < 2; ++e) {
+      const int so = xd_s0 + fr * xd_fstride + e * HW * 4;
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 32)     /* timing experiment: no feature-map loads */
+      continue;
+#endif
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(xr[set][fs][e]) : "v"(voff), "s"(xd_desc), "s"(so) : "memory");
+    }
   };
 
-  // ---- the cut: lane (pixel li, a = lg) of piece i holds k = 16 (wave & 1) + 4 a + 0..3 of frame (wave + 4 i) >> 1 ----
-  const char* const raw_rd = lds + wave * PS_RAW_WAVE + lg * 64 + li * 4;          // + stage, + piece, + r * 256
-  // planes: g = 2 (wave & 1) + (a >> 1), 8-byte half a & 1 of the lane's 16 B
-  char* const pl_wr = planes + (2 * (wave & 1) + (lg >> 1)) * 256 + li * 16 + (lg & 1) * 8;   // + stage, + frame, + plane
-  char* const pl_dummy = lds + wave * PS_RAW_WAVE + 3 * PS_PIECE + (pl_wr - planes);     // + raw stage: the wave's own fourth piece
-  // half hf of piece i: k rows r = 2 hf, 2 hf + 1 of the lane's four -> one dword per plane
-  auto cut_half = [&](const int i, const int hf, const int rs, const int ps) {
+  // ---- the cut.  Atom a = (frame slot a >> 2, pixel i = a & 3 of the lane's quad): the lane's two k of that pixel -> one dword (k pair)
+  //      of each plane.  In stages of two vector instructions, operands in registers between stages: a stage rides behind one MFMA
+  //      (a v_mfma_f32_16x16x32_bf16 holds the SIMD's issue port for 8 of its 16 cycles -- two 4-cycle instructions fit; left to the
+  //      compiler a unit came out as twelve MFMAs back to back with the vector work behind them at its full cost, while the partner wave
+  //      of the SIMD -- the CU's other block, in step with this one -- was at the same place) ----
+  char* const pl_wr = planes + (kp >> 2) * PS_GS + 4 * pq * 16 + (kp & 3) * 4;       // + stage, + frame, + plane, + pixel i * 16
+  unsigned ch0 = 0, ch1 = 0, cm0 = 0, cm1 = 0;
+  float cr0 = 0.f, cr1 = 0.f, cl0 = 0.f, cl1 = 0.f;
+  auto atom_stage = [&](const int st, const int a, const int set, const int ps) {
 #if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 4)      /* timing experiment: no cut */
-    if (i < 8) return;
+    if (a < 8) return;
 #endif
-    const int fr = (wave + 4 * i) >> 1;      // slots 14, 15 (fr = 7: zeros) are cut like the others -- no branch in the MFMA stream (hipcc sinks
-                                             // the accumulator updates across any block boundary) -- and land on the piece itself
-    const char* src = raw_rd + rs * PS_RAW_STAGE + i * PS_PIECE + hf * 512;
-    unsigned x[2], h[2], m[2], l[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) x[r] = *reinterpret_cast<const unsigned*>(src + r * 256);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      h[r] = x[r] & 0xffff0000u;
-      const float r1 = __uint_as_float(x[r]) - __uint_as_float(h[r]);
-      m[r] = __float_as_uint(r1) & 0xffff0000u;
-      l[r] = __float_as_uint(r1 - __uint_as_float(m[r]));               // <= 8 significant bits: its low half is zero
+    const int fs = a >> 2, i = a & 3;
+    const unsigned xa = xr[set][fs][0][i], xb = xr[set][fs][1][i];
+    if (st == 0) { ch0 = xa & 0xffff0000u; ch1 = xb & 0xffff0000u; }
+    if (st == 1) { cr0 = __uint_as_float(xa) - __uint_as_float(ch0); cr1 = __uint_as_float(xb) - __uint_as_float(ch1); }
+    if (st == 2) { cm0 = __float_as_uint(cr0) & 0xffff0000u; cm1 = __float_as_uint(cr1) & 0xffff0000u; }
+    if (st == 3) { cl0 = cr0 - __uint_as_float(cm0); cl1 = cr1 - __uint_as_float(cm1); }      // <= 8 significant bits: the low halves are zero
+    char* dst = pl_wr + ps * PS_STAGE + (wave + 4 * fs) * PS_FRAME + i * 16;      // (wave 3, slot 1: frame slot 7 -- never read)
+    if (st == 4) {
+      *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(ch1, ch0, 0x07060302);
+      *reinterpret_cast<unsigned*>(dst + PS_PLANE) = __builtin_amdgcn_perm(cm1, cm0, 0x07060302);
     }
-    const bool real = i < 3 || fr < PS_FT;
-    char* dst = (real ? pl_wr + ps * PS_PL_STAGE + fr * PS_FRAME : pl_dummy + rs * PS_RAW_STAGE) + hf * 4;
-    const int pstride = real ? PS_PLANE : 0;
-    *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(h[1], h[0], 0x07060302);
-    *reinterpret_cast<unsigned*>(dst + pstride) = __builtin_amdgcn_perm(m[1], m[0], 0x07060302);
-    *reinterpret_cast<unsigned*>(dst + 2 * pstride) = __builtin_amdgcn_perm(l[1], l[0], 0x07060302);
+    if (st == 5) *reinterpret_cast<unsigned*>(dst + 2 * PS_PLANE) = __builtin_amdgcn_perm(__float_as_uint(cl1), __float_as_uint(cl0), 0x07060302);
   };
-  auto cut_piece = [&](const int i, const int rs, const int ps) { cut_half(i, 0, rs, ps); cut_half(i, 1, rs, ps); };
 
   // ---- weights: image [kt][slab (4 gen + 1 down)][ct][plane][lane] x 16 B (pw_pack_split16_kernel) ----
   u32x4 wg[2][2][3], wd[3];                // gen [set][ct][plane] (set = K-tile parity), down [plane] (the wave's ONE down channel tile)
@@ -194,18 +174,11 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
   // stored) -- every wave loading BOTH down tiles made the weight stream 48 KB per block and K-tile, 24 KB of it the down rows four times
   const int ctd = wave & 1, fd0 = wave >> 1;
   auto load_wg1 = [&](const int set, const int n, int kt) {       // n = ct * 3 + plane
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 2)      /* timing experiment: the same (cached) weight tile every time */
-    kt = 0;
-#endif
-    const int so = ((kt * 5 + wave) * 6 + n) * 1024;
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 16)     /* timing experiment: no weight loads inside the loop at all */
+#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 16)     /* timing experiment: no weight loads inside the loop */
     if (kt > 0) return;
 #endif
+    const int so = ((kt * 5 + wave) * 6 + n) * 1024;
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wg[set][n / 3][n % 3]) : "v"(wlane), "s"(wdesc), "s"(so));
-  };
-  auto load_wg = [&](const int set, int kt) {
-#pragma unroll
-    for (int n = 0; n < 6; ++n) load_wg1(set, n, kt);
   };
   auto load_wd = [&](int kt) {
 #pragma unroll
@@ -217,8 +190,10 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wd[q]) : "v"(wlane), "s"(wdesc), "s"(so));
     }
   };
-#define OFFK_WAIT_WG(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[set][0][0]), "+v"(wg[set][0][1]), "+v"(wg[set][0][2]), \
-                                          "+v"(wg[set][1][0]), "+v"(wg[set][1][1]), "+v"(wg[set][1][2]) :: "memory")
+  // "all but my N newest vector-memory operations have completed", tied to the registers the operations before that write
+#define OFFK_WAIT_STEP(N, set) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wg[set][0][0]), "+v"(wg[set][0][1]), "+v"(wg[set][0][2]), \
+                                            "+v"(wg[set][1][0]), "+v"(wg[set][1][1]), "+v"(wg[set][1][2]), "+v"(xr[set ^ 1][0][0]), \
+                                            "+v"(xr[set ^ 1][0][1]), "+v"(xr[set ^ 1][1][0]), "+v"(xr[set ^ 1][1][1]) :: "memory")
 #define OFFK_WAIT_WD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]) :: "memory")
 
   f32x4 ag[PS_FT][2], ad[4];
@@ -227,50 +202,23 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) ad[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // B operand of frame f out of plane stage st: three ds_read_b128
-  const char* const xrd = planes + lg * 256 + li * 16;
+  // B operand of a frame out of plane stage st: three ds_read_b128
+  const char* const xrd = planes + lg * PS_GS + li * 16;
   const int xoffD = fd0 * PS_FRAME, xoffD3 = min(fd0 + 6, PS_FT - 1) * PS_FRAME;     // down frames: xoffD + 2 i frames, the fourth clamped
   auto rdx = [&](u32x4 (&x)[3], const int st, int foff) {
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 256)    /* timing experiment: no operand reads but the step's first */
-    if (foff != 0) return;
-#endif
 #pragma unroll
-    for (int q = 0; q < 3; ++q) x[q] = *reinterpret_cast<const u32x4*>(xrd + st * PS_PL_STAGE + foff + q * PS_PLANE);
+    for (int q = 0; q < 3; ++q) x[q] = *reinterpret_cast<const u32x4*>(xrd + st * PS_STAGE + foff + q * PS_PLANE);
   };
   auto mf = [&](f32x4 c, const u32x4& a, const u32x4& bb) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), c, 0, 0, 0);
   };
-  // the six products of one (frame, two channel tiles) unit, the two tiles' chains alternating; planes: 0 = h, 1 = m, 2 = l
-  auto unit = [&](f32x4& t0, f32x4& t1, const u32x4 (&w0)[3], const u32x4 (&w1)[3], const u32x4 (&x)[3]) {
-#if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 128)    /* timing experiment: the chains start at the scratch tiles' old values and nothing is folded */
-    const f32x4 z = t0;
-#else
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#endif
-    t0 = mf(z, w0[2], x[0]);  t1 = mf(z, w1[2], x[0]);
-    t0 = mf(t0, w0[0], x[2]); t1 = mf(t1, w1[0], x[2]);
-    t0 = mf(t0, w0[1], x[1]); t1 = mf(t1, w1[1], x[1]);
-    t0 = mf(t0, w0[1], x[0]); t1 = mf(t1, w1[1], x[0]);
-    t0 = mf(t0, w0[0], x[1]); t1 = mf(t1, w1[0], x[1]);
-    t0 = mf(t0, w0[0], x[0]); t1 = mf(t1, w1[0], x[0]);
-  };
-
-  auto unit1 = [&](f32x4& t0, const u32x4 (&w0)[3], const u32x4 (&x)[3]) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    t0 = mf(z, w0[2], x[0]);
-    t0 = mf(t0, w0[0], x[2]);
-    t0 = mf(t0, w0[1], x[1]);
-    t0 = mf(t0, w0[1], x[0]);
-    t0 = mf(t0, w0[0], x[1]);
-    t0 = mf(t0, w0[0], x[0]);
+  // half of a scratch tile into its accumulator (two v_add_f32)
+  auto fold2 = [&](f32x4& acc, const f32x4& tv, const int hi) {
+    if (hi) { acc.z += tv.z; acc.w += tv.w; } else { acc.x += tv.x; acc.y += tv.y; }
+    asm volatile("" : "+v"(acc));           // the update stays where it is written (hipcc sinks it across any block boundary otherwise)
   };
 
   const int nkt = C / BK;
-  // one step: tile kt out of plane stage ST, gen weights of set ST; the cut of tile kt + 1 from raw stage ST ^ 1 into plane stage ST ^ 1
-  // (eight half pieces: one beside each gen unit and the first down unit); DMA of tile kt + 2 into raw stage ST (its tile kt was cut
-  // during the last step).  The step's vector-memory instructions go out ONE OR TWO PER UNIT (all ten at the top of the step cost
-  // ~1200 cycles of issue per step: eight waves' 1-KB requests against the CU's 64 B / clk): DMA(kt + 2) piece j and gen weight
-  // n = j of tile kt + 1 behind unit j, the three down-weight loads behind the last down unit.  4 + 6 + 3 operations per wave and step.
 #ifdef OFFK_PT_TIMING
   unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tm_c = 0;
   const unsigned long long tm_begin = __builtin_readcyclecounter();
@@ -278,60 +226,29 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
 #else
 #define OFFK_TICK(i)
 #endif
-  // The cut of one half piece in stages of two vector instructions, its operands kept in registers between stages: a stage rides behind
-  // one MFMA (a v_mfma_f32_16x16x32_bf16 holds the SIMD's issue port for 8 of its 16 cycles -- two 4-cycle instructions fit; left to
-  // the compiler the unit came out as twelve MFMAs back to back and the vector work behind them, at its full cost, and the partner wave of
-  // the SIMD -- the CU's other block, in step with this one -- was at the same place at the same time)
-  unsigned cx0 = 0, cx1 = 0, ch0 = 0, ch1 = 0, cm0 = 0, cm1 = 0;
-  float cr0 = 0.f, cr1 = 0.f, cl0 = 0.f, cl1 = 0.f;
-  auto cut_read = [&](const int i, const int hf, const int rs) {
-    const char* src = raw_rd + rs * PS_RAW_STAGE + i * PS_PIECE + hf * 512;
-    cx0 = *reinterpret_cast<const unsigned*>(src);
-    cx1 = *reinterpret_cast<const unsigned*>(src + 256);
-  };
-  auto cut_stage = [&](const int st, const int i, const int hf, const int rs, const int ps) {
-    if (st == 0) { ch0 = cx0 & 0xffff0000u; ch1 = cx1 & 0xffff0000u; }
-    if (st == 1) { cr0 = __uint_as_float(cx0) - __uint_as_float(ch0); cr1 = __uint_as_float(cx1) - __uint_as_float(ch1); }
-    if (st == 2) { cm0 = __float_as_uint(cr0) & 0xffff0000u; cm1 = __float_as_uint(cr1) & 0xffff0000u; }
-    if (st == 3) { cl0 = cr0 - __uint_as_float(cm0); cl1 = cr1 - __uint_as_float(cm1); }      // <= 8 significant bits: the low halves are zero
-    if (st == 4 || st == 5) {
-      const int fr = (wave + 4 * i) >> 1;     // slots 14, 15 (fr = 7: zeros) are cut like the others and land on the piece itself
-      const bool real = i < 3 || fr < PS_FT;
-      char* dst = (real ? pl_wr + ps * PS_PL_STAGE + fr * PS_FRAME : pl_dummy + rs * PS_RAW_STAGE) + hf * 4;
-      const int pstride = real ? PS_PLANE : 0;
-      if (st == 4) {
-        *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(ch1, ch0, 0x07060302);
-        *reinterpret_cast<unsigned*>(dst + pstride) = __builtin_amdgcn_perm(cm1, cm0, 0x07060302);
-      } else {
-        *reinterpret_cast<unsigned*>(dst + 2 * pstride) = __builtin_amdgcn_perm(__float_as_uint(cl1), __float_as_uint(cl0), 0x07060302);
-      }
-    }
-  };
 #define OFFK_SB __builtin_amdgcn_sched_barrier(0)
-  // half of a scratch tile into its accumulator (two v_add_f32)
-  auto fold2 = [&](f32x4& acc, const f32x4& tv, const int hi) {
-    if (hi) { acc.z += tv.z; acc.w += tv.w; } else { acc.x += tv.x; acc.y += tv.y; }
-    asm volatile("" : "+v"(acc));
-  };
+  // One step: tile kt out of plane stage ST with the gen weights of set ST; the cut of tile kt + 1 out of register set ST ^ 1 into plane
+  // stage ST ^ 1 (eight atoms: one beside each gen unit and the first down unit); that register set re-loaded with tile kt + 3; the gen
+  // weights of tile kt + 1 into set ST ^ 1.  The step's vector-memory instructions go out one at a time between the MFMAs (all at the
+  // top of the step they cost ~1200 cycles of issue: eight waves' 1-KB requests against the CU's 64 B / clk), in this order:
+  // Wg(kt + 1) [6], X(kt + 3) [2 + 2], Wd(kt + 1) [3] -- 13 operations per wave and step, the waits below count on it.
   auto step = [&](int kt, const int ST) {
     const int kn = min(kt + 1, nkt - 1);
 #ifdef OFFK_PT_TIMING
     tm_c = __builtin_readcyclecounter();
 #endif
-    dma_prep(min(kt + 2, nkt - 1));
+    x_prep(min(kt + 3, nkt - 1));
     OFFK_SB;
     OFFK_TICK(0)
     u32x4 x[2][3];
     f32x4 t[2][2];
     rdx(x[0], ST, 0);
-    // everything but Wd(kt) [3]: the gen weights of tile kt (issued during the last step) and this wave's pieces of tile kt + 1
-    if (ST == 0) OFFK_WAIT_WG(3, 0); else OFFK_WAIT_WG(3, 1);
-    cut_read(0, 0, ST ^ 1);
+    // all but X(kt + 2) [4] and Wd(kt) [3]: the gen weights of tile kt and the feature-map registers of tile kt + 1 (a step older)
+    if (ST == 0) OFFK_WAIT_STEP(7, 0); else OFFK_WAIT_STEP(7, 1);
     OFFK_TICK(1)
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // gen unit j: twelve MFMAs (the two channel tiles' chains alternating; planes 0 = h, 1 = m, 2 = l, smallest products first); behind
-    // MFMA n: n = 0..3 the scratch tiles of unit j - 1 into their accumulators, 4..9 the cut of half piece j, 10 the raw read of half
-    // piece j + 1; DMA piece j of tile kt + 2 behind MFMA 5, gen weight j of tile kt + 1 behind MFMA 11
+    // MFMA n: n = 0..3 the scratch tiles of unit j - 1 into their accumulators, n = 4..9 the stages of cut atom j
 #pragma unroll
     for (int j = 0; j < PS_FT; ++j) {
       if (j + 1 < PS_FT) rdx(x[(j + 1) & 1], ST, (j + 1) * PS_FRAME);
@@ -342,52 +259,55 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
       const u32x4 (&xx)[3] = x[j & 1];
       f32x4 &t0 = t[j & 1][0], &t1 = t[j & 1][1];
       const f32x4 &p0 = t[(j - 1) & 1][0], &p1 = t[(j - 1) & 1][1];
-      const int ci = j >> 1, chf = j & 1;
-      t0 = mf(z, w0[2], xx[0]);  if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][0], p0, 0); OFFK_SB;
-      t1 = mf(z, w1[2], xx[0]);  if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][0], p0, 1); OFFK_SB;
-      t0 = mf(t0, w0[0], xx[2]); if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][1], p1, 0); OFFK_SB;
-      t1 = mf(t1, w1[0], xx[2]); if (j > 0) fold2(ag[j > 0 ? j - 1 : 0][1], p1, 1); OFFK_SB;
-      t0 = mf(t0, w0[1], xx[1]); cut_stage(0, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
-      t1 = mf(t1, w1[1], xx[1]); cut_stage(1, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
-      if (j < 4) { dma_piece(j, ST); OFFK_SB; }
-      t0 = mf(t0, w0[1], xx[0]); cut_stage(2, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
-      t1 = mf(t1, w1[1], xx[0]); cut_stage(3, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
-      t0 = mf(t0, w0[0], xx[1]); cut_stage(4, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
-      t1 = mf(t1, w1[0], xx[1]); cut_stage(5, ci, chf, ST ^ 1, ST ^ 1); OFFK_SB;
-      t0 = mf(t0, w0[0], xx[0]); cut_read((j + 1) >> 1, (j + 1) & 1, ST ^ 1); OFFK_SB;
+      const int jp = j > 0 ? j - 1 : 0;
+      t0 = mf(z, w0[2], xx[0]);  if (j > 0) fold2(ag[jp][0], p0, 0); OFFK_SB;
+      t1 = mf(z, w1[2], xx[0]);  if (j > 0) fold2(ag[jp][0], p0, 1); OFFK_SB;
+      t0 = mf(t0, w0[0], xx[2]); if (j > 0) fold2(ag[jp][1], p1, 0); OFFK_SB;
+      t1 = mf(t1, w1[0], xx[2]); if (j > 0) fold2(ag[jp][1], p1, 1); OFFK_SB;
+      t0 = mf(t0, w0[1], xx[1]); atom_stage(0, j, ST ^ 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[1], xx[1]); atom_stage(1, j, ST ^ 1, ST ^ 1); OFFK_SB;
+      if (j < 3) { load_wg1(ST ^ 1, 2 * j, kn); OFFK_SB; }
+      t0 = mf(t0, w0[1], xx[0]); atom_stage(2, j, ST ^ 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[1], xx[0]); atom_stage(3, j, ST ^ 1, ST ^ 1); OFFK_SB;
+      t0 = mf(t0, w0[0], xx[1]); atom_stage(4, j, ST ^ 1, ST ^ 1); OFFK_SB;
+      t1 = mf(t1, w1[0], xx[1]); atom_stage(5, j, ST ^ 1, ST ^ 1); OFFK_SB;
+      t0 = mf(t0, w0[0], xx[0]); OFFK_SB;
       t1 = mf(t1, w1[0], xx[0]); OFFK_SB;
-      if (j < 6) { load_wg1(ST ^ 1, j, kn); OFFK_SB; }
+      if (j < 3) { load_wg1(ST ^ 1, 2 * j + 1, kn); OFFK_SB; }
+      if (j == 4) { load_x(ST ^ 1, 0); OFFK_SB; }          // atoms 0..3 have read slot 0 of the set
     }
     OFFK_TICK(2)
     // the wave's down tiles: frames fd0 + 2 i (x[1] holds the first): one chain of six MFMAs each; beside them the scratch tiles of gen
-    // unit 6, the cut of the last half piece (read behind gen unit 6), and the down tiles' own scratch tiles
-    OFFK_WAIT_WD(10);                         // Wd(kt): all but DMA(kt + 2) [4] and Wg(kt + 1) [6]
+    // unit 6, cut atom 7, and the down tiles' own scratch tiles
+    OFFK_WAIT_WD(8);                          // Wd(kt): all but Wg(kt + 1) [6] and X(kt + 3) slot 0 [2]
     OFFK_TICK(3)
     f32x4 td[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i + 1 < 4) rdx(x[i & 1], ST, i + 1 < 3 ? xoffD + 2 * (i + 1) * PS_FRAME : xoffD3);
       OFFK_SB;
+      if (i == 1) { load_x(ST ^ 1, 1); OFFK_SB; }          // atom 7 has read slot 1 (its stages 0, 1 ran beside the first down unit)
       const u32x4 (&xx)[3] = x[(i + 1) & 1];
       f32x4 &t0 = td[i & 1];
       const f32x4 &pd = td[(i - 1) & 1];
+      const int ip = i > 0 ? i - 1 : 0;
       t0 = mf(z, wd[2], xx[0]);
-      if (i == 0) fold2(ag[PS_FT - 1][0], t[0][0], 0); else fold2(ad[i > 0 ? i - 1 : 0], pd, 0);
+      if (i == 0) fold2(ag[PS_FT - 1][0], t[0][0], 0); else fold2(ad[ip], pd, 0);
       OFFK_SB;
       t0 = mf(t0, wd[0], xx[2]);
-      if (i == 0) fold2(ag[PS_FT - 1][0], t[0][0], 1); else fold2(ad[i > 0 ? i - 1 : 0], pd, 1);
+      if (i == 0) fold2(ag[PS_FT - 1][0], t[0][0], 1); else fold2(ad[ip], pd, 1);
       OFFK_SB;
       t0 = mf(t0, wd[1], xx[1]);
-      if (i == 0) fold2(ag[PS_FT - 1][1], t[0][1], 0); else if (i == 1) cut_stage(2, 3, 1, ST ^ 1, ST ^ 1);
+      if (i == 0) fold2(ag[PS_FT - 1][1], t[0][1], 0); else if (i == 1) atom_stage(2, 7, ST ^ 1, ST ^ 1);
       OFFK_SB;
       t0 = mf(t0, wd[1], xx[0]);
-      if (i == 0) fold2(ag[PS_FT - 1][1], t[0][1], 1); else if (i == 1) cut_stage(3, 3, 1, ST ^ 1, ST ^ 1);
+      if (i == 0) fold2(ag[PS_FT - 1][1], t[0][1], 1); else if (i == 1) atom_stage(3, 7, ST ^ 1, ST ^ 1);
       OFFK_SB;
       t0 = mf(t0, wd[0], xx[1]);
-      if (i == 0) cut_stage(0, 3, 1, ST ^ 1, ST ^ 1); else if (i == 1) cut_stage(4, 3, 1, ST ^ 1, ST ^ 1);
+      if (i == 0) atom_stage(0, 7, ST ^ 1, ST ^ 1); else if (i == 1) atom_stage(4, 7, ST ^ 1, ST ^ 1);
       OFFK_SB;
       t0 = mf(t0, wd[0], xx[0]);
-      if (i == 0) cut_stage(1, 3, 1, ST ^ 1, ST ^ 1); else if (i == 1) cut_stage(5, 3, 1, ST ^ 1, ST ^ 1);
+      if (i == 0) atom_stage(1, 7, ST ^ 1, ST ^ 1); else if (i == 1) atom_stage(5, 7, ST ^ 1, ST ^ 1);
       OFFK_SB;
     }
     load_wd(kn);
@@ -397,18 +317,22 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
     __syncthreads();                         // (the compiler's lgkmcnt(0) in front of it covers the plane writes)
     OFFK_TICK(5)
   };
-#undef OFFK_SB
 
-  // ---- prologue: DMA(0) [4], Wg(0) [6], DMA(1) [4], Wd(0) [3] ----
-  dma_prep(0);
-  dma_tile(0);
-  load_wg(0, 0);
-  dma_prep(min(1, nkt - 1));
-  dma_tile(1);
-  load_wd(0);
-  asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // DMA(0)
+  // ---- prologue: X(0) [4], X(1) [4], Wg(0) [6]; cut tile 0; X(2) [4], Wd(0) [3] -- the order the steps' wait counts assume ----
+  x_prep(0);
+  load_x(0, 0); load_x(0, 1);
+  x_prep(min(1, nkt - 1));
+  load_x(1, 0); load_x(1, 1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) cut_piece(i, 0, 0);
+  for (int n = 0; n < 6; ++n) load_wg1(0, n, 0);
+  asm volatile("s_waitcnt vmcnt(10)" : "+v"(xr[0][0][0]), "+v"(xr[0][0][1]), "+v"(xr[0][1][0]), "+v"(xr[0][1][1]) :: "memory");      // X(0)
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int st = 0; st < 6; ++st) atom_stage(st, a, 0, 0);
+  x_prep(min(2, nkt - 1));
+  load_x(0, 0); load_x(0, 1);
+  load_wd(0);
   __syncthreads();
 #ifdef OFFK_PT_TIMING
   const unsigned long long tm_loop = __builtin_readcyclecounter();
@@ -422,11 +346,13 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
 #ifdef OFFK_PT_TIMING
   const unsigned long long tm_epi = __builtin_readcyclecounter();
 #endif
-  // nothing may still be landing when the LDS is handed on; the weight registers stay allocated until their last load returned
+#undef OFFK_SB
+  // every load has returned before its registers die
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0][0][0]), "+v"(wg[0][0][1]), "+v"(wg[0][0][2]), "+v"(wg[0][1][0]), "+v"(wg[0][1][1]), "+v"(wg[0][1][2]),
                "+v"(wg[1][0][0]), "+v"(wg[1][0][1]), "+v"(wg[1][0][2]), "+v"(wg[1][1][0]), "+v"(wg[1][1][1]), "+v"(wg[1][1][2]) :: "memory");
-  asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]));
-#undef OFFK_WAIT_WG
+  asm volatile("" : "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]), "+v"(xr[0][0][0]), "+v"(xr[0][0][1]), "+v"(xr[0][1][0]), "+v"(xr[0][1][1]),
+               "+v"(xr[1][0][0]), "+v"(xr[1][0][1]), "+v"(xr[1][1][0]), "+v"(xr[1][1][1]));
+#undef OFFK_WAIT_STEP
 #undef OFFK_WAIT_WD
 
   // ---- epilogue (as pw_tdiff16_kernel): lane = (pixel li, channels 4 kq .. + 3 of a channel tile) ----
