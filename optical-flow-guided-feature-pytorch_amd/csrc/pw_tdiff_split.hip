@@ -117,18 +117,16 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
     xd_s0 = (((b * L + t0) * cpart + kl) * HW) * 4;
     xd_voff = vrow0 + (int)__umul24((unsigned)vclip, (unsigned)xd_fstride);
   };
-  auto load_x = [&](const int set, const int fs) {      // frame slot fs of the prepared K-tile into register set `set`
+  auto load_x1 = [&](const int set, const int fs, const int e) {      // row e of frame slot fs of the prepared K-tile into register set `set`
     const int fr = wave + 4 * fs;
     const int voff = fr < nf ? xd_voff : (int)0x80000000;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int so = xd_s0 + fr * xd_fstride + e * HW * 4;
+    const int so = xd_s0 + fr * xd_fstride + e * HW * 4;
 #if defined(OFFK_PS_EXP) && (OFFK_PS_EXP & 32)     /* timing experiment: no feature-map loads */
-      continue;
+    return;
 #endif
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(xr[set][fs][e]) : "v"(voff), "s"(xd_desc), "s"(so) : "memory");
-    }
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(xr[set][fs][e]) : "v"(voff), "s"(xd_desc), "s"(so) : "memory");
   };
+  auto load_x = [&](const int set, const int fs) { load_x1(set, fs, 0); load_x1(set, fs, 1); };
 
   // ---- the cut.  Atom a = (frame slot a >> 2, pixel i = a & 3 of the lane's quad): the lane's two k of that pixel -> one dword (k pair)
   //      of each plane.  In stages of two vector instructions, operands in registers between stages: a stage rides behind one MFMA
@@ -274,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
       t0 = mf(t0, w0[0], xx[0]); OFFK_SB;
       t1 = mf(t1, w1[0], xx[0]); OFFK_SB;
       if (j < 3) { load_wg1(ST ^ 1, 2 * j + 1, kn); OFFK_SB; }
-      if (j == 4) { load_x(ST ^ 1, 0); OFFK_SB; }          // atoms 0..3 have read slot 0 of the set
+      if (j == 4) { load_x1(ST ^ 1, 0, 0); OFFK_SB; }      // atoms 0..3 have read slot 0 of the set; one load per unit: eight waves' KBs in
+      if (j == 5) { load_x1(ST ^ 1, 0, 1); OFFK_SB; }      // one burst fill the CU's queue and the next instruction of every wave waits
     }
     OFFK_TICK(2)
     // the wave's down tiles: frames fd0 + 2 i (x[1] holds the first): one chain of six MFMAs each; beside them the scratch tiles of gen
@@ -286,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void pw_tdiff_split_kernel(PtParams p) {
     for (int i = 0; i < 4; ++i) {
       if (i + 1 < 4) rdx(x[i & 1], ST, i + 1 < 3 ? xoffD + 2 * (i + 1) * PS_FRAME : xoffD3);
       OFFK_SB;
-      if (i == 1) { load_x(ST ^ 1, 1); OFFK_SB; }          // atom 7 has read slot 1 (its stages 0, 1 ran beside the first down unit)
+      if (i == 1) { load_x1(ST ^ 1, 1, 0); OFFK_SB; }      // atom 7 has read slot 1 (its stages 0, 1 ran beside the first down unit)
+      if (i == 2) { load_x1(ST ^ 1, 1, 1); OFFK_SB; }
       const u32x4 (&xx)[3] = x[(i + 1) & 1];
       f32x4 &t0 = td[i & 1];
       const f32x4 &pd = td[(i - 1) & 1];
