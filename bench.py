@@ -57,6 +57,10 @@ def parse_args():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="N > 1 on a box with fewer GPUs than ranks: ranks share devices (rank %% device_count), scores go "
                          "over a gloo group (host-staged).  Exercises the multi-rank code path; not a scaling measurement")
+    ap.add_argument("--dump-scores", default=None, metavar="PATH",
+                    help="with a score exchange on the step (N > 1 or --collective-smoke): rank 0 writes the exchanged scores of the "
+                         "verification step, [3 heads (7, 14, 28)][world * clips][classes], to PATH (.npy) -- "
+                         "tests/test_gpu_two_ranks.py compares them with the oracle called per shard")
     return ap.parse_args()
 
 
@@ -610,18 +614,27 @@ def rccl_smoke_object(B, L, variant, weights, feats, dev, steps):
         h.load_state_dict(weights)
         arr = h._feat_array(feats)
         ncls = spec.NUM_CLASSES
-        local = torch.empty(3, B, ncls, device=dev)
-        gathered = torch.empty(1, 3, B, ncls, device=dev)
-        reduced = torch.zeros(3, B, ncls, device=dev)
+        local = [torch.empty(3, B, ncls, device=dev) for _ in range(2)]
+        gathered = [torch.empty(1, 3, B, ncls, device=dev) for _ in range(2)]
+        reduced = [torch.zeros(3, B, ncls, device=dev) for _ in range(2)]
+        xg, xr = odist.ScoreExchange(2), odist.ScoreExchange(2)
+        cnt = [0]
 
         def step():
-            h.forward_into(arr, local[0], local[1], local[2])
-            odist.all_gather_scores_into(gathered, local)
-            reduced.zero_()
-            reduced.copy_(local)
-            odist.all_reduce_scores_inplace(reduced)
+            # both forms of the exchange behind every forward, asynchronously (dist.ScoreExchange): the next forward is not ordered
+            # behind this step's collectives; a buffer set is waited for only when it comes round again, two steps later
+            i = cnt[0] & 1
+            cnt[0] += 1
+            xg.wait_slot(i)
+            xr.wait_slot(i)
+            h.forward_into(arr, local[i][0], local[i][1], local[i][2])
+            xg.all_gather(i, gathered[i], local[i])
+            reduced[i].copy_(local[i])
+            xr.all_reduce(i, reduced[i])
 
         def fence():
+            xg.finish()
+            xr.finish()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -629,9 +642,14 @@ def rccl_smoke_object(B, L, variant, weights, feats, dev, steps):
         for _ in range(3):
             step()
         dt = timed_loop(step, steps, fence)
-        rec.update(ms_per_step=dt / steps * 1e3, steps=steps, n_ranks_seen=dist.get_world_size(),
-                   per_step="consensus forward + all_gather_into_tensor + zero-buffer all_reduce",
-                   exchange_ok=bool(torch.equal(gathered[0], local) and torch.equal(reduced, local)))
+        # the plain step on the same handle, same loop: what the exchange costs the step
+        dt0 = timed_loop(lambda: h.forward_into(arr, local[0][0], local[0][1], local[0][2]), steps, torch.cuda.synchronize)
+        last = (cnt[0] - 1) & 1
+        rec.update(ms_per_step=dt / steps * 1e3, ms_per_step_without_exchange=dt0 / steps * 1e3,
+                   exchange_cost_us_per_step=(dt - dt0) / steps * 1e6, steps=steps, n_ranks_seen=dist.get_world_size(),
+                   per_step="consensus forward + all_gather_into_tensor + zero-buffer all_reduce, both async_op=True on two alternating "
+                            "buffer sets (the forward of step i + 1 is not ordered behind the exchange of step i)",
+                   exchange_ok=bool(torch.equal(gathered[last][0], local[last]) and torch.equal(reduced[last], local[last])))
     except Exception as e:      # noqa: BLE001 -- a broken RCCL install must not take the headline line with it
         rec["error"] = "%s: %s" % (type(e).__name__, e)
     return rec
@@ -693,8 +711,13 @@ def main():
         if local is None:     # the forward writes straight into its rows of the buffer
             local = [g[:, rank * rows:(rank + 1) * rows] for g in reduced]
     last_exchange = [None, 0]
+    # the exchange runs asynchronously (dist.ScoreExchange): the compute stream is not ordered behind the collective of the step before;
+    # a buffer set is waited for when it comes round again (two steps later), everything outstanding at the fences
+    xchg, xchg2 = odist.ScoreExchange(2), odist.ScoreExchange(2)
 
     def fence():
+        xchg.finish()
+        xchg2.finish()
         torch.cuda.synchronize()
         if coll:
             dist.barrier()
@@ -708,16 +731,16 @@ def main():
             fn = odist.gather_scores if args.collective == "allgather" else odist.gather_scores_allreduce
             last_exchange[0] = fn(mine)
         elif smoke:       # single-rank RCCL group: BOTH forms of the exchange, every step
-            odist.all_gather_scores_into(gathered[i], local[i])
+            xchg.all_gather(i, gathered[i], local[i])
             reduced[i].zero_()
             reduced[i][:, rank * rows:(rank + 1) * rows] = local[i]
-            odist.all_reduce_scores_inplace(reduced[i])
+            xchg2.all_reduce(i, reduced[i])
             last_exchange[0] = gathered[i]
         elif args.collective == "allgather":
-            odist.all_gather_scores_into(gathered[i], local[i])
+            xchg.all_gather(i, gathered[i], local[i])
             last_exchange[0] = gathered[i]
         else:
-            odist.all_reduce_scores_inplace(reduced[i])
+            xchg.all_reduce(i, reduced[i])
             last_exchange[0] = reduced[i]
 
     def measure(precision, steps, warmup, variant=variant, weights=weights, feats=feats, consensus=consensus, k2=True):
@@ -732,6 +755,8 @@ def main():
             if coll:
                 i = counter[0] & 1
                 counter[0] += 1
+                xchg.wait_slot(i)             # the collective that used this buffer set two steps ago
+                xchg2.wait_slot(i)
                 if args.collective == "allreduce" and not smoke:
                     reduced[i].zero_()
                 h.forward_into(arr, local[i][0], local[i][1], local[i][2])
@@ -775,12 +800,16 @@ def main():
     exchange_ok = None
     if coll:
         i_chk = 0
+        xchg.finish()
+        xchg2.finish()
         if reduced is not None and not smoke and args.collective == "allreduce":
             reduced[i_chk].zero_()
         h.forward_into(h._feat_array(feats), local[i_chk][0], local[i_chk][1], local[i_chk][2])
         torch.cuda.synchronize()
         mine = torch.stack([local[i_chk][k] for k in range(3)], 0).clone()
         exchange(i_chk)
+        xchg.finish()
+        xchg2.finish()
         torch.cuda.synchronize()
         got = last_exchange[0]
         if torch.is_tensor(got) and got.dim() == 4:      # all-gather layout [rank][head][row] -> [head][rank * rows + row]
@@ -795,6 +824,8 @@ def main():
         for r in range(world):      # the shards are different clips: no two ranks may hold the same rows
             if r != rank:
                 good = good and not torch.equal(ref[:, r * rows:(r + 1) * rows], mine.cpu())
+        if args.dump_scores and rank == 0:
+            np.save(args.dump_scores, got.numpy())
         ok = torch.tensor([1.0 if good else 0.0], device="cpu" if over else dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         exchange_ok = bool(ok.item() == 1.0)

@@ -39,18 +39,53 @@ def _active(group, always):
     return always or dist.get_world_size(group) > 1
 
 
-def all_gather_scores_into(gathered, local, group=None):
+def all_gather_scores_into(gathered, local, group=None, async_op=False):
     """One fused all-gather of this rank's [heads, b, classes] scores into ``gathered`` [world, heads, b, classes] (both contiguous,
-    caller-owned: the benchmark alternates two buffer sets).  CUDA/HIP tensors: RCCL ``all_gather_into_tensor``."""
+    caller-owned: the benchmark alternates two buffer sets).  CUDA/HIP tensors: RCCL ``all_gather_into_tensor``.
+
+    ``async_op=True`` returns the collective's work handle instead of waiting on it: RCCL runs the exchange on its own stream
+    behind the forward that produced ``local``, and the CALLER's stream is not ordered behind it -- the forward of the next step
+    starts while the scores of this one travel.  ``wait()`` the handle in front of whatever reads ``gathered`` or re-uses either
+    buffer (``ScoreExchange`` below does that for a loop of steps).  With ``async_op=False`` the current stream waits for the
+    exchange at once: one step's wire time in front of every next forward."""
     world, heads, b, c = gathered.shape
-    dist.all_gather_into_tensor(gathered.view(world * heads * b, c), local.view(heads * b, c), group=group)
-    return gathered
+    work = dist.all_gather_into_tensor(gathered.view(world * heads * b, c), local.view(heads * b, c), group=group, async_op=async_op)
+    return work if async_op else gathered
 
 
-def all_reduce_scores_inplace(buf, group=None):
-    """The literal north-star form: ``buf`` [heads, world * b, classes] is zero except for this rank's rows; ONE sum all-reduce."""
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return buf
+def all_reduce_scores_inplace(buf, group=None, async_op=False):
+    """The literal north-star form: ``buf`` [heads, world * b, classes] is zero except for this rank's rows; ONE sum all-reduce.
+    ``async_op`` as in all_gather_scores_into."""
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else buf
+
+
+class ScoreExchange:
+    """The per-step exchange of a loop of forwards with the collective OFF the compute stream's critical path: ``nbuf`` alternating
+    buffer sets; step i launches its collective asynchronously and only waits for the collective that used the same buffer set
+    ``nbuf`` steps earlier (long finished).  ``finish()`` waits for everything outstanding -- call it in front of the consumer of
+    the gathered scores.  form: "allgather" (RCCL all_gather_into_tensor into [world, heads, b, classes]) or "allreduce" (the
+    zero-buffer sum all-reduce of [heads, world * b, classes]; the caller fills its rows, e.g. as the forward's outputs)."""
+
+    def __init__(self, nbuf=2, group=None):
+        self.group, self.pending = group, [None] * nbuf
+
+    def wait_slot(self, i):
+        """Before buffer set ``i`` is written again (by the next forward into it, or by zeroing it)."""
+        w = self.pending[i]
+        if w is not None:
+            w.wait()
+            self.pending[i] = None
+
+    def all_gather(self, i, gathered, local):
+        self.pending[i] = all_gather_scores_into(gathered, local, group=self.group, async_op=True)
+
+    def all_reduce(self, i, buf):
+        self.pending[i] = all_reduce_scores_inplace(buf, group=self.group, async_op=True)
+
+    def finish(self):
+        for i in range(len(self.pending)):
+            self.wait_slot(i)
 
 
 def gather_scores(local, group=None, always=False):
