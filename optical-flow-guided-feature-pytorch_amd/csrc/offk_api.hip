@@ -157,6 +157,7 @@ struct offk_handle {
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
   float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
+  int split_pc = 1;                 // OFFK_SPLIT_PC: 0 / 1 (default: by size) / 2 -- which split-fp32 units kernel (PtParams.split_pc)
   bool f32split = false;            // created with OFFK_PRECISION_F32SPLIT: cfg.precision is OFFK_PRECISION_FP32 inside the library, the
                                     // kernels that have a split form take it
   bool pw_dirty = true;
@@ -576,6 +577,7 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   // the operand-order weight image is the library's own copy: not with contraction weights bound in place
   pt.bdirect = 1;
   pt.f32split = h->f32split;
+  pt.split_pc = h->split_pc;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
@@ -798,6 +800,7 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   //   OFFK_WINO_GEMM     the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); 0: one block of the generic 1x1 kernel per
   //                      tile (bit-identical).  The handle-less stage entry points read it once per process.
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
+  { const char* e = getenv("OFFK_SPLIT_PC"); if (e && *e >= '0' && *e <= '2') h->split_pc = *e - '0'; }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINO_MID"); h->wino_mid = !(e && *e == '0'); }

@@ -34,6 +34,13 @@ def dev(x):
     return torch.as_tensor(x).to("cuda").contiguous()
 
 
+@pytest.fixture(params=["0", "2"], ids=["two-blocks-per-CU", "producer-consumer"])
+def split_form(request, monkeypatch):
+    """OFFK_SPLIT_PC (read at offk_create): both forms of the split-fp32 units kernel at every test size (the default picks by size)."""
+    monkeypatch.setenv("OFFK_SPLIT_PC", request.param)
+    return request.param
+
+
 def make_handle(rt, B, L, precision, weights=None, variant=spec.VARIANT_RGB):
     h = rt.OffForward(B, L, variant, spec.SLICE_FLAT, None, precision=precision)
     w = synth.make_weights(variant) if weights is None else weights
@@ -99,7 +106,7 @@ def run_units(rt, B, L, precision, feats_np, weights=None):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind):
+def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind, split_form):
     B, L = 2, 7
     feats_np = synth.make_features_kind(B, L, 4, kind)
     stats = {}
@@ -119,7 +126,7 @@ def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind):
     assert stats["f32split"]["max_over_max"] < 2e-6 and stats["f32split"]["c_max"] < 16.0
 
 
-def test_units_split_cancellation_case(rt):
+def test_units_split_cancellation_case(rt, split_form):
     """tests/test_gpu_parity.py::test_pw_reduce_cancellation_case on the fused kernels: every channel of a pixel carries the
     same value and every weight row sums to zero -- the exact G is relu(bias), the exact T is 0, the exact D is the bias."""
     B, L = 2, 7
@@ -145,7 +152,7 @@ def test_units_split_cancellation_case(rt):
 
 
 @pytest.mark.parametrize("B,L", [(1, 2), (3, 3), (2, 9), (5, 7)])
-def test_units_split_shapes(rt, B, L):
+def test_units_split_shapes(rt, B, L, split_form):
     """Short clips (frames past the group read zeros), two temporal groups (L = 9), odd batches (packed 14x14 leftovers, the 7x7
     quad stream crossing clip boundaries): every T and D element against fp64."""
     feats_np = synth.make_features(B, L, 5)
