@@ -847,6 +847,10 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
       if (hb[18])
         fprintf(stderr, "[pt timing, split form, wave 0 cycles] prologue %llu loop %llu epilogue+drain %llu | per step: dma-issue %llu wait-Wg %llu gen pass %llu wait-Wd %llu "
                 "down pass + cut %llu barrier %llu | ktiles %llu blocks %llu\n", hb[8], hb[9], hb[10], hb[11], hb[12], hb[13], hb[14], hb[15], hb[16], hb[17], hb[18]);
+      if (hb[24])
+        fprintf(stderr, "[pt timing, producer / consumer form, cycles of producer 0 / consumer 0 of a block] producer: wait for loads %llu cut + issue %llu barrier %llu | "
+                "consumer: steps %llu barrier %llu item boundary (locate + epilogue) %llu | tiles %llu blocks %llu items %llu\n",
+                hb[20], hb[21], hb[22], hb[25], hb[26], hb[27], hb[23], hb[24], hb[28]);
       (void)hipMemset(dbg, 0, 256);
     }
   }

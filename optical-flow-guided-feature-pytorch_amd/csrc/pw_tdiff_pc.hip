@@ -186,16 +186,31 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
     // slots in pairs, register set 0 then set 1, straight-line (a set picked by a branch on the slot's parity made hipcc merge the two
     // sets' registers through COPIES -- of registers whose loads were still in flight: stale data, silently)
     int stage = 0;
+#ifdef OFFK_PT_TIMING
+    unsigned long long tp[3] = {0, 0, 0}, tc_ = __builtin_readcyclecounter();
+#define OFFK_PTICK(i) { const unsigned long long c_ = __builtin_readcyclecounter(); tp[i] += c_ - tc_; tc_ = c_; }
+#else
+#define OFFK_PTICK(i)
+#endif
     auto slot = [&](const int set, int s) {
       if (s < T) {
         if (set) asm volatile("s_waitcnt vmcnt(4)" : "+v"(xr[1][0][0]), "+v"(xr[1][0][1]), "+v"(xr[1][1][0]), "+v"(xr[1][1][1]) :: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" : "+v"(xr[0][0][0]), "+v"(xr[0][0][1]), "+v"(xr[0][1][0]), "+v"(xr[0][1][1]) :: "memory");
+        OFFK_PTICK(0)
+#if !(defined(OFFK_PC_EXP) && (OFFK_PC_EXP & 1))     /* timing experiment 1: the producers cut nothing */
         cut_tile(set, stage);
+#endif
+#if !(defined(OFFK_PC_EXP) && (OFFK_PC_EXP & 2))     /* timing experiment 2: ... and load only zeros */
         load_tile(set, s + 2 < T);
+#else
+        load_tile(set, false);
+#endif
         if (s + 2 < T) advance();
         stage = stage == PC_NST - 1 ? 0 : stage + 1;
+        OFFK_PTICK(1)
       }
       __syncthreads();
+      OFFK_PTICK(2)
     };
     for (int s = 0; s < T + 2; s += 2) {
       slot(0, s);
@@ -203,6 +218,9 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0][0][0]), "+v"(xr[0][0][1]), "+v"(xr[0][1][0]), "+v"(xr[0][1][1]),
                  "+v"(xr[1][0][0]), "+v"(xr[1][0][1]), "+v"(xr[1][1][0]), "+v"(xr[1][1][1]) :: "memory");
+#ifdef OFFK_PT_TIMING
+    if (p.dbg && threadIdx.x == 256) { atomicAdd(p.dbg + 20, tp[0]); atomicAdd(p.dbg + 21, tp[1]); atomicAdd(p.dbg + 22, tp[2]); atomicAdd(p.dbg + 23, (unsigned long long)T); atomicAdd(p.dbg + 24, 1ull); }
+#endif
     return;
   }
 
@@ -250,14 +268,14 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
 #define OFFK_WAIT_W(set) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[set][0][0]), "+v"(wg[set][0][1]), "+v"(wg[set][0][2]), "+v"(wg[set][1][0]), \
                                       "+v"(wg[set][1][1]), "+v"(wg[set][1][2]), "+v"(wd[0]), "+v"(wd[1]), "+v"(wd[2]) :: "memory")
 
-  f32x4 ag[PC_FT][2], ad[4], t[3];
+  f32x4 ag[PC_FT][2], ad[4], t[2][6];          // t[unit parity][chain a of tile 0..2 | chain b of tile 0..2]
   auto zero_acc = [&]() {
 #pragma unroll
     for (int j = 0; j < PC_FT; ++j) { ag[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) ad[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) t[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 6; ++c) { t[0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; t[1][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   };
   zero_acc();
 
@@ -272,10 +290,12 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
   auto mf = [&](f32x4 c, const u32x4& a, const u32x4& bb) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), c, 0, 0, 0);
   };
-  auto fold = [&](f32x4& acc, const f32x4& tv) {
-    acc.x += tv.x; acc.y += tv.y; acc.z += tv.z; acc.w += tv.w;
+  auto fold2 = [&](f32x4& acc, const f32x4& tv, const int hi) {      // half of a scratch tile into its accumulator (two v_add_f32)
+    if (hi) { acc.z += tv.z; acc.w += tv.w; } else { acc.x += tv.x; acc.y += tv.y; }
     asm volatile("" : "+v"(acc));           // the update stays where it is written
   };
+  auto fold = [&](f32x4& acc, const f32x4& tv) { fold2(acc, tv, 0); fold2(acc, tv, 1); };
+  auto rd1 = [&](u32x4& dst, const char* sb, int off) { dst = *reinterpret_cast<const u32x4*>(sb + off); };
   u32x4 x[2][2][3];                          // [unit parity][operand A / B of the unit][plane]
 #define OFFK_SB __builtin_amdgcn_sched_barrier(0)
 #ifdef OFFK_PC_DBG_NOPRE
@@ -309,61 +329,90 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
     rdx(x[0][1], sb, xoffD);
 #endif
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    // unit u: chain c multiplies (weights wq[c], operand xq[c]); its scratch tile t[c] first goes into the accumulator of the chain that
-    // used it one unit ago (ft[c]); products smallest first: w_l x_h, w_h x_l, w_m x_m, w_m x_h, w_h x_m, w_h x_h (planes 0 = h, 1 = m, 2 = l)
-#define OFFK_UNIT(u, W0, X0, F0, W1, X1, F1, W2, X2, F2, PREFETCH, LOADS)                                        \
+    // unit u: three tiles (weights W, operand X).  The six products of a tile are TWO chains of three (a: w_l x_h, w_h x_l, w_m x_m;
+    // b: w_m x_h, w_h x_m, w_h x_h; planes 0 = h, 1 = m, 2 = l) -- six chains per unit: a dependent v_mfma_f32_16x16x32_bf16 is ~5 issue
+    // slots away (probe_vmem_issue.txt: 25.8 / 19.7 / 13.7 cycles per MFMA with 3 / 4 / 6 chains on a wave that has its SIMD to itself), and
+    // ONE wave per SIMD multiplies here.  The tile's two scratch tiles are summed and added to the accumulator during the NEXT unit: the
+    // running sum is still rounded once per 32 k.  Nothing covers an instruction that does not fit into the 8 issue cycles an MFMA leaves
+    // free of its 16: behind MFMA n at most two vector adds (n = 0..11: the folds), one LDS read (12..17: the operands of the next unit) and
+    // one weight load (16, 17).
+#define OFFK_FOLD(n, F, TP, c)                                                                                   \
+    if ((n) == 0) { TP[c].x += TP[c + 3].x; TP[c].y += TP[c + 3].y; }                                            \
+    if ((n) == 1) { TP[c].z += TP[c + 3].z; TP[c].w += TP[c + 3].w; }                                            \
+    if ((n) == 2) { F.x += TP[c].x; F.y += TP[c].y; asm volatile("" : "+v"(F)); }                                \
+    if ((n) == 3) { F.z += TP[c].z; F.w += TP[c].w; asm volatile("" : "+v"(F)); }
+#define OFFK_UNIT(TC, TP, W0, X0, F0, W1, X1, F1, W2, X2, F2, NA, NAOFF, NB, NBOFF, NBASE, LD0, LD1)             \
     {                                                                                                            \
-      fold(F0, t[0]); t[0] = mf(z, W0[2], X0[0]); OFFK_SB;                                                       \
-      fold(F1, t[1]); t[1] = mf(z, W1[2], X1[0]); OFFK_SB;                                                       \
-      fold(F2, t[2]); t[2] = mf(z, W2[2], X2[0]); OFFK_SB;                                                       \
-      PREFETCH                                                                                                   \
-      OFFK_SB;                                                                                                   \
-      t[0] = mf(t[0], W0[0], X0[2]); OFFK_SB; t[1] = mf(t[1], W1[0], X1[2]); OFFK_SB; t[2] = mf(t[2], W2[0], X2[2]); OFFK_SB; \
-      LOADS                                                                                                      \
-      OFFK_SB;                                                                                                   \
-      t[0] = mf(t[0], W0[1], X0[1]); OFFK_SB; t[1] = mf(t[1], W1[1], X1[1]); OFFK_SB; t[2] = mf(t[2], W2[1], X2[1]); OFFK_SB; \
-      t[0] = mf(t[0], W0[1], X0[0]); OFFK_SB; t[1] = mf(t[1], W1[1], X1[0]); OFFK_SB; t[2] = mf(t[2], W2[1], X2[0]); OFFK_SB; \
-      t[0] = mf(t[0], W0[0], X0[1]); OFFK_SB; t[1] = mf(t[1], W1[0], X1[1]); OFFK_SB; t[2] = mf(t[2], W2[0], X2[1]); OFFK_SB; \
-      t[0] = mf(t[0], W0[0], X0[0]); OFFK_SB; t[1] = mf(t[1], W1[0], X1[0]); OFFK_SB; t[2] = mf(t[2], W2[0], X2[0]); OFFK_SB; \
+      TC[0] = mf(z, W0[2], X0[0]);      OFFK_FOLD(0, F0, TP, 0) OFFK_SB;                                         \
+      TC[1] = mf(z, W1[2], X1[0]);      OFFK_FOLD(1, F0, TP, 0) OFFK_SB;                                         \
+      TC[2] = mf(z, W2[2], X2[0]);      OFFK_FOLD(0, F1, TP, 1) OFFK_SB;                                         \
+      TC[3] = mf(z, W0[1], X0[0]);      OFFK_FOLD(1, F1, TP, 1) OFFK_SB;                                         \
+      TC[4] = mf(z, W1[1], X1[0]);      OFFK_FOLD(0, F2, TP, 2) OFFK_SB;                                         \
+      TC[5] = mf(z, W2[1], X2[0]);      OFFK_FOLD(1, F2, TP, 2) OFFK_SB;                                         \
+      TC[0] = mf(TC[0], W0[0], X0[2]);  OFFK_FOLD(2, F0, TP, 0) OFFK_SB;                                         \
+      TC[1] = mf(TC[1], W1[0], X1[2]);  OFFK_FOLD(3, F0, TP, 0) OFFK_SB;                                         \
+      TC[2] = mf(TC[2], W2[0], X2[2]);  OFFK_FOLD(2, F1, TP, 1) OFFK_SB;                                         \
+      TC[3] = mf(TC[3], W0[0], X0[1]);  OFFK_FOLD(3, F1, TP, 1) OFFK_SB;                                         \
+      TC[4] = mf(TC[4], W1[0], X1[1]);  OFFK_FOLD(2, F2, TP, 2) OFFK_SB;                                         \
+      TC[5] = mf(TC[5], W2[0], X2[1]);  OFFK_FOLD(3, F2, TP, 2) OFFK_SB;                                         \
+      TC[0] = mf(TC[0], W0[1], X0[1]);  rd1(NA[0], NBASE, NAOFF); OFFK_SB;                                       \
+      TC[1] = mf(TC[1], W1[1], X1[1]);  rd1(NA[1], NBASE, NAOFF + PC_PLANE); OFFK_SB;                            \
+      TC[2] = mf(TC[2], W2[1], X2[1]);  rd1(NA[2], NBASE, NAOFF + 2 * PC_PLANE); OFFK_SB;                        \
+      TC[3] = mf(TC[3], W0[0], X0[0]);  rd1(NB[0], NBASE, NBOFF); OFFK_SB;                                       \
+      TC[4] = mf(TC[4], W1[0], X1[0]);  rd1(NB[1], NBASE, NBOFF + PC_PLANE); LD0; OFFK_SB;                       \
+      TC[5] = mf(TC[5], W2[0], X2[0]);  rd1(NB[2], NBASE, NBOFF + 2 * PC_PLANE); LD1; OFFK_SB;                   \
     }
     const u32x4 (&g0)[3] = wg[WS][0];
     const u32x4 (&g1)[3] = wg[WS][1];
     const u32x4 (&dw)[3] = wd;
     // unit 0: frame 0 tiles 0, 1 + down frame 0 (folds: the chains of unit 5 of the step before: frame 5 tile 1, frame 6 tiles 0, 1)
-    OFFK_UNIT(0, g0, x[0][0], ag[5][1], g1, x[0][0], ag[6][0], dw, x[0][1], ag[6][1],
-              rdx(x[1][0], sb, 1 * PC_FRAME); rdx(x[1][1], sb, xoffD + 2 * PC_FRAME);, load_wg1(WS ^ 1, 0); load_wg1(WS ^ 1, 1);)
-    OFFK_UNIT(1, g0, x[1][0], ag[0][0], g1, x[1][0], ag[0][1], dw, x[1][1], ad[0],
-              rdx(x[0][0], sb, 2 * PC_FRAME); rdx(x[0][1], sb, xoffD + 4 * PC_FRAME);, load_wg1(WS ^ 1, 2); load_wg1(WS ^ 1, 3);)
-    OFFK_UNIT(2, g0, x[0][0], ag[1][0], g1, x[0][0], ag[1][1], dw, x[0][1], ad[1],
-              rdx(x[1][0], sb, 3 * PC_FRAME); rdx(x[1][1], sb, xoffD3);, load_wg1(WS ^ 1, 4); load_wg1(WS ^ 1, 5);)
-    OFFK_UNIT(3, g0, x[1][0], ag[2][0], g1, x[1][0], ag[2][1], dw, x[1][1], ad[2],
-              rdx(x[0][0], sb, 4 * PC_FRAME); rdx(x[0][1], sb, 5 * PC_FRAME);, ;)
-    // unit 4: frame 4 tiles 0, 1, frame 5 tile 0
-    OFFK_UNIT(4, g0, x[0][0], ag[3][0], g1, x[0][0], ag[3][1], g0, x[0][1], ad[3],
-              rdx(x[1][0], sb, 5 * PC_FRAME); rdx(x[1][1], sb, 6 * PC_FRAME);, load_wd1(0); load_wd1(1); load_wd1(2);)
+    OFFK_UNIT(t[0], t[1], g0, x[0][0], ag[5][1], g1, x[0][0], ag[6][0], dw, x[0][1], ag[6][1],
+              x[1][0], 1 * PC_FRAME, x[1][1], xoffD + 2 * PC_FRAME, sb, load_wg1(WS ^ 1, 0), load_wg1(WS ^ 1, 1))
+    OFFK_UNIT(t[1], t[0], g0, x[1][0], ag[0][0], g1, x[1][0], ag[0][1], dw, x[1][1], ad[0],
+              x[0][0], 2 * PC_FRAME, x[0][1], xoffD + 4 * PC_FRAME, sb, load_wg1(WS ^ 1, 2), load_wg1(WS ^ 1, 3))
+    OFFK_UNIT(t[0], t[1], g0, x[0][0], ag[1][0], g1, x[0][0], ag[1][1], dw, x[0][1], ad[1],
+              x[1][0], 3 * PC_FRAME, x[1][1], xoffD3, sb, load_wg1(WS ^ 1, 4), load_wg1(WS ^ 1, 5))
+    OFFK_UNIT(t[1], t[0], g0, x[1][0], ag[2][0], g1, x[1][0], ag[2][1], dw, x[1][1], ad[2],
+              x[0][0], 4 * PC_FRAME, x[0][1], 5 * PC_FRAME, sb, (void)0, (void)0)
+    // unit 4: frame 4 tiles 0, 1, frame 5 tile 0 (the down chain is done: its weights of the next tile)
+    OFFK_UNIT(t[0], t[1], g0, x[0][0], ag[3][0], g1, x[0][0], ag[3][1], g0, x[0][1], ad[3],
+              x[1][0], 5 * PC_FRAME, x[1][1], 6 * PC_FRAME, sb, load_wd1(0), load_wd1(1))
     // unit 5: frame 5 tile 1, frame 6 tiles 0, 1; reads the first operands of the next tile
-    OFFK_UNIT(5, g1, x[1][0], ag[4][0], g0, x[1][1], ag[4][1], g1, x[1][1], ag[5][0],
-              OFFK_PC_NEXT_OPERANDS, ;)
+    OFFK_UNIT(t[1], t[0], g1, x[1][0], ag[4][0], g0, x[1][1], ag[4][1], g1, x[1][1], ag[5][0],
+              x[0][0], 0, x[0][1], xoffD, nb, load_wd1(2), (void)0)
 #undef OFFK_UNIT
+#undef OFFK_FOLD
     stage = nstage;
   };
 
   // Every item starts on weight set 0: two copies of the step in sequence (set 0, set 1, ...; chosen per tile by a branch the two
   // copies met at a merge that cost hipcc ~120 spilled registers); an item with an odd number of K-tiles leaves the next item's first
   // weights in set 1 -- moved over once (24 register moves per item of 19 steps).
+#ifdef OFFK_PT_TIMING
+  unsigned long long tq[3] = {0, 0, 0}, tc_ = __builtin_readcyclecounter();
+  int n_items = 0;
+#define OFFK_CTICK(i) { const unsigned long long c_ = __builtin_readcyclecounter(); tq[i] += c_ - tc_; tc_ = c_; }
+#else
+#define OFFK_CTICK(i)
+#endif
   int gtile = 0;
   for (int l = (int)blockIdx.x; l < p.total_blocks; l += G) {
     PcItem it;
     pc_locate(p, l, it);
     bool odd;
+    OFFK_CTICK(2)
     for (int kt = 0;;) {
       step(0);
       if (++gtile < T) w_advance();
+      OFFK_CTICK(0)
       __syncthreads();
+      OFFK_CTICK(1)
       if (++kt == it.nkt) { odd = true; break; }
       step(1);
       if (++gtile < T) w_advance();
+      OFFK_CTICK(0)
       __syncthreads();
+      OFFK_CTICK(1)
       if (++kt == it.nkt) { odd = false; break; }
     }
     if (odd) {
@@ -374,7 +423,8 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
         for (int q = 0; q < 3; ++q) wg[0][c][q] = wg[1][c][q];
     }
     // the last unit's scratch tiles
-    fold(ag[5][1], t[0]); fold(ag[6][0], t[1]); fold(ag[6][1], t[2]);
+    fold(ag[5][1], t[1][0]); fold(ag[6][0], t[1][1]); fold(ag[6][1], t[1][2]);
+    fold(ag[5][1], t[1][3]); fold(ag[6][0], t[1][4]); fold(ag[6][1], t[1][5]);
 
     // ---- epilogue (as pw_tdiff_split_kernel): lane = (pixel li, channels 4 lg .. + 3 of a channel tile) ----
     const PtSite& S = p.s[it.si];
@@ -414,7 +464,14 @@ __global__ __launch_bounds__(512, 1) void pw_tdiff_pc_kernel(PtParams p) {
       }
     }
     zero_acc();
+#ifdef OFFK_PT_TIMING
+    ++n_items;
+#endif
+    OFFK_CTICK(2)
   }
+#ifdef OFFK_PT_TIMING
+  if (p.dbg && threadIdx.x == 0) { atomicAdd(p.dbg + 25, tq[0]); atomicAdd(p.dbg + 26, tq[1]); atomicAdd(p.dbg + 27, tq[2]); atomicAdd(p.dbg + 28, (unsigned long long)n_items); }
+#endif
 #undef OFFK_SB
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(wg[0][0][0]), "+v"(wg[0][0][1]), "+v"(wg[0][0][2]), "+v"(wg[0][1][0]), "+v"(wg[0][1][1]), "+v"(wg[0][1][2]),
                "+v"(wg[1][0][0]), "+v"(wg[1][0][1]), "+v"(wg[1][0][2]), "+v"(wg[1][1][0]), "+v"(wg[1][1][1]), "+v"(wg[1][1][2]) :: "memory");

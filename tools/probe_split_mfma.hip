@@ -71,6 +71,9 @@ __device__ __forceinline__ void split8_rne(const float (&v)[8], u32x4& h, u32x4&
 //       5 nine, two accumulators (hh | the rest)              6 six, two accumulators
 //       7 nine, three accumulators (hh | hm mh | the rest)    8 three products of a two-plane cut (the round-2 "bf16x3" mode)
 //       9 six, three accumulators                             10 nine, one acc, RNE cut     11 six, one acc, RNE cut
+//       12 six: the three small ones summed from zero per 32-k step and added to the accumulator once per step, the three large ones
+//          (w_m x_h, w_h x_m, w_h x_h) accumulated directly -- two chains of three per tile (the kernels' form since the chain-latency probe)
+//       13 six, all summed from zero per 32-k step and added once per step (the kernels' first form)
 template <int MODE>
 __global__ __launch_bounds__(64) void contract(const float* __restrict__ W, const float* __restrict__ X, float* __restrict__ out, int K, int NPX) {
   const int lane = threadIdx.x, i16 = lane & 15, g = lane >> 4;
@@ -113,6 +116,15 @@ __global__ __launch_bounds__(64) void contract(const float* __restrict__ W, cons
         MF(c2, wl, xl); MF(c2, wl, xm); MF(c2, wm, xl); MF(c2, wl, xh); MF(c2, wh, xl); MF(c2, wm, xm); MF(c1, wm, xh); MF(c1, wh, xm); MF(c0, wh, xh);
       } else if (MODE == 9) {
         MF(c2, wl, xh); MF(c2, wh, xl); MF(c2, wm, xm); MF(c1, wm, xh); MF(c1, wh, xm); MF(c0, wh, xh);
+      } else if (MODE == 12) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        MF(t, wl, xh); MF(t, wh, xl); MF(t, wm, xm);
+        MF(c0, wm, xh); MF(c0, wh, xm); MF(c0, wh, xh);
+        c0 = c0 + t;
+      } else if (MODE == 13) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        MF(t, wl, xh); MF(t, wh, xl); MF(t, wm, xm); MF(t, wm, xh); MF(t, wh, xm); MF(t, wh, xh);
+        c0 = c0 + t;
       }
     }
     c0 = c0 + (c1 + c2);
@@ -267,6 +279,8 @@ int main() {
       if (run_mode<11>("6 products, 1 acc, small first, RNE cut", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
       if (run_mode<6>("6 products, 2 acc (hh | rest)", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
       if (run_mode<9>("6 products, 3 acc (hh | hm mh | rest)", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
+      if (run_mode<13>("6 products from zero per step, one add per step", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
+      if (run_mode<12>("3 small from zero + add per step, 3 large direct", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
       if (run_mode<4>("8 products, 1 acc, small first", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
       if (run_mode<1>("9 products, 1 acc, small first", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;
       if (run_mode<10>("9 products, 1 acc, small first, RNE cut", dW, dX, dO, CH, NPX, K, ref, mag, refmax)) return 1;

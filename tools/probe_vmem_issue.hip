@@ -202,6 +202,98 @@ static int run_pc(const char* what, const float* src, float* out, unsigned long 
   return 0;
 }
 
+// chains: one wave per SIMD, NCH independent accumulation chains round-robin, 6 MFMAs per chain per round (in-place accumulate)
+template <int NCH>
+__global__ __launch_bounds__(256, 1) void kchains(float* out, int rounds, unsigned long long* cyc) {
+  const int lane = threadIdx.x & 63;
+  u32x4 a[3], b[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { a[q] = u32x4{0x3f803f80u + lane, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u}; b[q] = u32x4{0x3f803f80u, 0x3f003f00u + q, 0x3e803e80u, 0x3f803f80u}; }
+  f32x4 t[NCH], acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  for (int r = 0; r < rounds; ++r) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { t[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[2]), __builtin_bit_cast(bf16x8, b[c % 3]), z, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) { t[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s % 3]), __builtin_bit_cast(bf16x8, b[(s + c) % 3]), t[c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc += t[c];
+    asm volatile("" : "+v"(acc));
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) atomicAdd(cyc, c1 - c0);
+  if (acc[0] == 123.25f) out[threadIdx.x] = acc[1];
+}
+template <int NCH>
+static int run_ch(float* out, unsigned long long* cyc, int ncu) {
+  const int rounds = 2000;
+  CK(hipMemset(cyc, 0, 8));
+  hipLaunchKernelGGL(kchains<NCH>, dim3(ncu), dim3(256), 0, 0, out, rounds, cyc);
+  CK(hipDeviceSynchronize());
+  unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+  printf("  %d chains x 6 MFMAs per round, one wave per SIMD: %6.2f cycles per MFMA (the adds of the %d scratch tiles at the end of a round included)\n", NCH,
+         (double)c / ncu / rounds / (6.0 * NCH), NCH);
+  return 0;
+}
+
+// the same with side work behind every MFMA: SIDE bit 0: two v_add_f32 on other registers; bit 1: one ds_read_b128 behind every third MFMA
+// (operands of later MFMAs: consumed two rounds later); bit 2: the B operands come from those reads (rotating registers)
+template <int NCH, int SIDE>
+__global__ __launch_bounds__(256, 1) void kside(float* out, int rounds, unsigned long long* cyc) {
+  __shared__ __attribute__((aligned(16))) char lds[16384];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<unsigned*>(lds)[i] = 0x3f803f80u + (i & 7);
+  __syncthreads();
+  u32x4 a[3], b[3], xb[2][3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { a[q] = u32x4{0x3f803f80u + lane, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u}; b[q] = u32x4{0x3f803f80u, 0x3f003f00u + q, 0x3e803e80u, 0x3f803f80u}; xb[0][q] = b[q]; xb[1][q] = b[q]; }
+  f32x4 t[NCH], acc = {0.f, 0.f, 0.f, 0.f}, junk[4] = {acc, acc, acc, acc};
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const char* rd = lds + lane * 16;
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  for (int r = 0; r < rounds; ++r) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+    const int par = r & 1;
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u32x4& bb = (SIDE & 4) ? xb[0][(s + c) % 3] : b[(s + c) % 3];
+        t[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s % 3]), __builtin_bit_cast(bf16x8, bb), s == 0 ? z : t[c], 0, 0, 0);
+        if (SIDE & 1) { junk[n & 3].x += junk[(n + 1) & 3].y; junk[n & 3].z += junk[(n + 1) & 3].w; asm volatile("" : "+v"(junk[n & 3])); }
+        if ((SIDE & 2) && n % 3 == 0 && n / 3 < 3) xb[1][n / 3] = *reinterpret_cast<const u32x4*>(rd + (n / 3) * 1024 + par * 4096);
+        __builtin_amdgcn_sched_barrier(0);
+        ++n;
+      }
+    if (SIDE & 2) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const u32x4 tmp = xb[0][q]; xb[0][q] = xb[1][q]; xb[1][q] = tmp; }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc += t[c];
+    asm volatile("" : "+v"(acc));
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) atomicAdd(cyc, c1 - c0);
+  if (acc[0] + junk[0].x + junk[1].x + junk[2].x + junk[3].x == 123.25f) out[threadIdx.x] = acc[1];
+}
+template <int NCH, int SIDE>
+static int run_side(float* out, unsigned long long* cyc, int ncu) {
+  const int rounds = 2000;
+  CK(hipMemset(cyc, 0, 8));
+  hipLaunchKernelGGL((kside<NCH, SIDE>), dim3(ncu), dim3(256), 0, 0, out, rounds, cyc);
+  CK(hipDeviceSynchronize());
+  unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+  printf("  %d chains, side work %d (1: two adds per MFMA, 2: an LDS read per three MFMAs, 4: operands from those reads): %6.2f cycles per MFMA\n", NCH, SIDE,
+         (double)c / ncu / rounds / (6.0 * NCH));
+  return 0;
+}
+
 int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
@@ -240,5 +332,9 @@ int main() {
   if (run_pc<2, 0>("producers stream 2 KB / wave / unit", src, out, cyc3, region, ncu)) return 1;
   if (run_pc<1, 1>("producers stream 1 KB / wave / unit, barrier / 22 units", src, out, cyc3, region, ncu)) return 1;
   if (run_pc<2, 1>("producers stream 2 KB / wave / unit, barrier / 22 units", src, out, cyc3, region, ncu)) return 1;
+  printf("dependent chains of v_mfma_f32_16x16x32_bf16:\n");
+  if (run_ch<1>(out, cyc3, ncu) || run_ch<2>(out, cyc3, ncu) || run_ch<3>(out, cyc3, ncu) || run_ch<4>(out, cyc3, ncu) || run_ch<6>(out, cyc3, ncu)) return 1;
+  if (run_side<6, 0>(out, cyc3, ncu) || run_side<6, 1>(out, cyc3, ncu) || run_side<6, 2>(out, cyc3, ncu) || run_side<6, 3>(out, cyc3, ncu) || run_side<6, 7>(out, cyc3, ncu)) return 1;
+  if (run_side<3, 0>(out, cyc3, ncu) || run_side<3, 3>(out, cyc3, ncu)) return 1;
   return 0;
 }
