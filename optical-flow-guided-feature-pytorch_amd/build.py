@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "liboffk.so")
 SOURCES = ("offk_api.hip", "pw_reduce.hip", "sobel_tdiff.hip", "conv_igemm.hip", "heads.hip", "units_bwd.hip", "pw_tdiff.hip",
-           "pw_tdiff_split.hip", "pw_tdiff_pc.hip", "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "winograd7_fused.hip")
+           "pw_tdiff_split.hip", "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "winograd7_fused.hip")
 HEADERS = ("offk_common.h", "offk_internal.h", "winograd_common.h", os.path.join("..", "..", "include", "offk.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
@@ -28,7 +28,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # conv_igemm.hip: its LDS-DMA inline asm writes m0 and says so in the clobber list (the compiler must not assume an m0 value
 # of its own survives the statement); clang answers every such statement with "clobber list contains reserved registers".
 EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"], "units_bwd.hip": ["-fno-slp-vectorize"],
-               "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"], "pw_tdiff_split.hip": ["-Wno-inline-asm", "-fno-slp-vectorize"], "pw_tdiff_pc.hip": ["-Wno-inline-asm", "-fno-slp-vectorize"],
+               "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"], "pw_tdiff_split.hip": ["-Wno-inline-asm", "-fno-slp-vectorize"],
                "chain_fused.hip": ["-Wno-inline-asm"]}
 
 

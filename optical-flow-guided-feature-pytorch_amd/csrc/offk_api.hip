@@ -157,7 +157,7 @@ struct offk_handle {
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
   float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
-  int split_pc = 1;                 // OFFK_SPLIT_PC: 0 / 1 (default: by size) / 2 -- which split-fp32 units kernel (PtParams.split_pc)
+  int split_pc = 0;                 // OFFK_SPLIT_PC=2 in builds with -DOFFK_WITH_PC (tools): the producer / consumer experiment
   bool f32split = false;            // created with OFFK_PRECISION_F32SPLIT: cfg.precision is OFFK_PRECISION_FP32 inside the library, the
                                     // kernels that have a split form take it
   bool pw_dirty = true;

@@ -181,8 +181,7 @@ struct PtParams {
   int B, L, P, slice_mode, tgroups;
   int precision, presplit;
   int f32split;              // precision 0 with bdirect: the split-fp32 form (pw_tdiff_split.hip) instead of pw_tdiff16_kernel
-  int split_pc;              // f32split: 0 = always pw_tdiff_split_kernel, 1 = the producer / consumer form (pw_tdiff_pc.hip) from four items per
-                             // CU on, 2 = always the producer / consumer form (OFFK_SPLIT_PC at offk_create)
+  int split_pc;              // builds with -DOFFK_WITH_PC only (tools/experiments/pw_tdiff_pc.hip): 2 = the producer / consumer form (OFFK_SPLIT_PC=2)
   int bdirect;               // every site carries wt / wt16: the weight operand bypasses LDS.  Exact fp32 then runs the 16-pixel LDS-DMA
                              // form (pw_tdiff16_kernel), bf16x3 the register-staged kernel with two LDS stages for the feature-map tile
   const float* zeros;
@@ -198,9 +197,12 @@ hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStre
 // pw_tdiff_split.hip: out = 160 * C * 6 bytes; p with the 16-pixel form's block layout (pw_tdiff_launch fills it and calls this)
 hipError_t pw_pack_split16_launch(const float* w160, int C, void* out, hipStream_t st);
 hipError_t pw_tdiff_split_launch(const PtParams& p, hipStream_t st);
-// pw_tdiff_pc.hip: the same arithmetic and tile as ONE persistent block of eight waves per CU (four producer waves stream and cut the
-// feature map, four consumer waves multiply); n_cu = the grid
+#ifdef OFFK_WITH_PC
+// tools/experiments/pw_tdiff_pc.hip (NOT in the product build): the same arithmetic and tile as ONE persistent block of eight waves per CU
+// (four producer waves stream and cut the feature map, four consumer waves multiply); n_cu = the grid.  Measured 1.07 ms against the
+// two-blocks-per-CU form's 0.90 ms (profiles/r05/split_units_producer_consumer.txt): recorded and dropped.
 hipError_t pw_tdiff_pc_launch(const PtParams& p, int n_cu, hipStream_t st);
+#endif
 
 // ---- K2 ------------------------------------------------------------------------
 struct StSite {

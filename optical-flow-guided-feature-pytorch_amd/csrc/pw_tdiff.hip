@@ -951,9 +951,10 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   else hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);
 #endif
   if (form16 && p.f32split) {
-    // producer / consumer form from four items per CU on (a persistent block needs a stream of items to hide its two warm-up slots)
+#ifdef OFFK_WITH_PC
     static const int n_cu = [] { int d = 0; hipDeviceProp_t pr; return hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
-    if (p.split_pc == 2 || (p.split_pc == 1 && p.total_blocks >= 4 * n_cu)) return pw_tdiff_pc_launch(p, n_cu, st);
+    if (p.split_pc == 2) return pw_tdiff_pc_launch(p, n_cu, st);
+#endif
     return pw_tdiff_split_launch(p, st);
   }
   if (p.precision == 0) { OFFK_PT_LAUNCH(0, kStage32) } else { OFFK_PT_LAUNCH(1, kStageB3) }

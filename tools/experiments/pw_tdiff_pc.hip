@@ -29,8 +29,12 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "offk_common.h"
-#include "offk_internal.h"
+// NOT in the product build (round 5: measured 1.07 ms against pw_tdiff_split_kernel's 0.90 ms, profiles/r05/split_units_producer_consumer.txt).
+// To build it: add this file to build.py's SOURCES (flags as pw_tdiff_split.hip) and compile pw_tdiff.hip / offk_api.hip with -DOFFK_WITH_PC;
+// OFFK_SPLIT_PC=2 at offk_create selects it.
+#include "../../optical-flow-guided-feature-pytorch_amd/csrc/offk_common.h"
+#define OFFK_WITH_PC
+#include "../../optical-flow-guided-feature-pytorch_amd/csrc/offk_internal.h"
 
 namespace offk {
 
