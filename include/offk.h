@@ -206,7 +206,7 @@ int offk_off_units_fused(offk_handle* h, void* stream, const float* const feats[
  * [Co][Ci/32][KH*KW][32] (see offk_pack_conv_weight).  Requires Ci % 32 == 0, Co % 64 == 0,
  * strides/offsets % 4 == 0.  Tile shape and K-split are chosen automatically. */
 enum offk_conv_flags { OFFK_CONV_RELU_IN = 1, OFFK_CONV_RELU_PRE = 2, OFFK_CONV_RELU_POST = 4,
-                       OFFK_CONV_WINO7_FUSED = 256 /* offk_winograd_conv7x7s2 only (ABI v8): the input transform inside the GEMM kernel */ };
+                       /* (256 was OFFK_CONV_WINO7_FUSED in ABI v8: an experiment that lost, out of the library since ABI v9) */ };
 int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci,
                 const float* w, const float* bias, int Co, int KH, int KW, int stride, int pad,
                 const float* res, int res_cstride, int res_coff, int flags,
@@ -268,8 +268,8 @@ int offk_winograd_conv5x5s2(void* stream, const float* x, int x_cstride, int x_c
 /* The 7x7 / stride 2 / pad 3 conv on 28x28 maps (motion_conv_trans_28, RGB_OFF.py:657) in polyphase Winograd form F(5x5, 4x4):
  * four 14x14 phase images x 4x4 phase kernels concatenated along K, 9 output tiles of 5x5 per image, 64 points (winograd7.hip).
  * x: [n_img * 784][x_cstride]; y: [n_img * 196][y_cstride]; w_packed: the packed 7x7 weight [Co][Ci/32][49][32]; flags: ReLU
- * (PRE / POST; no residual input; | OFFK_CONV_WINO7_FUSED: the input transform inside the GEMM kernel, Co == 64, Ci % 16 == 0);
- * scratch: 225 * Ci * (Co + 9 * n_img) + 64 * 9 * n_img * Co floats (+ 64 * (Ci / 4) * 1024 for the fused form's weight image). */
+ * (PRE / POST; no residual input);
+ * scratch: 225 * Ci * (Co + 9 * n_img) + 64 * 9 * n_img * Co floats. */
 int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci,
                             const float* w_packed, const float* bias, int Co, int flags,
                             float* y, int y_cstride, int y_coff, float* scratch, size_t scratch_floats);

@@ -10,7 +10,6 @@ NUM_STAGES = 6
 STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7", "heads")
 
 CONV_RELU_IN, CONV_RELU_PRE, CONV_RELU_POST = 1, 2, 4
-CONV_WINO7_FUSED = 256      # offk_winograd_conv7x7s2: the input transform inside the GEMM kernel (winograd7_fused.hip)
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "f32split": 2}
 

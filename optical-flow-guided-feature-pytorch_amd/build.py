@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "liboffk.so")
 SOURCES = ("offk_api.hip", "pw_reduce.hip", "sobel_tdiff.hip", "conv_igemm.hip", "heads.hip", "units_bwd.hip", "pw_tdiff.hip",
-           "pw_tdiff_split.hip", "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "winograd7_fused.hip")
+           "pw_tdiff_split.hip", "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip")
 HEADERS = ("offk_common.h", "offk_internal.h", "winograd_common.h", os.path.join("..", "..", "include", "offk.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]

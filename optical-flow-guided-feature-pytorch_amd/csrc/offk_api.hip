@@ -1246,8 +1246,8 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   if (h->wino_u7 && wino && h->wino_7x7 && P >= h->wino7_min_p) {
     const ConvSpec& c = kConvs[C_T28];
     const int T = kWino7Tiles * n;
-    // (the input transform INSIDE the GEMM kernel was built and measured in round 4 -- winograd7_fused.hip, reachable through
-    //  offk_winograd_conv7x7s2 | OFFK_CONV_WINO7_FUSED: 0.84 ms against 0.54 ms for these two launches; profiles/r04/wino7_fused_attempt.txt)
+    // (the input transform INSIDE the GEMM kernel was built and measured in round 4 -- tools/experiments/winograd7_fused.hip, out of the
+    //  product build since round 5: 0.84 ms against 0.54 ms for these two launches; profiles/r04/wino7_fused_attempt.txt)
     TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: input transform]").c_str()));
     HIP_TRY(h, wino7_input_launch(F28, 320, 0, n, c.Ci, wino_V, s));
     TRY(trace_mark(h, s, (std::string(c.key) + " [winograd: 64 GEMMs]").c_str()));
@@ -1625,28 +1625,20 @@ int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_c
   if (!x || !w_packed || !y || !scratch || n_img < 1 || Ci < 32 || (Ci & 31) || Co < 64 || (Co & 63) || (flags & OFFK_CONV_RELU_IN_))
     return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument (Ci % 32 == 0, Co % 64 == 0, no RELU_IN)");
   const size_t T = (size_t)kWino7Tiles * n_img;
-  const bool fused = (flags & OFFK_CONV_WINO7_FUSED) != 0;
-  const size_t need = (size_t)kWino7Units * Ci * (Co + T) + (size_t)kWino7Points * T * Co + (fused ? wino7_fused_weight_floats(Ci) : 0);
+  const size_t need = (size_t)kWino7Units * Ci * (Co + T) + (size_t)kWino7Points * T * Co;
   if (scratch_floats < need) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* U = scratch;
   float* V = U + (size_t)kWino7Units * Co * Ci;
   float* M = V + (size_t)kWino7Units * T * Ci;
   hipError_t e = wino7_weight_launch(w_packed, Co, Ci, U, st);
-  if (fused && !wino7_fused_supported(n_img, Ci, Co, x_cstride))
-    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": the fused form needs Co == 64, Ci % 16 == 0 and an input below 1 GiB");
-  float* Uf = M + (size_t)kWino7Points * T * Co;
-  if (e == hipSuccess && fused) e = wino7_pack_fused_launch(U, Ci, Uf, st);
-  if (e == hipSuccess && fused) e = wino7_fused_launch(x, x_cstride, x_coff, n_img, Ci, Co, Uf, M, st);
-  else if (e == hipSuccess) e = wino7_input_launch(x, x_cstride, x_coff, n_img, Ci, V, st);
+  if (e == hipSuccess) e = wino7_input_launch(x, x_cstride, x_coff, n_img, Ci, V, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
   WinoGroup grp[4];
   const int ngrp = wino7_groups((long long)T, Ci, Co, grp);
-  if (!fused) {
-    const char* why = nullptr;
-    e = wino_gemms_launch(grp, ngrp, kWino7Points, (int)T, Ci, Co, V, U, M, wino_gemm_stage_default(), st, &why);
-    if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
-  }
+  const char* why = nullptr;
+  e = wino_gemms_launch(grp, ngrp, kWino7Points, (int)T, Ci, Co, V, U, M, wino_gemm_stage_default(), st, &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, why ? why : hipGetErrorString(e));
   e = wino7_output_launch(M, n_img, Co, bias, flags, y, y_cstride, y_coff, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
   return OFFK_OK;

@@ -109,12 +109,6 @@ hipError_t wino7_weight_launch(const float* w_packed, int Co, int Ci, float* U, 
 hipError_t wino7_input_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, float* V, hipStream_t st);
 hipError_t wino7_output_launch(const float* M, int n_img, int Co, const float* bias, int flags, float* y, int y_cs, int y_coff, hipStream_t st);
 int wino7_groups(long long T, int Ci, int Co, WinoGroup out[4]);
-// ---- K4w7f: the same conv with the input transform inside the GEMM kernel (winograd7_fused.hip): x -> M [64][9 n_img][64], no V
-bool wino7_fused_supported(int n_img, int Ci, int Co, int x_cs);
-// Uf: the transformed weights in the kernel's operand order (wino7_pack_fused_launch from wino7_weight_launch's U; wino7_fused_weight_floats)
-size_t wino7_fused_weight_floats(int Ci);
-hipError_t wino7_pack_fused_launch(const float* U, int Ci, float* Uf, hipStream_t st);
-hipError_t wino7_fused_launch(const float* x, int x_cs, int x_coff, int n_img, int Ci, int Co, const float* Uf, float* M, hipStream_t st);
 
 // ---- K1 ------------------------------------------------------------------------
 struct PwSite {

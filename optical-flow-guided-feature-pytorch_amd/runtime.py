@@ -390,7 +390,7 @@ def winograd_conv5x5s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0):
     return y
 
 
-def winograd_conv7x7s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0, fused=False):
+def winograd_conv7x7s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0):
     """7x7 / stride 2 / pad 3 conv on 28x28 maps in polyphase Winograd form F(5x5, 4x4) (offk_winograd_conv7x7s2).
     x: [n, 28, 28, Cs]; returns y [n, 14, 14, Co]."""
     lib = _lib.load()
@@ -402,7 +402,7 @@ def winograd_conv7x7s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0, fus
     nfl = 225 * Ci * (Co + 9 * n) + 64 * 9 * n * Co + (64 * 4 * (Ci // 16) * 1024 if fused else 0)
     scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
     _lib.check(lib.offk_winograd_conv7x7s2(_stream(x.device), _ptr(x), cs, x_coff, n, Ci, _ptr(pack_conv_weight(w_oihw)), _ptr(bias), Co,
-                                           flags | (_lib.CONV_WINO7_FUSED if fused else 0), _ptr(y), y.shape[-1], y_coff, _ptr(scratch), nfl))
+                                           flags, _ptr(y), y.shape[-1], y_coff, _ptr(scratch), nfl))
     return y
 
 

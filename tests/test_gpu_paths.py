@@ -458,28 +458,3 @@ def test_wino_gemm_persistent_matches_generic(rt, monkeypatch, B):
         assert torch.equal(h1.region(name, 1), h0.region(name, 1)), name
 
 
-@pytest.mark.parametrize("ci,n,relu", [(32, 1, False), (320, 3, False), (64, 5, True), (320, 8, False)])
-def test_winograd_conv7x7s2_fused_vs_torch(rt, ci, n, relu):
-    """offk_winograd_conv7x7s2 with OFFK_CONV_WINO7_FUSED (winograd7_fused.hip: the input transform inside the GEMM kernel, the
-    transformed input never in HBM) against torch CPU fp32 F.conv2d and against the three-kernel form (same transforms, same
-    products; the fused kernel sums k in a different order)."""
-    co = 64
-    g = torch.Generator().manual_seed(77 * ci + n)
-    x = torch.randn(n, 28, 28, ci + 32, generator=g).clamp_min(0)
-    w = (torch.rand(co, ci, 7, 7, generator=g) * 2 - 1) / (49 * ci) ** 0.5
-    b = (torch.rand(co, generator=g) * 2 - 1) / (49 * ci) ** 0.5
-    xin = x[..., 32:].permute(0, 3, 1, 2).contiguous()
-    want = F.conv2d(xin, w, b, stride=2, padding=3)
-    if relu:
-        want = F.relu(want)
-    want = want.permute(0, 2, 3, 1)
-    ybuf = torch.full((n, 14, 14, co + 64), -3.0, device="cuda")
-    rt.winograd_conv7x7s2(dev(x), dev(w), dev(b), flags=2 if relu else 0, x_coff=32, y=ybuf, y_coff=64, fused=True)
-    y3 = rt.winograd_conv7x7s2(dev(x), dev(w), dev(b), flags=2 if relu else 0, x_coff=32)
-    torch.cuda.synchronize()
-    err = rel_err(ybuf[..., 64:], want)
-    print("fused polyphase winograd 7x7/2 %d -> 64 n=%d: max error / max |ref| = %.2e; vs three-kernel form %.2e"
-          % (ci, n, err, rel_err(ybuf[..., 64:], y3.cpu())))
-    assert err < RTOL
-    assert rel_err(ybuf[..., 64:], y3.cpu()) < 2e-5
-    assert torch.all(ybuf[..., :64] == -3.0)

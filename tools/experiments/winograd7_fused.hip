@@ -28,8 +28,10 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "offk_common.h"
-#include "offk_internal.h"
+// (out of the product build since round 5; to build it again: add to build.py SOURCES, restore the declarations in offk_internal.h and the
+// OFFK_CONV_WINO7_FUSED branch of offk_winograd_conv7x7s2 from git history)
+#include "../../optical-flow-guided-feature-pytorch_amd/csrc/offk_common.h"
+#include "../../optical-flow-guided-feature-pytorch_amd/csrc/offk_internal.h"
 
 namespace offk {
 
