@@ -68,9 +68,8 @@ enum offk_feat_layout {
 
 enum offk_precision {
   OFFK_PRECISION_FP32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
-  OFFK_PRECISION_BF16X3 = 1, /* each fp32 operand split into bf16 hi + lo, a*b = a_lo*b_hi + a_hi*b_lo +
-                               a_hi*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate: ~1e-5 relative
-                               to the fp32 path (budget 1e-3) at 3/16 of its matrix-core cycles */
+  /* (1 was OFFK_PRECISION_BF16X3 until ABI v8: each fp32 operand as TWO bf16 planes, three products, ~1e-5 of the fp32 path;
+   *  retired in ABI v9 -- offk_create rejects it -- in favour of the exact three-plane mode below) */
   OFFK_PRECISION_F32SPLIT = 2 /* fp32 arithmetic on the bf16 matrix pipe: each fp32 operand cut into THREE bf16 planes
                                (8 + 8 + 8 significand bits = the fp32 value exactly), the six plane products above
                                2^-24 of the leading one on v_mfma_f32_16x16x32_bf16, summed per 32-k step from zero
@@ -116,9 +115,9 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
  * the key ([128,C,1,1], [128], [32,C,1,1], [32], [32,1,3,3], [32]; contiguous, 16-byte aligned, on the handle's device);
  * every later launch reads it in place, so an in-place optimizer update needs NO call at all -- it only has to be ordered
  * before the next launch, which it is when both are enqueued on the same stream.  The caller keeps the storage alive and
- * re-binds if the tensor is re-allocated.  A later offk_set_weight of the same key replaces the binding by a copy.  In
- * bf16x3 mode bound weights are split on the fly by the kernel: binding ANY gen / down weight moves all nine sites off the
- * pre-split copies and off the operand-order weight image of the fused units kernel (a performance fallback, same bits).
+ * re-binds if the tensor is re-allocated.  A later offk_set_weight of the same key replaces the binding by a copy.
+ * Binding ANY gen / down weight moves all nine sites off the operand-order weight images of the fused units kernels (the library's
+ * own packed copies: the fp32 form's and the split-fp32 form's) onto the register-staged fp32 kernel that reads the bound tensors.
  * `shape` / `ndim` are checked against the key's reference shape, and the allocation behind `device_data` must hold that
  * many bytes (hipMemGetAddressRange): every later launch sizes its buffer descriptors from the key, not from the tensor.
  * Not blocking, no allocation, no kernel launch. */
@@ -212,24 +211,18 @@ int offk_conv2d(void* stream, const float* x, int x_cstride, int x_coff, int n_i
                 const float* res, int res_cstride, int res_coff, int flags,
                 float* y, int y_cstride, int y_coff);
 /* Same with an explicit plan (tuning / micro-benchmarks): tile_cfg 0..5 = block tile 128x128,
- * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), 6 / 7 = the LDS-patch kernel (bf16x3, k x k
+ * 128x64, 256x64, 64x64, 64x128, 128x256 (pixels x channels), 6 / 7 = the LDS-patch kernel (k x k
  * convs whose 196-pixel output groups come from a 28x28 / four 14x14 / one 14x14 / four 7x7 input patch: 7x7s2@28,
- * 5x5s2@14, 3x3s1@14, 3x3s1@7; 128 / 64 output channels per block; splitk then splits the channel chunks),
- * 10 = its half-chunk form (16-channel patches, 64 channels per block, 7x7s2@28 and 5x5s2@14: two blocks per CU),
- * < 0 = automatic; splitk >= 1
+ * 5x5s2@14, 3x3s1@14, 3x3s1@7; 128 / 64 output channels per block; splitk then splits the channel chunks)
+ * (10 was its half-chunk bf16x3 form: retired in ABI v9), < 0 = automatic; splitk >= 1
  * K-slices whose fp32 partial slabs [splitk][M][Co] go to `partial` (summed in slice order by
- * a second launch, so results are bit-reproducible); splitk < 1 = automatic; precision = enum
- * offk_precision. */
+ * a second launch, so results are bit-reproducible); splitk < 1 = automatic; precision must be
+ * OFFK_PRECISION_FP32 (the stage entry has no split form). */
 int offk_conv2d_ex(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int H, int W, int Ci,
                    const float* w, const float* bias, int Co, int KH, int KW, int stride, int pad,
                    const float* res, int res_cstride, int res_coff, int flags,
                    float* y, int y_cstride, int y_coff, int tile_cfg, int splitk, float* partial, size_t partial_floats,
                    int precision);
-/* bf16x3 weight format: n fp32 values (rows of K, K % 32 == 0, so n % 32 == 0) -> for every 32-wide
- * K-tile 64 bf16: the 32 "hi" halves (upper 16 bits of each value) then the 32 "lo" halves
- * (bf16_rne(x - hi)); same byte count as the fp32 input.  With precision = OFFK_PRECISION_BF16X3,
- * offk_conv2d_ex expects `w` to point at this form of the packed weights. */
-int offk_split_bf16x3(void* stream, const float* src, size_t n, void* dst);
 /* [Co][Ci][KH][KW] (PyTorch) -> [Co][Ci/32][KH*KW][32]; both device pointers. */
 int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_packed);
 /* Override the plan offk_forward uses for one fusion conv (key = its state_dict name without

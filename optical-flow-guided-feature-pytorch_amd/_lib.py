@@ -11,7 +11,7 @@ STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7",
 
 CONV_RELU_IN, CONV_RELU_PRE, CONV_RELU_POST = 1, 2, 4
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "f32split": 2}
+PRECISIONS = {"fp32": 0, "f32split": 2}      # (1 was "bf16x3", retired in ABI v9)
 
 
 class OffkError(RuntimeError):
@@ -67,7 +67,6 @@ SIGNATURES = {
     "offk_winograd_conv5x5s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_winograd_conv7x7s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_winograd_between": (_I, [_P, _F, _F, _I, _I, _I, _F, _I, _I, _F, _F, _I, _F]),
-    "offk_split_bf16x3": (_I, [_P, _F, _c.c_size_t, _F]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),
     "offk_head": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _F]),

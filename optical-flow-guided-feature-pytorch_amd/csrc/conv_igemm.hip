@@ -1007,254 +1007,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
   }
 }
 
-// Half-chunk form of the patch kernel (tile_cfg 10, 64 output channels per block): the patch holds 16 channels
-// (one MFMA k-step) instead of 32, so the 784-pixel patches of the 7x7 / 5x5 convs take 50 KB and TWO blocks fit a
-// CU within 128 VGPRs -- the 32-channel form runs one block per CU there and loses to the generic kernel.  One
-// barrier per (half-chunk, tap) step = 12 MFMAs per consumer wave, the same granularity as the generic 128x64 tile,
-// with a third of its operand traffic.  LDS rows are 32 bytes (16 bf16); the two 16-byte halves of a row swap
-// places every 8 rows, which keeps the ds_read_b128 of 16 consecutive rows conflict-free.
-template <int KH, int S, int W>
-__global__ __launch_bounds__(512, 4) void conv_patch16_kernel(ConvArgs p) {
-  constexpr int KW = KH, TAPS = KH * KW, PAD = KH / 2, H = W, HW = H * W, NT = 2, CK = 16;
-  constexpr int WO = (W + 2 * PAD - KW) / S + 1, HOWO = WO * WO, IMG = 196 / HOWO, NP = IMG * HW;
-  constexpr int BN = 32 * NT, RT = 4, ROWB = 32;
-  constexpr int PATCH_PLANE = ((NP + 1) * ROWB + 127) / 128 * 128, B_PLANE = BN * ROWB, B_STAGE = 2 * B_PLANE;
-  constexpr int NJ = (NP + 63) / 64;   // patch pixels per producer thread (64 pixels x 4 channel quads per pass)
-  extern __shared__ __attribute__((aligned(16))) char lds_c[];
-  char* const patch = lds_c;
-  char* const bst = lds_c + 2 * PATCH_PLANE;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tid = threadIdx.x & 255;
-  int lid;
-  {
-    const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = lid % p.gn, mt = (lid / p.gn) % p.gm, zs = lid / (p.gn * p.gm);
-  const int n0 = nt * BN;
-  const int K = TAPS * p.Ci, nch = p.Ci / CK;                                   // 16-channel half-chunks
-  const int c_begin = (int)((long long)nch * zs / p.splitk), c_end = (int)((long long)nch * (zs + 1) / p.splitk);
-  const int G = (c_end - c_begin) * TAPS;
-  const bool relu_in = p.flags & OFFK_CONV_RELU_IN_;
-
-  if (wave >= 4) {
-    // ================================ producers ================================
-    const int c4 = tid & 3;
-    const float* wrow = p.w + (size_t)(n0 + (tid >> 2)) * K;                    // BN = 64 rows: one per thread quad
-    const float* xbase = p.x + p.x_coff + 4 * c4;
-    const long long npix_all = (long long)p.n_img * HW;
-    float4 rgP[NJ + 2];   // patch pieces, then the two weight pieces (one array)
-    constexpr int B0 = NJ, B1 = NJ + 1;
-    unsigned okp = 0;
-    auto load_patch = [&](int c16) {
-      unsigned m = 0;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int pp = (tid >> 2) + 64 * j;
-        const long long gp = (long long)mt * NP + pp;
-        const bool ok = pp < NP && gp < npix_all;
-        m |= ok ? (1u << j) : 0u;
-        rgP[j] = *reinterpret_cast<const float4*>(ok ? xbase + (size_t)gp * p.x_cs + c16 * CK : xbase);
-      }
-      okp = m;
-    };
-    auto store_patch = [&]() {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int pp = (tid >> 2) + 64 * j;
-        if (pp < NP) {
-          float4 t = rgP[j];
-          if (!((okp >> j) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (relu_in) t = relu4(t);
-          const int img = pp / HW, rem = pp - img * HW, y = rem / W, x = rem - y * W;
-          const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
-          const int slot = img * HW + y * W + xp;
-          uint2 hh, ll;
-          split4(t, hh, ll);
-          char* q = patch + slot * ROWB + ((((c4 >> 1) ^ ((slot >> 3) & 1)) << 4) | ((c4 & 1) << 3));
-          *reinterpret_cast<uint2*>(q) = hh;
-          *reinterpret_cast<uint2*>(q + PATCH_PLANE) = ll;
-        }
-      }
-    };
-    // weight piece of step g: row's 128-byte K-tile line = [hi 64 B | lo 64 B]; this thread takes 16 B of the hi (c4 0,1) or
-    // lo (c4 2,3) half-chunk
-    auto load_b = [&](const int set, int g) {
-      const int cl = g / TAPS, tap = g - cl * TAPS;
-      const int c16 = c_begin + cl;
-      const size_t line = (size_t)((c16 >> 1) * TAPS + tap) * BK;                // floats
-      rgP[set] = *reinterpret_cast<const float4*>(wrow + line + (c4 >> 1) * 16 + (2 * (c16 & 1) + (c4 & 1)) * 4);
-    };
-    auto store_b = [&](const int set, int stage) {
-      const int row = tid >> 2;
-      *reinterpret_cast<float4*>(bst + stage * B_STAGE + (c4 >> 1) * B_PLANE + row * ROWB + (((c4 & 1) ^ ((row >> 3) & 1)) << 4)) = rgP[set];
-    };
-    if (tid < 4) {   // the zero pixel
-      *reinterpret_cast<uint2*>(patch + NP * ROWB + tid * 8) = make_uint2(0u, 0u);
-      *reinterpret_cast<uint2*>(patch + PATCH_PLANE + NP * ROWB + tid * 8) = make_uint2(0u, 0u);
-    }
-    load_patch(c_begin);
-    load_b(B0, 0);
-    store_patch();
-    store_b(B0, 0);
-    if (c_begin + 1 < c_end) load_patch(c_begin + 1);
-    if (1 < G) load_b(B0, 1);
-    if (2 < G) load_b(B1, 2);
-    __syncthreads();
-    int g = 0, chunk = c_begin;
-#define OFFK_PATCH_PRODUCER_STEP(RG)                                                                    \
-    if (g >= G) break;                                                                                  \
-    if (g + 1 < G) store_b(RG, (g + 1) & 1);                                                            \
-    if (g + 3 < G) load_b(RG, g + 3);                                                                   \
-    __syncthreads();                                                                                    \
-    ++g;                                                                                                \
-    if (g < G && g % TAPS == 0) {                                                                       \
-      ++chunk;                                                                                          \
-      store_patch();                                                                                    \
-      if (chunk + 1 < c_end) load_patch(chunk + 1);                                                     \
-      __syncthreads();                                                                                  \
-    }
-    for (;;) {
-      OFFK_PATCH_PRODUCER_STEP(B0)
-      OFFK_PATCH_PRODUCER_STEP(B1)
-    }
-#undef OFFK_PATCH_PRODUCER_STEP
-    return;
-  }
-
-  // ================================ consumers ================================
-  const int r32 = lane & 31, h = lane >> 5;
-  const int ct = wave & 1;
-  int geo[4 * RT];
-#define y0(i) geo[4 * (i)]
-#define x0(i) geo[4 * (i) + 1]
-#define ib(i) geo[4 * (i) + 2]
-#define aoff(i) geo[4 * (i) + 3]
-#pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    const int rt = (wave >> 1) + 2 * i;
-    const int ml = rt * 32 + r32;
-    const bool mv = rt < 7 && ml < 196 && (long long)mt * 196 + ml < p.M;
-    const int img = ml / HOWO, rem = ml - img * HOWO, ho = rem / WO, wo = rem - ho * WO;
-    y0(i) = mv ? ho * S - PAD : -100000;
-    x0(i) = wo * S - PAD;
-    ib(i) = img * HW;
-    aoff(i) = 0;
-  }
-  f32x16 acc[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const int brow = ct * 32 + r32;
-  const int bbase = brow * ROWB + ((h ^ ((brow >> 3) & 1)) << 4);
-  __syncthreads();
-  int tap = 0;
-  for (int g = 0; g < G; ++g) {
-    const int kh = tap / KW, kw = tap - kh * KW;
-    const char* bp = bst + (g & 1) * B_STAGE + bbase;
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const int y = y0(i) + kh, x = x0(i) + kw;
-      const bool inb = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-      const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
-      const int slot = inb ? ib(i) + y * W + xp : NP;
-      aoff(i) = slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4);
-    }
-    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + B_PLANE);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      if ((wave >> 1) + 2 * i < 7) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(patch + aoff(i));
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(patch + PATCH_PLANE + aoff(i));
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (++tap == TAPS) {
-      tap = 0;
-      if (g + 1 < G) __syncthreads();
-    }
-  }
-#undef y0
-#undef x0
-#undef ib
-#undef aoff
-  const int co = n0 + ct * 32 + r32;
-  if (p.splitk > 1) {
-    float* part = p.partial + (size_t)zs * p.M * p.Co;
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const int rt = (wave >> 1) + 2 * i;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int ml = rt * 32 + acc_row(reg, h);
-        const long long m = (long long)mt * 196 + ml;
-        if (rt < 7 && ml < 196 && m < p.M) part[(size_t)m * p.Co + co] = acc[i][reg];
-      }
-    }
-    return;
-  }
-  const bool relu_pre = p.flags & OFFK_CONV_RELU_PRE_, relu_post = p.flags & OFFK_CONV_RELU_POST_;
-  const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    const int rt = (wave >> 1) + 2 * i;
-    float rv[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) rv[reg] = 0.f;
-    if (p.res) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int ml = rt * 32 + acc_row(reg, h);
-        const long long m = (long long)mt * 196 + ml;
-        const bool ok = rt < 7 && ml < 196 && m < p.M;
-        rv[reg] = *(ok ? p.res + (size_t)m * p.res_cs + p.res_coff + co : p.res);
-      }
-    }
-    float ov[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float v = acc[i][reg] + bv;
-      if (relu_pre) v = fmaxf(v, 0.f);
-      v += rv[reg];
-      if (relu_post) v = fmaxf(v, 0.f);
-      asm volatile("" : "+v"(v));
-      ov[reg] = v;
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int ml = rt * 32 + acc_row(reg, h);
-      const long long m = (long long)mt * 196 + ml;
-      if (rt < 7 && ml < 196 && m < p.M) p.y[(size_t)m * p.y_cs + p.y_coff + co] = ov[reg];
-    }
-  }
-}
-
-template <int KH, int S, int W>
-static hipError_t launch_patch16(ConvArgs a, hipStream_t st) {
-  constexpr int PAD = KH / 2, WO = (W + 2 * PAD - KH) / S + 1, IMG = 196 / (WO * WO), NP = IMG * W * W, BN = 64;
-  constexpr size_t lds = 2 * (size_t)(((NP + 1) * 32 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 32);
-  if (a.Co % BN) return hipErrorInvalidConfiguration;
-  auto kern = conv_patch16_kernel<KH, S, W>;
-  {
-    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  a.gm = (a.M + 195) / 196;
-  a.gn = a.Co / BN;
-  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk), dim3(512), lds, st, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || a.splitk == 1) return e;
-  size_t n4 = (size_t)a.M * (a.Co / 4);
-  int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
+// (Rounds 1-4 also had a half-chunk bf16x3 form of this kernel, conv_patch16_kernel / tile_cfg 10: retired with the two-plane
+//  bf16x3 mode in round 5 -- git history.)
 
 template <int KH, int S, int W, int NT, int PREC>
 static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
@@ -1282,8 +1036,8 @@ static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
 static hipError_t launch_patch_shape(const ConvArgs& a, int KH, int S, int W, int nt, int prec, hipStream_t st) {
 #define OFFK_PATCH_CASE(k, s, w)                                                                                     \
   if (KH == k && S == s && W == w) {                                                                                 \
-    if (prec == 0) return nt == 4 ? launch_patch<k, s, w, 4, 0>(a, st) : launch_patch<k, s, w, 2, 0>(a, st);        \
-    return nt == 4 ? launch_patch<k, s, w, 4, 1>(a, st) : launch_patch<k, s, w, 2, 1>(a, st);                       \
+    if (prec != 0) return hipErrorInvalidValue;                                                                      \
+    return nt == 4 ? launch_patch<k, s, w, 4, 0>(a, st) : launch_patch<k, s, w, 2, 0>(a, st);                       \
   }
   OFFK_PATCH_CASE(7, 2, 28)
   OFFK_PATCH_CASE(5, 2, 14)
@@ -1338,7 +1092,7 @@ static hipError_t launch_prec(const ConvArgs& a, int cfg, hipStream_t st) {
 template <int KH, int KW, int S>
 static hipError_t launch_shape(const ConvArgs& a, int cfg, int prec, hipStream_t st) {
   // the lean (buffer-addressed) loader when both tensors fit 31-bit byte offsets
-  if (prec == 1) return a.x_bytes ? launch_prec<KH, KW, S, 3>(a, cfg, st) : launch_prec<KH, KW, S, 1>(a, cfg, st);
+  if (prec != 0) return hipErrorInvalidValue;      // (the two-plane bf16x3 core, PREC 1 / 3, is no longer instantiated: retired in round 5)
   // (LDS-DMA destinations above 64 KB work: tools/lds_dma_probe_hi.hip lands rows up to 139 KB into a 144 KB allocation)
   if (a.x_bytes && !(a.flags & OFFK_CONV_RELU_IN_) && !a.no_dma) return launch_prec<KH, KW, S, 4>(a, cfg, st);
   return a.x_bytes ? launch_prec<KH, KW, S, 2>(a, cfg, st) : launch_prec<KH, KW, S, 0>(a, cfg, st);
@@ -1384,7 +1138,7 @@ void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_ou
 
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
   *why = nullptr;
-  if (d.precision != 0 && d.precision != 1) { *why = "conv2d: precision must be 0 (fp32) or 1 (bf16x3)"; return hipErrorInvalidValue; }
+  if (d.precision != 0) { *why = "conv2d: precision must be 0 (fp32; the bf16x3 mode was retired in ABI v9)"; return hipErrorInvalidValue; }
   const bool narrow = d.co_limit > 0 && d.co_limit < d.Co;   // padded-N GEMM with scalar stores (the FC heads)
   if (d.Ci % 32 || d.Co % 64 || d.x_cs % 4 || d.x_coff % 4 || d.y_cs <= 0 || (!narrow && (d.y_cs % 4 || d.y_coff % 4)) ||
       (d.res && (d.res_cs % 4 || d.res_coff % 4))) {
@@ -1472,19 +1226,7 @@ hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why) {
 #endif
   const int key = d.KH * 100 + d.KW * 10 + d.stride;
   hipError_t e;
-  if (cfg == 10) {   // half-chunk patch kernel (7x7s2@28, 5x5s2@14): two blocks per CU
-    if (d.precision != 1 || narrow || d.KH != d.KW || d.H != d.W || d.pad != d.KH / 2) {
-      *why = "conv2d: the patch kernel (tile_cfg 10) needs bf16x3, a square map and pad = k / 2";
-      return hipErrorInvalidValue;
-    }
-    if (sk > d.Ci / 16) sk = d.Ci / 16;
-    a.splitk = sk;
-    if (d.KH == 7 && d.stride == 2 && d.H == 28) e = launch_patch16<7, 2, 28>(a, st);
-    else if (d.KH == 5 && d.stride == 2 && d.H == 14) e = launch_patch16<5, 2, 14>(a, st);
-    else e = hipErrorInvalidConfiguration;
-    if (e == hipErrorInvalidConfiguration) *why = "conv2d: the half-chunk patch kernel covers 7x7s2@28 and 5x5s2@14 with Co % 64 == 0";
-    return e;
-  }
+  if (cfg == 10) { *why = "conv2d: tile_cfg 10 (the half-chunk patch kernel) existed for the bf16x3 mode only, retired in ABI v9"; return hipErrorInvalidValue; }
   if (cfg == 6 || cfg == 7) {   // patch kernel: square map, pad = k / 2, one of its four shapes (both precisions)
     if (narrow || d.KH != d.KW || d.H != d.W || d.pad != d.KH / 2) {
       *why = "conv2d: the patch kernel (tile_cfg 6 / 7) needs a square map and pad = k / 2";
@@ -1519,24 +1261,6 @@ __global__ void pack_oihw_kernel(const float* __restrict__ src, float* __restric
     int co = (int)(t / (Ci >> 5));
     dst[i] = src[((size_t)co * Ci + chunk * 32 + cl) * KHW + tap];
   }
-}
-
-// bf16x3 weight format: fp32 [rows][K] (K % 32 == 0) -> per row and 32-wide K-tile 64 bf16:
-// the 32 hi halves followed by the 32 lo halves (one 128-B line per (row, K-tile), same bytes as fp32)
-__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
-  for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
-    uint2 h, l;
-    split4(*reinterpret_cast<const float4*>(src + i), h, l);
-    const size_t tile = i >> 5, k = i & 31;            // K % 32 == 0, so tiles never straddle rows
-    *reinterpret_cast<uint2*>(dst + tile * 64 + k) = h;
-    *reinterpret_cast<uint2*>(dst + tile * 64 + 32 + k) = l;
-  }
-}
-hipError_t split_bf16_launch(const float* src, size_t n, void* dst, hipStream_t st) {
-  if (n % 32) return hipErrorInvalidValue;
-  int blocks = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<unsigned short*>(dst), n);
-  return hipGetLastError();
 }
 
 hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st) {

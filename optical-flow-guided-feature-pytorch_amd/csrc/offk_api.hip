@@ -153,7 +153,7 @@ struct offk_handle {
   std::map<std::string, int> index;
   // packed device weights
   float* pw_w[kNumSites] = {};   // [160][C]
-  float* pw_wb3[kNumSites] = {}; // bf16x3 mode: the same matrix pre-split per K-tile (hi 32 | lo 32)
+  float* pw_wb3[kNumSites] = {}; // (always null: the pre-split copy of the retired two-plane bf16x3 mode)
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
   float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
@@ -174,13 +174,11 @@ struct offk_handle {
   float* sobel_w = nullptr;      // shared [9][32] (diag variant)
   bool sobel_taps4 = false;      // the loaded Sobel weight is zero outside the four taps of util.py:61 -> K2's four-tap path
   float* conv_w[kNumConvs] = {};
-  float* conv_wb3[kNumConvs] = {};   // bf16x3 mode: bf16 hi plane | lo plane of conv_w (same byte size)
   float* conv_b[kNumConvs] = {};
   float* fc_w[3] = {};
   float* fc_b[3] = {};
   // residual-branch 1x1 convs merged into their sibling: out = W3*t + Wb*x == [W3|Wb] * [t|x] (K-concatenated)
   float* merged_w[3] = {};
-  float* merged_wb3[3] = {};
   float* merged_b[3] = {};
   int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};   // kMergedPlan at offk_create
   bool merged_dirty = true;
@@ -425,7 +423,7 @@ int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
 // bf16x3: K1 reads the library's pre-split weight copies unless a contraction weight is bound in place -- then every site
 // takes fp32 weights (its bound tensors, or the library's fp32 copy) and the kernel splits them on the way into LDS
 bool pw_presplit_now(const offk_handle* h) {
-  if (h->cfg.precision != OFFK_PRECISION_BF16X3) return false;
+  if (true) return false;       // (pre-split weights existed for the two-plane bf16x3 mode, retired in ABI v9)
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) return false;
   return true;
@@ -520,14 +518,8 @@ int check_parts(offk_handle* h, const offk_feat_parts parts[]) {
 
 int finalize_pw(offk_handle* h, hipStream_t st) {
   if (!h->pw_dirty) return OFFK_OK;
-  if (h->cfg.precision == OFFK_PRECISION_BF16X3)
-    for (int s = 0; s < kNumSites; ++s)
-      HIP_TRY(h, split_bf16_launch(h->pw_w[s], (size_t)kUnitCh * kSites[s].C, h->pw_wb3[s], st));
-  // the operand-order image the fused units kernel reads straight into registers: bf16x3 -> pw_tdiff_kernel, fp32 -> pw_tdiff16_kernel
-  if (h->cfg.precision == OFFK_PRECISION_BF16X3)
-    for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct_launch(h->pw_w[s], kSites[s].C, 1, h->pw_wt[s], st));
-  else
-    for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16[s], st));
+  // the operand-order image the fused units kernel reads straight into registers (pw_tdiff16_kernel; split-fp32: the plane image too)
+  for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_direct16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16[s], st));
   if (h->f32split)
     for (int s = 0; s < kNumSites; ++s) HIP_TRY(h, pw_pack_split16_launch(h->pw_w[s], kSites[s].C, h->pw_wt16s[s], st));
   h->pw_dirty = false;
@@ -632,7 +624,7 @@ int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, i
 int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, const float* res, int res_cs, int res_coff,
          int flags, float* y, int y_cs, int y_coff) {
   const ConvSpec& c = kConvs[id];
-  const float* w = h->cfg.precision == OFFK_PRECISION_BF16X3 ? h->conv_wb3[id] : h->conv_w[id];
+  const float* w = h->conv_w[id];
   return conv_raw(h, st, c.key, c.Co, c.Ci, c.K, c.stride, c.pad, w, h->conv_b[id], h->conv_cfg[id], h->conv_splitk[id], n_img,
                   H, x, res, res_cs, res_coff, flags, y, y_cs, y_coff);
 }
@@ -641,7 +633,7 @@ int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, co
 int conv_merged(offk_handle* h, hipStream_t st, int m, int n_img, int H, View x, int flags, float* y, int y_cs, int y_coff) {
   const ConvSpec& a = kConvs[kMerged[m].main_id];
   const ConvSpec& b = kConvs[kMerged[m].branch_id];
-  const float* w = h->cfg.precision == OFFK_PRECISION_BF16X3 ? h->merged_wb3[m] : h->merged_w[m];
+  const float* w = h->merged_w[m];
   return conv_raw(h, st, kMerged[m].name, a.Co, a.Ci + b.Ci, 1, 1, 0, w, h->merged_b[m], h->merged_cfg[m], h->merged_sk[m], n_img,
                   H, x, nullptr, 0, 0, flags, y, y_cs, y_coff);
 }
@@ -658,7 +650,6 @@ int finalize_merged(offk_handle* h, hipStream_t st) {
     HIP_TRY(h, hipMemcpy2DAsync(h->merged_w[m] + a.Ci, K * 4, h->conv_w[kMerged[m].branch_id], (size_t)b.Ci * 4, (size_t)b.Ci * 4,
                                 a.Co, hipMemcpyDeviceToDevice, st));
     HIP_TRY(h, vec_add_launch(h->conv_b[kMerged[m].main_id], h->conv_b[kMerged[m].branch_id], h->merged_b[m], a.Co, st));
-    if (h->merged_wb3[m]) HIP_TRY(h, split_bf16_launch(h->merged_w[m], (size_t)a.Co * K, h->merged_wb3[m], st));
   }
   h->merged_dirty = false;
   return OFFK_OK;
@@ -699,8 +690,8 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   if (cfg->slice_mode != OFFK_SLICE_REFERENCE_FLAT && cfg->slice_mode != OFFK_SLICE_PER_CLIP) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad slice_mode");
   if (cfg->consensus != OFFK_CONSENSUS_NONE && cfg->consensus != OFFK_CONSENSUS_AVG) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad consensus");
   if (cfg->feat_layout != OFFK_FEAT_NCHW && cfg->feat_layout != OFFK_FEAT_NHWC) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad feat_layout");
-  if (cfg->precision != OFFK_PRECISION_FP32 && cfg->precision != OFFK_PRECISION_BF16X3 && cfg->precision != OFFK_PRECISION_F32SPLIT)
-    return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad precision");
+  if (cfg->precision != OFFK_PRECISION_FP32 && cfg->precision != OFFK_PRECISION_F32SPLIT)
+    return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad precision (0 = fp32, 2 = f32split; 1 was the two-plane bf16x3 mode, retired in ABI v9)");
   if (cfg->num_classes < 1 || cfg->num_classes > 4096) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: bad num_classes");
   if ((long long)cfg->batch * cfg->length * 784 * 320 > 0x7fffffffLL) return fail(nullptr, OFFK_ERR_INVALID, "offk_create: batch*length too large for one call; shard the clips");
   int ndev = 0;
@@ -718,13 +709,13 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
   for (int c = 0; c < kNumConvs; ++c) {
-    const bool b3 = cfg->precision == OFFK_PRECISION_BF16X3;
+    const bool b3 = false;
     const int (*tab)[2] = h->P == 384 ? (b3 ? kTunedP384B3 : nullptr) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
   for (int m = 0; m < 3; ++m) {
-    const int (*mp)[2] = kMergedPlan[h->P == 240][cfg->precision == OFFK_PRECISION_BF16X3];
+    const int (*mp)[2] = kMergedPlan[h->P == 240][0];
     h->merged_cfg[m] = mp[m][0];
     h->merged_sk[m] = mp[m][1];
   }
@@ -738,8 +729,6 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     add_slot(h, "motion_spatial_down_" + n + ".weight", {kDownCh, C, 1, 1}, SK_DOWN_W, s);
     add_slot(h, "motion_spatial_down_" + n + ".bias", {kDownCh}, SK_DOWN_B, s);
     rc = dev_alloc(h, &h->pw_w[s], (size_t)kUnitCh * C);
-    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wb3[s], (size_t)kUnitCh * C);
-    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->pw_wt[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_FP32) rc = dev_alloc(h, &h->pw_wt16[s], (size_t)kUnitCh * C);
     if (rc == OFFK_OK && h->f32split) rc = dev_alloc(h, &h->pw_wt16s[s], (size_t)kUnitCh * C * 3 / 2);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->pw_b[s], kUnitCh);
@@ -759,7 +748,6 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     add_slot(h, std::string(cs.key) + ".weight", {cs.Co, cs.Ci, cs.K, cs.K}, SK_CONV_W, c);
     add_slot(h, std::string(cs.key) + ".bias", {cs.Co}, SK_CONV_B, c);
     rc = dev_alloc(h, &h->conv_w[c], (size_t)cs.Co * cs.Ci * cs.K * cs.K);
-    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->conv_wb3[c], (size_t)cs.Co * cs.Ci * cs.K * cs.K);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->conv_b[c], cs.Co);
   }
   for (int m = 0; m < 3 && rc == OFFK_OK; ++m) {
@@ -767,7 +755,6 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     const ConvSpec& b = kConvs[kMerged[m].branch_id];
     const size_t n = (size_t)a.Co * (a.Ci + b.Ci);
     rc = dev_alloc(h, &h->merged_w[m], n);
-    if (rc == OFFK_OK && cfg->precision == OFFK_PRECISION_BF16X3) rc = dev_alloc(h, &h->merged_wb3[m], n);
     if (rc == OFFK_OK) rc = dev_alloc(h, &h->merged_b[m], a.Co);
   }
   for (int k = 0; k < 3 && rc == OFFK_OK; ++k) {
@@ -891,11 +878,6 @@ int offk_set_weight(offk_handle* h, const char* key, const float* data, const in
     case SK_CONV_W:
       if (kConvs[i].K == 1) rc = copy(h->conv_w[i]);
       else rc = staged([&](const float* t) { return pack_conv_weight_launch(t, kConvs[i].Co, kConvs[i].Ci, kConvs[i].K, kConvs[i].K, h->conv_w[i], nullptr); });
-      if (rc == OFFK_OK && h->conv_wb3[i]) {
-        hipError_t e = split_bf16_launch(h->conv_w[i], n, h->conv_wb3[i], nullptr);
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        if (e != hipSuccess) rc = fail_hip(h, e, "offk_set_weight split");
-      }
       break;
     case SK_CONV_B: rc = copy(h->conv_b[i]); break;
     case SK_FC_W: rc = copy(h->fc_w[i]); break;
@@ -1484,7 +1466,7 @@ int offk_off_units_backward(offk_handle* h, void* stream, const float* const fea
   WgParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.nsites = kNumSites; wp.L = h->cfg.length; wp.P = h->P; wp.slice_mode = h->cfg.slice_mode; wp.kt_per_blk = h->wg_kpb;
-  wp.precision = h->cfg.precision == OFFK_PRECISION_BF16X3 ? 1 : 0;
+  wp.precision = 0;
   wp.dbg = 0;   // ablation bits of the tools build only
   wp.zeros = h->zero_page;
   WrParams rp;
@@ -1674,13 +1656,6 @@ int offk_set_conv_plan(offk_handle* h, const char* conv_key, int tile_cfg, int s
       return OFFK_OK;
     }
   return fail(h, OFFK_ERR_UNKNOWN_KEY, std::string("offk_set_conv_plan: unknown conv ") + conv_key);
-}
-
-int offk_split_bf16x3(void* stream, const float* src, size_t n, void* dst) {
-  if (!src || !dst || n == 0 || n % 32) return fail(nullptr, OFFK_ERR_INVALID, "offk_split_bf16x3: need n % 32 == 0");
-  hipError_t e = split_bf16_launch(src, n, dst, static_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return fail_hip(nullptr, e, "offk_split_bf16x3");
-  return OFFK_OK;
 }
 
 int offk_pack_conv_weight(void* stream, const float* w_oihw, int Co, int Ci, int KH, int KW, float* w_ohwi) {

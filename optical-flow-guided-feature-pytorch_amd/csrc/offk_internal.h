@@ -39,7 +39,6 @@ struct ConvDesc {
 };
 void conv2d_auto_plan(long long M, int Co, int nkt, int* cfg_out, int* splitk_out, int precision);
 hipError_t conv2d_launch(const ConvDesc& d, hipStream_t st, const char** why);
-hipError_t split_bf16_launch(const float* src, size_t n, void* dst, hipStream_t st);   // fp32 -> bf16 hi plane | lo plane
 hipError_t pack_conv_weight_launch(const float* src, int Co, int Ci, int KH, int KW, float* dst, hipStream_t st);
 
 // ---- K4c: one 1x1 -> 3x3 -> 1x1 (+ residual) bottleneck chain at 14x14 per launch (chain_fused.hip, exact fp32) ----

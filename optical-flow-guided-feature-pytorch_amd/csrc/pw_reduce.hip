@@ -389,7 +389,8 @@ hipError_t pw_reduce_launch(const PwParams& p_in, hipStream_t st) {
   if (lean) hipLaunchKernelGGL((pw_reduce_kernel<P, kNT, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);             \
   else hipLaunchKernelGGL((pw_reduce_kernel<P, kNT, 0>), dim3(p.total_blocks), dim3(256), 0, st, p);
 #endif
-  if (p.precision == 0) { OFFK_PW_LAUNCH(0) } else { OFFK_PW_LAUNCH(1) }
+  if (p.precision != 0) return hipErrorInvalidValue;      // (the bf16x3 core is no longer instantiated: retired in round 5)
+  OFFK_PW_LAUNCH(0)
 #undef OFFK_PW_LAUNCH
   return hipGetLastError();
 }

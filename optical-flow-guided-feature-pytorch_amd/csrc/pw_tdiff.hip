@@ -855,20 +855,15 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
     }
   }
 #endif
-  constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4, kStageB3 = 2 * (size_t)(PT_BM + PT_BN) * B3_ROW;
+  constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4;
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
-  constexpr size_t kStageAB3 = 2 * (size_t)PT_BM * B3_ROW;   // BD (bf16x3): feature-map tile only, two stages
+  // exact fp32 + the library's own weight image: always the 16-pixel LDS-DMA form
 #define OFFK_PT_LAUNCH_BD(P)                                                                                         \
-  if (P == 0) {              /* exact fp32 + direct weights: always the 16-pixel LDS-DMA form */                      \
+  {                                                                                                                  \
     constexpr int k16Lds = 2 * PT_FT * 32 * 64 + 1024;                                                               \
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff16_kernel), k16Lds);                         \
     if (er != hipSuccess) return er;                                                                                 \
     hipLaunchKernelGGL(pw_tdiff16_kernel, dim3(p.total_blocks), dim3(256), k16Lds, st, p);                           \
-  } else {                                                                                                           \
-    const size_t bytes = 2 * kStageAB3;                                                                              \
-    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 0, 0, 1, 1>), (int)bytes);        \
-    if (er != hipSuccess) return er;                                                                                 \
-    hipLaunchKernelGGL((pw_tdiff_kernel<1, 0, 0, 1, 1>), dim3(p.total_blocks), dim3(256), bytes, st, p);             \
   }
   // buffer addressing needs every byte offset below 2^31: each feature-map part and the weight tables
   bool lean = true;
@@ -883,9 +878,6 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   { const char* pe = getenv("OFFK_PW_PACK"); if (pe && *pe == '0') pack = false; }
   { const char* be = getenv("OFFK_PW_BDIRECT"); if (be && *be == '0') bd = false; }
   { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = bd = pack = false; }   // bit 0 fp32, bit 1 bf16x3
-  const char* pce = getenv("OFFK_FUSED_PC");
-  const bool pc_form = p.precision == 1 && pce && *pce == '1';
-  if (pc_form) lean = bd = pack = false;
 #endif
   const bool form16 = p.precision == 0 && bd;      // exact fp32 with the library's own weight image: the 16-pixel form (pw_tdiff16_kernel)
   auto layout = [&]() {      // block layout of every site (PtSite)
@@ -928,13 +920,6 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #ifdef OFFK_TUNING_KNOBS
   const char* e = getenv("OFFK_PW_NT");
   const int nt = e ? atoi(e) : kNT;
-  // OFFK_FUSED_PC=1: the 512-thread producer / consumer form (measured slower: 0.945 vs 0.828 ms, one block per CU)
-  if (pc_form) {
-    hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff_kernel<1, 1, 0, 0, 0>), (int)(2 * kStageB3));
-    if (er != hipSuccess) return er;
-    hipLaunchKernelGGL((pw_tdiff_kernel<1, 1, 0, 0, 0>), dim3(p.total_blocks), dim3(512), 2 * kStageB3, st, p);
-    return hipGetLastError();
-  }
 #define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
   if (bd) OFFK_PT_LAUNCH_BD(P)                                                                                       \
   else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);  \
@@ -957,7 +942,8 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #endif
     return pw_tdiff_split_launch(p, st);
   }
-  if (p.precision == 0) { OFFK_PT_LAUNCH(0, kStage32) } else { OFFK_PT_LAUNCH(1, kStageB3) }
+  if (p.precision != 0) return hipErrorInvalidValue;      // (the two-plane bf16x3 mode is no longer instantiated: retired in round 5)
+  OFFK_PT_LAUNCH(0, kStage32)
 #undef OFFK_PT_LAUNCH
 #undef OFFK_PT_LAUNCH_BD
   return hipGetLastError();

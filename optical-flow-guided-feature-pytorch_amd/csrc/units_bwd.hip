@@ -493,8 +493,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
 
 hipError_t pw_wgrad_launch(const WgParams& p, hipStream_t st) {
   if (p.total_blocks <= 0) return hipSuccess;
-  if (p.precision == 1) hipLaunchKernelGGL(pw_wgrad_kernel<1>, dim3(p.total_blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(pw_wgrad_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
+  if (p.precision != 0) return hipErrorInvalidValue;      // (the bf16x3 core is no longer instantiated: retired in round 5)
+  hipLaunchKernelGGL(pw_wgrad_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 

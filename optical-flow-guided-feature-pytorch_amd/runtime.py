@@ -312,10 +312,6 @@ def conv2d_nhwc(x, w_oihw, bias, stride, pad, res=None, flags=0, x_coff=0, ci=No
     if wp is None:
         wp = torch.empty(Co, KH, KW, Ci, dtype=torch.float32, device=x.device)   # library K order [Co][Ci/32][KH*KW][32]
         _lib.check(lib.offk_pack_conv_weight(_stream(x.device), _ptr(w_oihw.contiguous()), Co, Ci, KH, KW, _ptr(wp)))
-    if precision == 1 and w_packed is None:      # bf16x3: the kernel consumes pre-split hi | lo bf16 planes
-        ws = torch.empty_like(wp)
-        _lib.check(lib.offk_split_bf16x3(_stream(x.device), _ptr(wp), wp.numel(), _ptr(ws)))
-        wp = ws
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     if y is None:
@@ -399,7 +395,7 @@ def winograd_conv7x7s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0):
     Co, Ci = w_oihw.shape[:2]
     if y is None:
         y = torch.empty(n, 14, 14, Co, dtype=torch.float32, device=x.device)
-    nfl = 225 * Ci * (Co + 9 * n) + 64 * 9 * n * Co + (64 * 4 * (Ci // 16) * 1024 if fused else 0)
+    nfl = 225 * Ci * (Co + 9 * n) + 64 * 9 * n * Co
     scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
     _lib.check(lib.offk_winograd_conv7x7s2(_stream(x.device), _ptr(x), cs, x_coff, n, Ci, _ptr(pack_conv_weight(w_oihw)), _ptr(bias), Co,
                                            flags, _ptr(y), y.shape[-1], y_coff, _ptr(scratch), nfl))

@@ -74,11 +74,11 @@ def make_features(batch, length, config_id=0, clip_offset=0):
     return feats
 
 
-# ---- stress distributions for the split-precision (bf16x3) contractions -----------------------------------------
+# ---- stress distributions for the split-precision contractions (f32split) -----------------------------------------
 # feature_values() yields k * 2**-15 with k < 2**17: at most 17 significant bits, so every value splits into bf16
-# hi + lo (almost) exactly and the activation split of the bf16x3 kernels is never stressed.  The maps below have
+# hi + lo (almost) exactly and the activation split of the split-precision kernels is never stressed.  The maps below have
 # full 24-bit mantissas and a realistic dynamic range (real BN-Inception taps are post-ReLU / post-max-pool and
-# reach 1e1 .. 1e2); tests/test_gpu_parity.py and bench.py measure the bf16x3 error on them.
+# reach 1e1 .. 1e2); tests/test_gpu_parity.py and bench.py measure the split modes' error on them.
 FEATURE_KINDS = ("synth", "full_mantissa", "heavy_tail")
 
 

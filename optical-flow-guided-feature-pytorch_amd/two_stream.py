@@ -14,7 +14,7 @@ from . import runtime, scores, spec
 
 class TwoStreamOFF:
     def __init__(self, batch, length, precision="fp32", slice_mode=spec.SLICE_FLAT, device=None):
-        """precision: "fp32" (default: the reference's arithmetic) or "bf16x3" (the faster split mode, ~2e-5)."""
+        """precision: "fp32" (default: the fp32 MFMA pipe) or "f32split" (fp32 operands as three bf16 planes on the bf16 pipe)."""
         self.batch, self.length = batch, length
         self.rgb = runtime.OffForward(batch, length, spec.VARIANT_RGB, slice_mode, consensus=True,
                                       device=device, precision=precision)

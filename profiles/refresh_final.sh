@@ -10,6 +10,10 @@ timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "bench done"
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-secondary --steps 100 --warmup 10 > $OUT/stats.log 2>&1) || exit 1
 echo "stats done"
+# the same command in the split-fp32 mode (the units kernel on the bf16 pipe)
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32split -- python3 $GRAFT_REPO_ROOT/bench.py --no-secondary --precision f32split --steps 100 --warmup 10 > $OUT/stats_f32split.log 2>&1) || exit 1
+echo "split stats done"
 bash profiles/collect_pmc.sh $TAG/pmc || exit 1
+bash profiles/collect_pmc.sh $TAG/pmc_f32split --precision f32split || exit 1
 timeout -k 10 300 python tools/bench_small.py 1,7 8,7 16,7 42,7 55,7 128,7 10,25 --fp32 > $OUT/batch_table.txt 2>&1 || exit 1
 echo "table done"

@@ -85,18 +85,14 @@ def make(rt, B, L, variant, slice_mode=spec.SLICE_FLAT, precision="fp32"):
 @pytest.mark.parametrize("variant,B,L,slice_mode,seed,prec", [
     (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, None, "fp32"),
     (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, 7, "fp32"),
-    (spec.VARIANT_RGB, 2, 3, spec.SLICE_FLAT, 7, "bf16x3"),
     (spec.VARIANT_RGB, 3, 4, spec.SLICE_FLAT, 11, "fp32"),
-    (spec.VARIANT_RGB, 3, 4, spec.SLICE_FLAT, 11, "bf16x3"),
     (spec.VARIANT_RGB, 3, 4, spec.SLICE_PER_CLIP, 5, "fp32"),
-    (spec.VARIANT_RGB, 3, 4, spec.SLICE_PER_CLIP, 5, "bf16x3"),
     (spec.VARIANT_FLOW, 2, 3, spec.SLICE_FLAT, None, "fp32"),
     (spec.VARIANT_FLOW, 2, 7, spec.SLICE_FLAT, 3, "fp32"),
-    (spec.VARIANT_FLOW, 2, 7, spec.SLICE_FLAT, 3, "bf16x3"),
+    (spec.VARIANT_FLOW, 2, 7, spec.SLICE_FLAT, 3, "f32split"),     # (training side of a split-fp32 handle: the fp32 kernels)
 ])
 def test_units_backward_vs_oracle(rt, variant, B, L, slice_mode, seed, prec):
-    """fp32: exact-fp32 MFMA weight-gradient GEMM; bf16x3: the split-bf16 core (offk_common.h), both operands
-    split on the fly -- same RTOL."""
+    """Exact-fp32 MFMA weight-gradient GEMM (the two-plane bf16x3 core of rounds 1-4 was retired with its mode in ABI v9)."""
     P = B * (L - 1)
     cfg = 2 if B == 2 else 3
     feats = synth.make_features(B, L, cfg)
@@ -173,7 +169,7 @@ def test_units_backward_full_size_properties(rt):
     zero dM, bias gradient = column sums of the kernel's own dGpre / dD, bitwise reproducibility."""
     B, L = 64, 7
     P = B * (L - 1)
-    h, _w = make(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
+    h, _w = make(rt, B, L, spec.VARIANT_RGB, precision="fp32")
     feats = [dev(f) for f in synth.make_features(B, L, 2)]
     h.off_units_train(feats, 21, DROP_P)
     gen = torch.Generator(device="cuda").manual_seed(5)
@@ -280,8 +276,8 @@ def test_off_units_module_autograd(rt, variant):
 
 @pytest.mark.parametrize("B,L,variant,prec,slice_mode,cons", [
     (3, 2, spec.VARIANT_RGB, "fp32", spec.SLICE_FLAT, True),          # L = 2: one pair per clip
-    (5, 9, spec.VARIANT_FLOW, "bf16x3", spec.SLICE_PER_CLIP, False),  # L > 7: two temporal steps per T-block
-    (1, 8, spec.VARIANT_RGB, "bf16x3", spec.SLICE_FLAT, True),        # one clip
+    (5, 9, spec.VARIANT_FLOW, "f32split", spec.SLICE_PER_CLIP, False),  # L > 7: two temporal steps per T-block
+    (1, 8, spec.VARIANT_RGB, "f32split", spec.SLICE_FLAT, True),       # one clip
     (5, 3, spec.VARIANT_RGB, "fp32", spec.SLICE_PER_CLIP, False),     # P % 4 != 0: partial 196-pixel groups in the patch conv
 ])
 def test_odd_shapes_forward_and_backward(rt, B, L, variant, prec, slice_mode, cons):
@@ -352,7 +348,7 @@ def test_off_units_interleaved_forwards_before_backward(rt):
         torch.autograd.backward(out, cots)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "f32split"])
 def test_off_units_bound_weights_follow_updates_on_a_side_stream(rt, prec):
     """the trainable tensors are bound in place (offk_bind_weight), so an optimizer step needs no
     library call at all.  Parameters updated by kernels on a NON-DEFAULT (non-blocking) stream must be the ones the next

@@ -21,7 +21,7 @@ from oracle import off_oracle as orc
 pytestmark = pytest.mark.gpu
 RTOL_NORTH_STAR = 1e-3
 RTOL = 2e-4
-PRECISIONS = ["fp32", "bf16x3"]   # bf16x3: split-fp32 on the bf16 matrix cores, measured ~1-3e-5 (tests/tools/precision_report.py)
+PRECISIONS = ["fp32"]   # (until round 4 also "bf16x3", the two-plane split mode: retired in ABI v9 in favour of the exact three-plane mode)
 # handle-level arithmetic modes: f32split = fp32 operands as three bf16 planes on the bf16 pipe (round 5; its own error tests:
 # tests/test_gpu_split.py); kernels without a split form run as in fp32
 HANDLE_PRECISIONS = PRECISIONS + ["f32split"]
@@ -76,7 +76,7 @@ CONV_CASES = [  # (Ci, Co, k, stride, pad, H, n_img)  -- the distinct shapes of 
 ]
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0])
 @pytest.mark.parametrize("Ci,Co,k,stride,pad,H,n", CONV_CASES)
 def test_conv2d_vs_torch(rt, Ci, Co, k, stride, pad, H, n, prec):
     g = torch.Generator().manual_seed(Ci * 7 + Co + k)
@@ -115,7 +115,7 @@ def test_conv2d_epilogues_and_slices(rt):
     assert rel_err(y.permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1) + res) < RTOL
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0])
 def test_conv2d_input_slab_beyond_31_bit_offsets(rt, prec):
     """The buffer-descriptor loader is used only while every byte offset fits 31 bits; a slice of a > 2 GiB slab must
     take the 64-bit pointer loader and give the same answer (the last images sit beyond the 2 GiB mark)."""
@@ -134,7 +134,7 @@ def test_conv2d_input_slab_beyond_31_bit_offsets(rt, prec):
     assert rel_err(y[-1:].permute(0, 3, 1, 2), ref[-1:]) < RTOL
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0])
 @pytest.mark.parametrize("cfg,splitk", [(0, 1), (1, 3), (2, 2), (3, 4), (4, 1), (5, 2), (-1, 0)])
 def test_conv2d_tile_plans_and_splitk(rt, cfg, splitk, prec):
     """Every tile configuration and the deterministic split-K reduction give the same conv."""
@@ -158,19 +158,15 @@ PATCH_CASES = [  # (k, stride, H, Ci, Co, n_img, cfg, splitk): the four shapes o
     (7, 2, 28, 320, 64, 3, 7, 1), (7, 2, 28, 64, 128, 2, 6, 2), (5, 2, 14, 1056, 128, 6, 6, 3), (5, 2, 14, 96, 64, 9, 7, 1),
     (3, 1, 14, 64, 64, 3, 7, 2), (3, 1, 14, 128, 256, 2, 6, 1), (3, 1, 7, 832, 256, 7, 6, 4), (3, 1, 7, 128, 128, 5, 7, 1),
     (3, 1, 7, 256, 256, 8, 6, 3),
-    # tile_cfg 10: the half-chunk (16-channel) form for the 784-pixel patches
-    (7, 2, 28, 320, 64, 3, 10, 1), (7, 2, 28, 64, 128, 2, 10, 3), (5, 2, 14, 1056, 128, 6, 10, 4), (5, 2, 14, 96, 64, 9, 10, 1),
 ]
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0])
 @pytest.mark.parametrize("k,stride,H,Ci,Co,n,cfg,splitk", PATCH_CASES)
 def test_conv2d_patch_kernel_vs_torch(rt, k, stride, H, Ci, Co, n, cfg, splitk, prec):
     """tile_cfg 6 / 7: the input patch of a 196-pixel output group stays in LDS across the taps (conv_igemm.hip).
     Same conv, same epilogue flags, channel-sliced input / output views, bit-reproducible."""
     from offk_amd import _lib
-    if prec == 0 and cfg == 10:
-        pytest.skip("the half-chunk form is bf16x3 only")
     g = torch.Generator().manual_seed(k * 1000 + Ci + Co + n)
     pad = k // 2
     xs = torch.randn(n, Ci + 32, H, H, generator=g)          # the conv reads channels 32.. of a wider buffer
@@ -200,7 +196,7 @@ def test_conv2d_patch_kernel_rejects_other_shapes(rt):
     x = torch.randn(2, 10, 10, 64, device="cuda")
     w = torch.randn(64, 64, 3, 3)
     with pytest.raises(_lib.OffkError, match="patch kernel"):
-        rt.conv2d_nhwc(x, dev(w), None, 1, 1, tile_cfg=7, splitk=1, precision=1)
+        rt.conv2d_nhwc(x, dev(w), None, 1, 1, tile_cfg=7, splitk=1, precision=0)
     with pytest.raises(_lib.OffkError, match="patch kernel"):
         rt.conv2d_nhwc(torch.randn(2, 7, 7, 64, device="cuda"), dev(w), None, 1, 1, tile_cfg=10, splitk=1, precision=0)
 
@@ -431,7 +427,7 @@ def test_forward_from_inception_branch_parts(rt, prec):
 def test_forward_is_stream_capturable(rt):
     """include/offk.h: offk_forward can be captured into a HIP graph; replaying the graph reproduces the eager bits."""
     B, L = 2, 3
-    h, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="bf16x3")
+    h, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision="f32split")
     feats = [dev(f) for f in synth.make_features(B, L, 2)]
     arr = h._feat_array(feats)
     out = [torch.empty(h.out_rows(), spec.NUM_CLASSES, device="cuda") for _ in range(3)]
@@ -457,10 +453,9 @@ def test_forward_is_stream_capturable(rt):
 @pytest.mark.parametrize("B,L", [(2, 3), (3, 9)])
 def test_fused_units_path_matches_unfused(rt, prec, B, L, monkeypatch):
     """The default inference path fuses K1 with the temporal difference (pw_tdiff.hip: G never written to HBM);
-    OFFK_FUSED_UNITS=0 at offk_create keeps K1 + K2 apart.  bf16x3 (the 32-pixel register-staged form) adds the k of an output
-    element in K1's order: the unfused path's bits, also with two temporal groups (L = 9).  Exact fp32 runs the 16-pixel
-    LDS-DMA form on 16x16x4 MFMA tiles, whose k grouping differs: same values to a few fp32 ulps (asserted at 2e-6 of the
-    logits' magnitude)."""
+    OFFK_FUSED_UNITS=0 at offk_create keeps K1 + K2 apart.  Exact fp32 runs the 16-pixel LDS-DMA form on 16x16x4 MFMA tiles,
+    split-fp32 the plane kernel on 16x16x32 bf16 tiles: their k grouping differs from K1's, same values to a few fp32 ulps
+    (asserted at 2e-6 of the logits' magnitude), also with two temporal groups (L = 9)."""
     feats = [dev(f) for f in synth.make_features(B, L, 4)]
     monkeypatch.setenv("OFFK_FUSED_UNITS", "0")
     h0, _ = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
@@ -477,10 +472,7 @@ def test_fused_units_path_matches_unfused(rt, prec, B, L, monkeypatch):
     # whole maps, and the branches-as-parts entry point (same path)
     for got in (h1.forward(feats), h1.forward(parts)):
         for a, b in zip(ref, got):
-            if prec != "bf16x3":        # (f32split: the unfused reference side runs the fp32 pipe)
-                assert rel_err(b, a.cpu()) < 2e-6
-            else:
-                assert torch.equal(a, b)
+            assert rel_err(b, a.cpu()) < 2e-6      # (f32split: the unfused reference side runs the fp32 pipe)
 
 
 @pytest.mark.parametrize("prec", HANDLE_PRECISIONS)
@@ -510,7 +502,7 @@ def test_test_time_shape_vs_oracle(rt, variant, prec):
 def test_forward_without_the_28_head(rt):
     """out28 = NULL (the reference never returns the 28x28 head, RGB_OFF.py:860): the other two logits are unchanged."""
     B, L = 2, 3
-    h, _ = make_handle(rt, B, L, spec.VARIANT_FLOW, precision="bf16x3")
+    h, _ = make_handle(rt, B, L, spec.VARIANT_FLOW, precision="f32split")
     feats = [dev(f) for f in synth.make_features(B, L, 2)]
     a7, a14, a28 = h.forward(feats)
     b7, b14, b28 = h.forward(feats, want28=False)
@@ -527,7 +519,7 @@ STRESS_KINDS = ["full_mantissa", "heavy_tail"]
 @pytest.mark.parametrize("kind", STRESS_KINDS)
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_pw_reduce_on_full_range_inputs(rt, prec, kind):
-    """K1 on maps with 24-bit mantissas / values up to 1e2 (synth.make_features_kind): the bf16x3 activation split is
+    """K1 on maps with 24-bit mantissas / values up to 1e2 (synth.make_features_kind): the activation split of a split-precision kernel is
     exercised for real.  Checked against an fp64 contraction, all nine sites."""
     B, L = 2, 3
     h, w = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
@@ -574,7 +566,7 @@ def test_forward_on_full_range_inputs(rt, prec, kind):
 def test_pw_reduce_cancellation_case(rt, prec):
     """Weights orthogonal to the activations: every channel of a pixel carries the same value a(pixel) and every weight
     row has zero sum, so the exact result is the bias and everything else is rounding.  The error of a contraction is
-    bounded by eps * sum_k |w_k x_k| (fp32 MFMA: eps ~ 2**-24 per term; bf16x3: 2**-16.5, lo*lo dropped), NOT by eps *
+    bounded by eps * sum_k |w_k x_k| (fp32 MFMA: eps ~ 2**-24 per term), NOT by eps *
     |result|: assert that backward-error bound and report the error relative to max|out| for DESIGN.md section 4."""
     B, L, site = 2, 3, 5
     name, C, H = spec.SITES[site]
@@ -600,7 +592,7 @@ def test_pw_reduce_cancellation_case(rt, prec):
     cpu32 = F.conv2d(x[:B * (L - 1)], w["motion_spatial_down_%s.weight" % name], w["motion_spatial_down_%s.bias" % name]).double()
     print("   torch CPU fp32 conv on the same case: max error / sum|w x| = %.2e, / max|out| = %.2e"
           % (((cpu32 - d_ref).abs() / mag).max().item(), ((cpu32 - d_ref).abs().max() / d_ref.abs().max()).item()))
-    assert backward < (2e-6 if prec == "fp32" else 4e-5)
+    assert backward < 2e-6
 
 
 # ---- round 2: the drop-in class itself on the GPU (VERDICT r01 missing #1) -------------------
