@@ -100,6 +100,8 @@ def check_isa(obj, code_objects):
 # (source file, regex on the demangled kernel name, max vgpr_count, SGPR spills tolerated, what the bound stands for)
 ASM_SCHEDULED_KERNELS = (
     ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 128, True, "four blocks per CU (4 waves / SIMD x 128 = 512; 4 x 29 KB of LDS)"),
+    ("pw_tdiff_split.hip", r"^offk::pw_tdiff_split_kernel\(", 256, True,
+     "two blocks per CU (2 waves / SIMD; 52 KB of LDS each); its weight / feature loads are asm with hand-counted vmcnt waits"),
     ("chain_fused.hip", r"^void offk::chain14_kernel<", 168, False, "three blocks per CU (52.5 KB of LDS each)"),
     ("wino_gemm.hip", r"^offk::wino_gemm_kernel\(", 128, True, "four blocks per CU (32 KB of LDS each); counts its epilogue's sixteen stores (vmcnt(16))"),
     ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 128, False,

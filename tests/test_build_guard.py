@@ -21,7 +21,9 @@ def build_mod():
 
 def test_guarded_kernels_have_no_spills_and_fit_their_budget(build_mod):
     table = build_mod.resource_table()
-    assert set(table) == {"pw_tdiff.hip", "chain_fused.hip", "conv_igemm.hip", "wino_gemm.hip"}
+    assert set(table) == {"pw_tdiff.hip", "pw_tdiff_split.hip", "chain_fused.hip", "conv_igemm.hip", "wino_gemm.hip"}
+    sp = [k for k in table["pw_tdiff_split.hip"] if "pw_tdiff_split_kernel" in k["name"]]
+    assert len(sp) == 1 and sp[0]["vgpr_count"] <= 256            # two blocks per CU (LDS); asm loads with counted waits
     wg = [k for k in table["wino_gemm.hip"] if "wino_gemm_kernel" in k["name"]]
     assert len(wg) == 1 and wg[0]["vgpr_count"] <= 128             # four blocks per CU (LDS); it counts its epilogue's stores
     k16 = [k for k in table["pw_tdiff.hip"] if "pw_tdiff16_kernel" in k["name"]]
