@@ -27,6 +27,7 @@ accumulation -- so far the units kernel, 36 % of the step) is timed beside it as
 with `error_vs_fp64` for BOTH modes (the split mode's error against fp64 is the smaller one on every input kind).
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -589,6 +590,21 @@ def two_stream_leg(B, L, dev, steps, warmup, rgb_feats, rgb_weights):
             "steps": steps, "warmup": warmup, "dtype": DTYPES["fp32"]}
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """fd 1 -> fd 2 while a communicator is created: gloo's "[Gloo] Rank ..." and RCCL's "RCCL version : ..." banners are
+    written by C++ code on fd 1, and stdout is for the one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def init_single_rank_rccl(dev):
     """A world_size-1 RCCL ("nccl" backend on ROCm) process group in THIS process: no launcher, no re-exec after the GPU is
     initialised.  Rendezvous over a loopback TCP store on a free port."""
@@ -639,8 +655,10 @@ def rccl_smoke_object(B, L, variant, weights, feats, dev, steps):
             dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(3):
-            step()
+        with stdout_to_stderr():      # the first collective creates the communicator
+            for _ in range(3):
+                step()
+            fence()
         dt = timed_loop(step, steps, fence)
         # the plain step on the same handle, same loop: what the exchange costs the step
         dt0 = timed_loop(lambda: h.forward_into(arr, local[0][0], local[0][1], local[0][2]), steps, torch.cuda.synchronize)
@@ -676,18 +694,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if over:    # several ranks per device: RCCL refuses that, the scores travel over gloo (host-staged)
-            # gloo's C++ side prints its "[Gloo] Rank ..." banner on fd 1: keep stdout for the one JSON line
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+            with stdout_to_stderr():
                 dist.init_process_group("gloo", rank=rank, world_size=world)
                 dist.barrier()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            with stdout_to_stderr():      # (the communicator, and RCCL's banner with it, comes with the first collective)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()
+                torch.cuda.synchronize()
         backend = dist.get_backend()
 
     variant = spec.VARIANT_RGB if args.variant == "rgb" else spec.VARIANT_FLOW
