@@ -280,6 +280,15 @@ int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_c
 int offk_winograd_between(void* stream, const float* M, const float* bias_in, int phases_in, int n_img, int Cin,
                           float* x, int x_cstride, int x_coff, const float* w1, const float* b1, int Cmid, float* V);
 
+/* The batched GEMMs of a convolution on a Winograd path as a stage of their own (wino_gemm.hip / wino_gemm_split.hip; ABI v9):
+ *   y[b] = x[b] . w[b]^T,  x [batch][M][K], w [batch][Co][K], y [batch][M][Co], all contiguous fp32; K % 32 == 0, Co % 64 == 0.
+ * precision OFFK_PRECISION_FP32: the fp32 matrix pipe.  OFFK_PRECISION_F32SPLIT (Co % 128 == 0, K >= 64): split-fp32 arithmetic on the
+ * bf16 pipe -- both operands cut into three bf16 planes, six plane products per multiply (the arithmetic of the split units kernel);
+ * scratch (>= batch * Co * K * 6 bytes, device) receives the plane image of w.  What a handle created with that precision runs for the
+ * fusion convolutions with Co % 128 == 0 (RGB_OFF.py:762, 766, 775-777, 833, 837). */
+int offk_batched_gemm_nt(void* stream, const float* x, const float* w, float* y, int batch, int M, int K, int Co, int precision,
+                         void* scratch, size_t scratch_bytes);
+
 /* K5. Replaces motion_pool_trans_28 / global_pool / squeeze / fc_action_motion*
  * (RGB_OFF.py:782-787, 789-793, 843-847): optional MaxPool(3,2,ceil) then global
  * average over the (pooled) map then Linear.  x: channel slice [x_coff, x_coff+C) of a

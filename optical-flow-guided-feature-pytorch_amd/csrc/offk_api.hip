@@ -19,15 +19,17 @@ using namespace offk;
 // (wino_gemm.hip), or -- persistent == false, OFFK_WINO_GEMM=0 -- gridDim.y problems of the generic 1x1 kernel (conv_igemm.hip, 64 x 64
 // LDS-DMA tile).  Bit-identical.  grp / ngrp: winograd.hip's wino_groups / winograd7.hip's wino7_groups; rows = rows of every V[point].
 static hipError_t wino_gemms_launch(const WinoGroup* grp, int ngrp, int npoints, int rows, int Ci, int Co, const float* V, const float* U,
-                                    float* M, bool persistent, hipStream_t s, const char** why) {
-  if (persistent) {
+                                    float* M, bool persistent, hipStream_t s, const char** why, const void* U_planes = nullptr) {
+  if (persistent || U_planes) {
     WinoGemmArgs a{};
     a.x = V; a.w = U; a.y = M; a.M = rows; a.Co = Co; a.ngroups = ngrp;
     for (int gi = 0; gi < ngrp; ++gi) {
       a.g_batch[gi] = grp[gi].batch; a.g_K[gi] = grp[gi].kmul * Ci;
       a.g_x[gi] = grp[gi].v_off; a.g_w[gi] = grp[gi].u_off; a.g_y[gi] = grp[gi].m_off;
     }
-    if (wino_gemm_supported(a)) return wino_gemm_launch(a, s);     // every error of the launch itself goes to the caller
+    a.w_planes = U_planes;
+    if (U_planes && wino_gemm_split_supported(a)) return wino_gemm_split_launch(a, s);     // split-fp32 handles (wino_gemm_split.hip)
+    if (persistent && wino_gemm_supported(a)) return wino_gemm_launch(a, s);     // every error of the launch itself goes to the caller
     // a shape the persistent kernel does not take: the generic one
   }
   const int K0 = grp[0].kmul * Ci;
@@ -157,6 +159,8 @@ struct offk_handle {
   float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
   float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
   float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
+  bool split_gemm = false;          // a split-fp32 handle runs the Winograd GEMMs with Co % 128 == 0 in split-fp32 too (OFFK_SPLIT_GEMM=0: fp32 pipe)
+  int split_gemm_skip = 0;          // (tuning builds: OFFK_SPLIT_GEMM_SKIP, bit k = wino_u[k] stays on the fp32 pipe)
   int split_pc = 0;                 // OFFK_SPLIT_PC=2 in builds with -DOFFK_WITH_PC (tools): the producer / consumer experiment
   bool f32split = false;            // created with OFFK_PRECISION_F32SPLIT: cfg.precision is OFFK_PRECISION_FP32 inside the library, the
                                     // kernels that have a split form take it
@@ -190,6 +194,7 @@ struct offk_handle {
   float* wino_u7 = nullptr;      // transformed weights of C_T28 in the four groups of winograd7.hip (225 x Co x Ci floats)
   bool wino_7x7 = true;          // the 7x7 / stride 2 conv of fusion@28 in polyphase Winograd form F(5x5, 4x4) (OFFK_WINOGRAD_7X7=0: direct)
   int wino7_min_p = 12;          // ... from this many pairs (OFFK_WINOGRAD_7X7=<n> with n > 1 at offk_create: tools)
+  float* wino_us[6] = {};        // split-fp32 handles: the plane images of wino_u (wino_gemm_split.hip), 6 bytes per element; nullptr: fp32 GEMMs
   float* wino_u[6] = {};         // transformed weights [121][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; 400 x Co x Ci floats of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
   float* chain_u2[3] = {};       // F(2x2, 3x3) weights [16][64][64] of the chains' 3x3 convs C2_28A / B / C (chain_fused.hip, OFFK_CHAIN_WINO)
@@ -657,8 +662,16 @@ int finalize_merged(offk_handle* h, hipStream_t st) {
 int finalize_wino(offk_handle* h, hipStream_t st) {
   if (!h->winograd || !h->wino_dirty) return OFFK_OK;
   const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
-  for (int k = 0; k < 6; ++k)
-    HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], kConvs[wid[k]].Co, kConvs[wid[k]].Ci, k == 5 ? 4 : 1, h->wino_u[k], st));
+  for (int k = 0; k < 6; ++k) {
+    const ConvSpec& c = kConvs[wid[k]];
+    HIP_TRY(h, wino_weight_launch(h->conv_w[wid[k]], c.Co, c.Ci, k == 5 ? 4 : 1, h->wino_u[k], st));
+    if (!h->wino_us[k]) continue;
+    WinoGroup grp[4];
+    const int ngrp = wino_groups(k == 5 ? 4 : 1, 1, c.Ci, c.Co, grp);
+    for (int g = 0; g < ngrp; ++g)
+      HIP_TRY(h, wino_pack_split_launch(h->wino_u[k] + grp[g].u_off, reinterpret_cast<char*>(h->wino_us[k]) + grp[g].u_off * 6, c.Co,
+                                        grp[g].kmul * c.Ci, grp[g].batch, st));
+  }
   if (h->wino_u7) HIP_TRY(h, wino7_weight_launch(h->conv_w[C_T28], kConvs[C_T28].Co, kConvs[C_T28].Ci, h->wino_u7, st));
   {
     const ConvId c2[3] = {C2_28A, C2_28B, C2_28C};
@@ -799,6 +812,16 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     const ConvId wid[6] = {C3_14B, C_T7, C2_7, C2_14A, C2_14B, C_T14};
     for (int k = 0; k < 6; ++k)
       if (dev_alloc(h, &h->wino_u[k], (size_t)(k == 5 ? kWinoUnits4 : kWinoPoints) * kConvs[wid[k]].Co * kConvs[wid[k]].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    { const char* e = getenv("OFFK_SPLIT_GEMM"); h->split_gemm = h->f32split && !(e && *e == '0'); }
+#ifdef OFFK_TUNING_KNOBS
+    { const char* e = getenv("OFFK_SPLIT_GEMM_SKIP"); if (e) h->split_gemm_skip = atoi(e); }
+#endif
+    if (h->split_gemm)
+      for (int k = 0; k < 6; ++k) {
+        const size_t elems = (size_t)(k == 5 ? kWinoUnits4 : kWinoPoints) * kConvs[wid[k]].Co * kConvs[wid[k]].Ci;
+        if (kConvs[wid[k]].Co % 128 == 0 && kConvs[wid[k]].Ci >= 64 && !(h->split_gemm_skip & (1 << k)) &&
+            dev_alloc(h, &h->wino_us[k], (elems * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+      }
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     { const char* e = getenv("OFFK_CHAIN_WINO"); h->chain_wino = h->chain && !(e && *e == '0'); }
     if (h->chain_wino)
@@ -1170,7 +1193,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   auto wino_gemms = [&](const char* key, const WinoGroup* grp, int ngrp, int npoints, int rows, int Ci, int Co, const float* V,
                         const float* U, float* M) -> int {
     const char* why = nullptr;
-    hipError_t e = wino_gemms_launch(grp, ngrp, npoints, rows, Ci, Co, V, U, M, h->wino_gemm, s, &why);
+    const void* planes = nullptr;
+    for (int k = 0; k < 6; ++k) if (U == h->wino_u[k]) planes = h->wino_us[k];
+    hipError_t e = wino_gemms_launch(grp, ngrp, npoints, rows, Ci, Co, V, U, M, h->wino_gemm, s, &why, planes);
     if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
     return OFFK_OK;
   };
@@ -1638,6 +1663,30 @@ int offk_winograd_between(void* stream, const float* M, const float* bias_in, in
   m.w1 = w1; m.b1 = b1; m.Cin = Cin; m.Cmid = Cmid; m.n_img = n_img; m.V = V;
   hipError_t e = wino_mid_launch(m, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  return OFFK_OK;
+}
+
+int offk_batched_gemm_nt(void* stream, const float* x, const float* w, float* y, int batch, int M, int K, int Co, int precision,
+                         void* scratch, size_t scratch_bytes) {
+  const char* who = "offk_batched_gemm_nt";
+  if (!x || !w || !y || batch < 1 || M < 1 || K < 32 || (K & 31) || Co < 64 || (Co & 63))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument (K % 32 == 0, Co % 64 == 0)");
+  if (precision != OFFK_PRECISION_FP32 && precision != OFFK_PRECISION_F32SPLIT)
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": precision must be OFFK_PRECISION_FP32 or OFFK_PRECISION_F32SPLIT");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  WinoGroup grp{batch, 1, 0, 0, 0};
+  const void* planes = nullptr;
+  if (precision == OFFK_PRECISION_F32SPLIT) {
+    if ((Co & 127) || K < 64) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": the split-fp32 form takes Co % 128 == 0, K >= 64");
+    if (!scratch || scratch_bytes < (size_t)batch * Co * K * 6)
+      return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch smaller than batch * Co * K * 6 bytes (the plane image of w)");
+    hipError_t e = wino_pack_split_launch(w, scratch, Co, K, batch, st);
+    if (e != hipSuccess) return fail_hip(nullptr, e, who);
+    planes = scratch;
+  }
+  const char* why = nullptr;
+  hipError_t e = wino_gemms_launch(&grp, 1, batch, M, K, Co, x, w, y, true, st, &why, planes);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(who) + ": " + (why ? why : hipGetErrorString(e)));
   return OFFK_OK;
 }
 

@@ -84,9 +84,16 @@ struct WinoGemmArgs {
   int ngroups, g_batch[4], g_K[4];
   long long g_x[4], g_w[4], g_y[4];
   int gm, gn, total_items;     // filled by wino_gemm_launch
+  // split-fp32 form (wino_gemm_split.hip): the plane image of w (6 bytes per element at the same element offsets; wino_pack_split_launch)
+  const void* w_planes = nullptr;
+  long long x_bytes = 0, w_bytes = 0, y_bytes = 0;      // filled by wino_gemm_split_launch: extents of x, the plane image, y
 };
 bool wino_gemm_supported(const WinoGemmArgs& a);
 hipError_t wino_gemm_launch(const WinoGemmArgs& a, hipStream_t st);
+// ---- K4gs: the same GEMMs in split-fp32 arithmetic on the bf16 matrix pipe (wino_gemm_split.hip; Co % 128 == 0, K % 32 == 0, K >= 64)
+bool wino_gemm_split_supported(const WinoGemmArgs& a);
+hipError_t wino_gemm_split_launch(const WinoGemmArgs& a, hipStream_t st);
+hipError_t wino_pack_split_launch(const float* U, void* img, int Co, int K, int nproblems, hipStream_t st);
 // ---- K4m: output transform -> (1x1 conv + ReLU) -> input transform between two Winograd convs on 7x7 maps, one launch (wino_mid.hip)
 struct WinoMidArgs {
   const float* M;          // GEMM output of the conv in front, Winograd domain: [121][n_img][Cin]

@@ -1,0 +1,313 @@
+// K4gs: the batched GEMMs of a convolution on a Winograd path (wino_gemm.hip: M[point] = V[point] . U[point]^T) in split-fp32
+// arithmetic on the bf16 matrix pipe -- the arithmetic of pw_tdiff_split.hip: every fp32 operand as three bf16 planes (h + m + l = the
+// value, exactly), six plane products per multiply on v_mfma_f32_16x16x32_bf16, the six products of a 32-k step summed from ZERO in a
+// scratch tile that is added to the running accumulator once per step.  Reference arithmetic: the fp32 contractions of
+// RGB_OFF.py:762, 766, 775-777, 833, 837 in their Winograd forms (winograd.hip).
+//
+// Structure.  One persistent launch (as wino_gemm.hip: a block works through its items (point, m-tile, n-tile) as one stream of
+// K-tiles, nothing is waited for at an item boundary), 64 rows x 128 output channels per item, two blocks per CU.
+//   * U: cut once by the library (wino_pack_split_kernel) into the plane image [problem][K-tile][channel tile][plane][lane] x 16 B in
+//     operand order; a wave owns two channel tiles (32 channels) of all 64 rows and loads their six 1-KB pieces of the NEXT K-tile
+//     straight from L2 into registers;
+//   * V: thread (row = tid / 8 (+ 32), k chunk = tid % 8) loads 16 B of the K-tile TWO steps ahead into registers, cuts them one step
+//     ahead (22 vector instructions per four values) and writes 8 B per plane into the plane image of the next K-tile in LDS:
+//     [row tile][plane][k group g][slot = row ^ 2 g] x 16 B -- conflict-free for the cut's ds_write_b64 (banks mod 32, sixteen-lane
+//     groups = two rows x eight chunks) and for the MFMA operand's ds_read_b128 (MI355X_MICROARCH.md, LDS);
+//   * a step = one K-tile: 48 MFMAs per wave, product-major (eight independent chains of six), the cut / the loads / the folds in
+//     slices behind single MFMAs; one barrier per step; the three cursors (V two tiles ahead, U one, the multiply) walk the same item
+//     list, an item's descriptors travel from the first to the last through two sets of pending registers.
+// Weights = A operand, V rows = B operand: an accumulator lane holds four consecutive output channels of one row (16-byte stores).
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+
+#include "offk_common.h"
+#include "offk_internal.h"
+
+namespace offk {
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int GS_BM = 64, GS_BN = 128;
+constexpr int GS_GRP = 256;                 // one k group of a plane: 16 row slots x 16 B (8 bf16 = k 8g .. 8g + 7)
+constexpr int GS_PLANE = 4 * GS_GRP;        // 32 k
+constexpr int GS_RT = 3 * GS_PLANE;         // a row tile (16 rows): planes h, m, l
+constexpr int GS_STAGE = 4 * GS_RT;         // 64 rows
+constexpr int GS_LDS = 2 * GS_STAGE;        // 24576 B
+constexpr int GS_RESIDENT = 2 * 256;        // blocks the chip holds at a time = the persistent grid
+constexpr int GS_OOB = (int)0x80000000;     // a per-lane offset past every descriptor: loads return zeros, stores are dropped
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char gs_planes[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- V loader / cut: thread = (row lrow (+ 32), k chunk lc) ----
+  const int lrow = tid >> 3, lc = tid & 7, lgp = lc >> 1;
+  char* const pl_wr = gs_planes + (lrow >> 4) * GS_RT + lgp * GS_GRP + (((lrow & 15) ^ (2 * lgp)) << 4) + (lc & 1) * 8;
+  const char* const xrd = gs_planes + lg * GS_GRP + ((li ^ (2 * lg)) << 4);
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_planes), 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+
+  // ---- items (the group tables as scalars of their own, as wino_gemm.hip) ----
+  const int gx = p.gm * p.gn;
+  const int nK0 = p.g_K[0], nK1 = p.g_K[1], nK2 = p.g_K[2], nK3 = p.g_K[3];
+  const int nB0 = p.g_batch[0], nB1 = p.g_batch[1], nB2 = p.g_batch[2];
+  const long long oX0 = p.g_x[0], oX1 = p.g_x[1], oX2 = p.g_x[2], oX3 = p.g_x[3];
+  const long long oW0 = p.g_w[0], oW1 = p.g_w[1], oW2 = p.g_w[2], oW3 = p.g_w[3];
+  const long long oY0 = p.g_y[0], oY1 = p.g_y[1], oY2 = p.g_y[2], oY3 = p.g_y[3];
+  const int ngroups = p.ngroups, argM = p.M, argCo = p.Co, gn = p.gn, total_items = p.total_items;
+  const int ukstep = (argCo >> 4) * 3072;          // bytes of one K-tile of a problem's plane image
+  const int grid = (int)gridDim.x;
+  auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+
+  // V cursor (two tiles ahead of the multiply)
+  int x_l = (int)blockIdx.x, x_t = 0, x_nkt = 0, x_soff = 0, x_off[2] = {GS_OOB, GS_OOB};
+  // what the V cursor found out about its item, for the U cursor (pu_*, one step behind) and the multiply (pc_*, via pd_*, two behind)
+  int pu_soff = 0, pu_nkt = 0, pc_ysoff = 0, pc_m0 = 0, pc_n0 = 0;
+  int pd_ysoff = 0, pd_m0 = 0, pd_n0 = 0, pd_nkt = 0;
+  auto locate = [&](int l) {
+    const int prob = sc(l / gx), bx = l - prob * gx;
+    const int xcd = bx & 7, q = gx >> 3, r = gx & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);      // as wino_gemm.hip: n-tile fastest
+    const int mt = sc(lid / gn), nt = lid - mt * gn;
+    int b = prob, K = nK0;
+    long long ox = oX0, ow = oW0, oy = oY0;
+    if (ngroups > 1 && prob >= nB0) { b = prob - nB0; K = nK1; ox = oX1; ow = oW1; oy = oY1; }
+    if (ngroups > 2 && prob >= nB0 + nB1) { b = prob - nB0 - nB1; K = nK2; ox = oX2; ow = oW2; oy = oY2; }
+    if (ngroups > 3 && prob >= nB0 + nB1 + nB2) { b = prob - nB0 - nB1 - nB2; K = nK3; ox = oX3; ow = oW3; oy = oY3; }
+    const int m0 = mt * GS_BM, n0 = nt * GS_BN;
+    x_soff = sc((int)((ox + (long long)b * argM * K) * 4));
+    x_nkt = sc(K >> 5);
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int m = m0 + lrow + 32 * r2;
+      x_off[r2] = m < argM ? (m * K + lc * 4) * 4 : GS_OOB;
+    }
+    pu_soff = sc((int)((ow + (long long)b * argCo * K) * 6) + ((n0 >> 4) + 2 * wave) * 3072);
+    pu_nkt = x_nkt;
+    pc_ysoff = sc((int)((oy + (long long)b * argM * argCo) * 4));
+    pc_m0 = m0; pc_n0 = n0;
+  };
+  // U cursor
+  int u_l = x_l, u_t = 0, u_nkt = 0, u_soff = 0, u_voff = lane * 16;
+  // the multiply
+  int c_l = x_l, c_t = 0, c_nkt = 0, c_ysoff = 0, c_m0 = 0, c_n0 = 0;
+
+  u32x4 xr[2][2];                  // V registers [set = K-tile parity][row half]
+  u32x4 wr[2][2][3];               // U planes [set][channel tile][plane]
+  auto load_x = [&](const int set, const int r) {
+    xr[set][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, x_off[r], x_soff + x_t * 128, 0));
+  };
+  auto load_u = [&](const int set, const int n) {      // n = ct * 3 + plane
+    wr[set][n / 3][n % 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, u_voff, u_soff + u_t * ukstep + n * 1024, 0));
+  };
+  auto adv_x = [&]() {
+    ++x_t;
+    if (x_t == x_nkt) {
+      x_l += grid; x_t = 0;
+      if (x_l < total_items) locate(x_l);
+      else { x_off[0] = GS_OOB; x_off[1] = GS_OOB; x_nkt = INT_MAX; }
+    }
+  };
+  auto adv_u = [&]() {
+    ++u_t;
+    if (u_t == u_nkt) {
+      u_l += grid; u_t = 0;
+      if (u_l < total_items) { u_soff = pu_soff; u_nkt = pu_nkt; pd_ysoff = pc_ysoff; pd_m0 = pc_m0; pd_n0 = pc_n0; pd_nkt = pu_nkt; }
+      else { u_voff = GS_OOB; u_nkt = INT_MAX; }
+    }
+  };
+
+  // ---- the cut of register set `set`, row half r, in slices of two vector instructions (+ a store) ----
+  unsigned ch[4], cm[4];
+  float cr[4], cl[4];
+  auto cut_slice = [&](const int s, const int set, const int r, const int st) {
+    const u32x4& x = xr[set][r];
+    if (s < 8) {
+      const int e = s >> 1;
+      if ((s & 1) == 0) { ch[e] = x[e] & 0xffff0000u; cr[e] = __uint_as_float(x[e]) - __uint_as_float(ch[e]); }
+      else { cm[e] = __float_as_uint(cr[e]) & 0xffff0000u; cl[e] = cr[e] - __uint_as_float(cm[e]); }     // <= 8 significant bits left
+      return;
+    }
+    char* dst = pl_wr + st * GS_STAGE + r * 2 * GS_RT + (s - 8) * GS_PLANE;
+    u32x2 d;
+    if (s == 8) d = u32x2{__builtin_amdgcn_perm(ch[1], ch[0], 0x07060302), __builtin_amdgcn_perm(ch[3], ch[2], 0x07060302)};
+    else if (s == 9) d = u32x2{__builtin_amdgcn_perm(cm[1], cm[0], 0x07060302), __builtin_amdgcn_perm(cm[3], cm[2], 0x07060302)};
+    else d = u32x2{__builtin_amdgcn_perm(__float_as_uint(cl[1]), __float_as_uint(cl[0]), 0x07060302),
+                   __builtin_amdgcn_perm(__float_as_uint(cl[3]), __float_as_uint(cl[2]), 0x07060302)};
+    *reinterpret_cast<u32x2*>(dst) = d;
+  };
+
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mf = [&](f32x4 c, const u32x4& a, const u32x4& b) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+#define OFFK_SB __builtin_amdgcn_sched_barrier(0)
+
+  // the finished item: tile i = (row tile i >> 1, channel tile i & 1); a lane holds channels 4 lg .. + 3 of row li
+  auto store_item = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = c_m0 + (i >> 1) * 16 + li;
+      const int voff = row < argM ? (row * argCo + c_n0 + (2 * wave + (i & 1)) * 16 + 4 * lg) * 4 : GS_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, c_ysoff, 0);
+      acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  // ---- prologue: V(0) cut into stage 0, V(1) in registers, U(0) in registers ----
+  locate(x_l);
+  u_soff = pu_soff; u_nkt = pu_nkt;
+  c_ysoff = pc_ysoff; c_m0 = pc_m0; c_n0 = pc_n0; c_nkt = pu_nkt;
+  load_x(0, 0); load_x(0, 1);
+  adv_x();
+  load_x(1, 0); load_x(1, 1);
+  adv_x();
+#pragma unroll
+  for (int n = 0; n < 6; ++n) load_u(0, n);
+  adv_u();
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int s = 0; s < 11; ++s) cut_slice(s, 0, r, 0);
+  __syncthreads();
+
+  // One step: K-tile c_t of the multiply's item out of plane stage ST with the U registers of set ST; the cut of the next tile (register
+  // set ST ^ 1) into plane stage ST ^ 1; V two tiles ahead into register set ST; U of the next tile into set ST ^ 1.
+  auto step = [&](const int ST) -> bool {
+    u32x4 xb[4][3];
+    f32x4 t[8];
+    const char* const rd = xrd + ST * GS_STAGE;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) xb[rt][0] = *reinterpret_cast<const u32x4*>(rd + rt * GS_RT);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) xb[rt][2] = *reinterpret_cast<const u32x4*>(rd + rt * GS_RT + 2 * GS_PLANE);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) xb[rt][1] = *reinterpret_cast<const u32x4*>(rd + rt * GS_RT + GS_PLANE);
+    OFFK_SB;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // planes 0 = h, 1 = m, 2 = l; smallest products first: w_l x_h, w_h x_l, w_m x_m, w_m x_h, w_h x_m, w_h x_h
+    constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, XP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int n = q * 8 + i, rt = i >> 1, ct = i & 1;
+        t[i] = mf(q == 0 ? z : t[i], wr[ST][ct][WP[q]], xb[rt][XP[q]]);
+        // behind MFMA n: the step's loads one at a time, then the cut in slices, then the scratch tiles into their accumulators
+        if (n == 0) load_x(ST, 0);
+        else if (n == 1) load_x(ST, 1);
+        else if (n < 8) load_u(ST ^ 1, n - 2);
+        else if (n < 19) cut_slice(n - 8, ST ^ 1, 0, ST ^ 1);
+        else if (n < 30) cut_slice(n - 19, ST ^ 1, 1, ST ^ 1);
+        else if (n >= 44) { acc[n - 44] += t[n - 44]; asm volatile("" : "+v"(acc[n - 44])); }
+        OFFK_SB;
+      }
+    }
+#pragma unroll
+    for (int i = 4; i < 8; ++i) { acc[i] += t[i]; asm volatile("" : "+v"(acc[i])); }
+    OFFK_SB;
+    // cursors: the multiply, then U, then V (an item's descriptors are handed down in that order)
+    ++c_t;
+    bool go_on = true;
+    if (c_t == c_nkt) {
+      store_item();
+      c_l += grid; c_t = 0;
+      if (c_l < total_items) { c_ysoff = pd_ysoff; c_m0 = pd_m0; c_n0 = pd_n0; c_nkt = pd_nkt; }
+      else go_on = false;
+    }
+    adv_u();
+    adv_x();
+    __syncthreads();
+    return go_on;
+  };
+  for (;;) {
+    if (!step(0)) break;
+    if (!step(1)) break;
+  }
+}
+
+// U -> plane image.  Thread = (problem, K-tile, channel tile, lane): 8 consecutive k of one output channel, three 16-byte pieces.
+__global__ void wino_pack_split_kernel(const float* __restrict__ U, uint4* __restrict__ img, int Co, int K, int nproblems) {
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nct = Co >> 4, nkt = K >> 5;
+  const long long per = (long long)nkt * nct * 64;
+  if (item >= per * nproblems) return;
+  const int prob = (int)(item / per);
+  const int rem = (int)(item - prob * per);
+  const int lane = rem & 63, ct = (rem >> 6) % nct, kt = (rem >> 6) / nct;
+  const int li = lane & 15, g = lane >> 4;
+  const float* row = U + ((size_t)prob * Co + ct * 16 + li) * K + kt * 32 + 8 * g;
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned x = __float_as_uint(row[e]);
+    h[e] = x & 0xffff0000u;
+    const float r1 = __uint_as_float(x) - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xffff0000u;
+    l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
+  }
+  auto pk = [](const unsigned (&v)[8]) {
+    return uint4{(v[0] >> 16) | (v[1] & 0xffff0000u), (v[2] >> 16) | (v[3] & 0xffff0000u), (v[4] >> 16) | (v[5] & 0xffff0000u),
+                 (v[6] >> 16) | (v[7] & 0xffff0000u)};
+  };
+  uint4* o = img + (((size_t)prob * nkt + kt) * nct + ct) * 3 * 64 + lane;
+  o[0] = pk(h); o[64] = pk(m); o[128] = pk(l);
+}
+
+// the plane image of the U of one group of problems (Co x K each): 6 bytes per element, same element offsets as U
+hipError_t wino_pack_split_launch(const float* U, void* img, int Co, int K, int nproblems, hipStream_t st) {
+  if (Co % 16 || K % 32 || nproblems <= 0) return hipErrorInvalidValue;
+  const long long items = (long long)nproblems * (K / 32) * (Co / 16) * 64;
+  hipLaunchKernelGGL(wino_pack_split_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, U, reinterpret_cast<uint4*>(img), Co, K,
+                     nproblems);
+  return hipGetLastError();
+}
+
+bool wino_gemm_split_supported(const WinoGemmArgs& a) {
+  if (!a.w_planes || a.M <= 0 || a.Co % GS_BN || a.ngroups < 1 || a.ngroups > 4) return false;
+  long long problems = 0, xe = 0, we = 0, ye = 0;
+  for (int g = 0; g < a.ngroups; ++g) {
+    if (a.g_K[g] % 32 || a.g_K[g] < 64 || a.g_batch[g] <= 0) return false;
+    problems += a.g_batch[g];
+    xe = std::max(xe, a.g_x[g] + (long long)a.g_batch[g] * a.M * a.g_K[g]);
+    we = std::max(we, a.g_w[g] + (long long)a.g_batch[g] * a.Co * a.g_K[g]);
+    ye = std::max(ye, a.g_y[g] + (long long)a.g_batch[g] * a.M * a.Co);
+    if ((long long)a.M * a.g_K[g] * 4 >= 0x7fffff00ll) return false;
+  }
+  if (xe * 4 >= 0x7fffff00ll || we * 6 >= 0x7fffff00ll || ye * 4 >= 0x7fffff00ll) return false;
+  const long long total = problems * ((a.M + GS_BM - 1) / GS_BM) * (a.Co / GS_BN);
+  return total > 0 && total < (1ll << 30);
+}
+
+hipError_t wino_gemm_split_launch(const WinoGemmArgs& a_in, hipStream_t st) {
+  WinoGemmArgs a = a_in;
+  if (!wino_gemm_split_supported(a)) return hipErrorInvalidValue;
+  long long problems = 0, xe = 0, we = 0, ye = 0;
+  for (int g = 0; g < a.ngroups; ++g) {
+    problems += a.g_batch[g];
+    xe = std::max(xe, a.g_x[g] + (long long)a.g_batch[g] * a.M * a.g_K[g]);
+    we = std::max(we, a.g_w[g] + (long long)a.g_batch[g] * a.Co * a.g_K[g]);
+    ye = std::max(ye, a.g_y[g] + (long long)a.g_batch[g] * a.M * a.Co);
+  }
+  a.x_bytes = xe * 4; a.w_bytes = we * 6; a.y_bytes = ye * 4;
+  a.gm = (a.M + GS_BM - 1) / GS_BM;
+  a.gn = a.Co / GS_BN;
+  a.total_items = (int)(problems * a.gm * a.gn);
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_gemm_split_kernel), GS_LDS);
+  if (e != hipSuccess) return e;
+  const int grid = a.total_items < GS_RESIDENT ? a.total_items : GS_RESIDENT;
+  hipLaunchKernelGGL(wino_gemm_split_kernel, dim3(grid), dim3(256), GS_LDS, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace offk

@@ -417,6 +417,20 @@ def winograd_between(M, bias_in, phases_in, w1=None, b1=None, x=None, x_coff=0):
     return V
 
 
+def batched_gemm_nt(x, w, precision="fp32"):
+    """offk_batched_gemm_nt: y[b] = x[b] @ w[b].T for x [batch, M, K], w [batch, Co, K] (the GEMMs of a conv on a Winograd path);
+    precision "f32split": split-fp32 arithmetic on the bf16 matrix pipe (wino_gemm_split.hip)."""
+    lib = _lib.load()
+    batch, m, k = x.shape
+    co = w.shape[1]
+    assert w.shape == (batch, co, k)
+    y = torch.empty(batch, m, co, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(batch * co * k * 6 if precision == "f32split" else 16, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.offk_batched_gemm_nt(_stream(x.device), _ptr(x.contiguous()), _ptr(w.contiguous()), _ptr(y), batch, m, k, co,
+                                        _lib.PRECISIONS[precision], _ptr(scratch), scratch.numel()))
+    return y
+
+
 def head(x, fc_w, fc_b, maxpool, x_coff=0, c=None):
     lib = _lib.load()
     n, H, W, cs = x.shape

@@ -161,3 +161,48 @@ def test_units_split_shapes(rt, B, L, split_form):
     for (name, _C, _H), (T, D), (Tr, _mT, Dr, _mD) in zip(spec.SITES, outs, ref):
         assert ((T - Tr).abs().max() / Tr.abs().max()).item() < 2e-6, name
         assert ((D - Dr).abs().max() / Dr.abs().max()).item() < 2e-6, name
+
+
+# ---- the batched GEMMs of the Winograd convs in split-fp32 arithmetic (wino_gemm_split.hip) ----
+
+def gemm_inputs(batch, M, K, Co, kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, M, K, generator=g)
+    w = torch.randn(batch, Co, K, generator=g) * (1.0 / K ** 0.5)
+    if kind == "relu":                # what V looks like behind a ReLU and B^T . B: mostly small, some zeros
+        x = torch.relu(x)
+    elif kind == "heavy_tail":
+        x = x * torch.exp(2.0 * torch.randn(batch, M, 1, generator=g))
+    elif kind == "cancellation":      # every row of w sums to zero, x constant along k (+ noise of 2^-12): the result is the noise's
+        w = w - w.mean(dim=2, keepdim=True)
+        x = 3.0 + torch.randn(batch, M, 1, generator=g) + torch.randn(batch, M, K, generator=g) * 2.0 ** -12
+    return x.float().contiguous(), w.float().contiguous()
+
+
+@pytest.mark.parametrize("batch,M,K,Co", [(5, 384, 832, 256), (121, 384, 256, 256), (3, 100, 128, 128), (7, 64, 64, 512),
+                                          (2, 777, 1056, 128)])
+def test_batched_gemm_split_shapes(rt, batch, M, K, Co):
+    """Item streams longer than the persistent grid (121 x 6 x 2 items), row tails (M % 64 != 0), the shortest K the kernel takes
+    (two K-tiles: the three cursors cross item boundaries on consecutive steps), every element against fp64."""
+    x, w = gemm_inputs(batch, M, K, Co, "relu", 11)
+    ref = torch.einsum("bmk,bnk->bmn", x.double(), w.double())
+    y = rt.batched_gemm_nt(dev(x), dev(w), "f32split").double().cpu()
+    assert ((y - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    y32 = rt.batched_gemm_nt(dev(x), dev(w), "fp32").double().cpu()
+    assert ((y32 - ref).abs().max() / ref.abs().max()).item() < 3e-6
+
+
+@pytest.mark.parametrize("kind", ["relu", "normal", "heavy_tail", "cancellation"])
+def test_batched_gemm_split_error_is_no_larger_than_the_fp32_pipes(rt, kind):
+    batch, M, K, Co = 6, 384, 832, 256
+    x, w = gemm_inputs(batch, M, K, Co, kind, 5)
+    ref = torch.einsum("bmk,bnk->bmn", x.double(), w.double())
+    mag = torch.einsum("bmk,bnk->bmn", x.double().abs(), w.double().abs())
+    stats = {}
+    for prec in ("fp32", "f32split"):
+        y = rt.batched_gemm_nt(dev(x), dev(w), prec).double().cpu()
+        stats[prec] = error_stats([(y, ref, mag)])
+        print("batched GEMM %-8s on %-12s inputs vs fp64: max %.3e  rms %.3e  c_max %.3f  c_rms %.4f"
+              % (prec, kind, stats[prec]["max_over_max"], stats[prec]["rms_over_max"], stats[prec]["c_max"], stats[prec]["c_rms"]))
+    for key in ("max_over_max", "rms_over_max", "c_max", "c_rms"):
+        assert stats["f32split"][key] <= stats["fp32"][key], (kind, key, stats)
