@@ -24,6 +24,10 @@
 #include "offk_common.h"
 #include "offk_internal.h"
 
+#ifndef OFFK_GS_EXP
+#define OFFK_GS_EXP 0      /* timing experiments (tools/build_one.py -DOFFK_GS_EXP=mask): 1 no cut, 2 no folds, 4 no U loads, 8 no V loads, 16 U from one K-tile */
+#endif
+
 namespace offk {
 
 namespace {
@@ -63,6 +67,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
   const long long oW0 = p.g_w[0], oW1 = p.g_w[1], oW2 = p.g_w[2], oW3 = p.g_w[3];
   const long long oY0 = p.g_y[0], oY1 = p.g_y[1], oY2 = p.g_y[2], oY3 = p.g_y[3];
   const int ngroups = p.ngroups, argM = p.M, argCo = p.Co, gn = p.gn, total_items = p.total_items;
+  const int gm = p.gm;
+  const int main_items = (total_items / gx / 8) * 8 * gx;      // the items of the problems that go to XCDs whole
   const int ukstep = (argCo >> 4) * 3072;          // bytes of one K-tile of a problem's plane image
   const int grid = (int)gridDim.x;
   auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -73,10 +79,16 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
   int pu_soff = 0, pu_nkt = 0, pc_ysoff = 0, pc_m0 = 0, pc_n0 = 0;
   int pd_ysoff = 0, pd_m0 = 0, pd_n0 = 0, pd_nkt = 0;
   auto locate = [&](int l) {
-    const int prob = sc(l / gx), bx = l - prob * gx;
-    const int xcd = bx & 7, q = gx >> 3, r = gx & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);      // as wino_gemm.hip: n-tile fastest
-    const int mt = sc(lid / gn), nt = lid - mt * gn;
+    // Item order.  Block b runs on XCD b & 7 and takes items b, b + grid, ...: item l belongs to XCD l & 7, and the blocks of an XCD are
+    // at positions j = l >> 3 .. + 63 of their XCD's list at any one time.  Whole problems go to one XCD (problem s = 8 (j / gx) + xcd,
+    // in the groups' order: every XCD gets the same mix of K), so the six m-tiles that read the same U tile and the n-tiles that read
+    // the same V rows meet in one L2 (with wino_gemm.hip's order -- a problem's items dealt over all XCDs -- every U tile was fetched by
+    // six L2s: the weight loads were 69 of 162 us at K = 832).  The problems % 8 last problems are dealt item by item.
+    int prob, lid;
+    if (l < main_items) { const int j = l >> 3, jq = sc(j / gx); prob = jq * 8 + (l & 7); lid = j - jq * gx; }
+    else { const int lr = l - main_items; const int pq = sc(lr / gx); prob = (main_items / gx) + pq; lid = lr - pq * gx; }
+    prob = sc(prob);
+    const int nt = sc(lid / gm), mt = lid - nt * gm;          // m-tile fastest
     int b = prob, K = nK0;
     long long ox = oX0, ow = oW0, oy = oY0;
     if (ngroups > 1 && prob >= nB0) { b = prob - nB0; K = nK1; ox = oX1; ow = oW1; oy = oY1; }
@@ -106,7 +118,11 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
     xr[set][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, x_off[r], x_soff + x_t * 128, 0));
   };
   auto load_u = [&](const int set, const int n) {      // n = ct * 3 + plane
+#if defined(OFFK_GS_EXP) && (OFFK_GS_EXP & 16)     /* timing experiment: every step re-reads the item's first K-tile (cache-resident) */
+    wr[set][n / 3][n % 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, u_voff, u_soff + n * 1024, 0));
+#else
     wr[set][n / 3][n % 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, u_voff, u_soff + u_t * ukstep + n * 1024, 0));
+#endif
   };
   auto adv_x = [&]() {
     ++x_t;
@@ -153,15 +169,24 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
   };
 #define OFFK_SB __builtin_amdgcn_sched_barrier(0)
 
-  // the finished item: tile i = (row tile i >> 1, channel tile i & 1); a lane holds channels 4 lg .. + 3 of row li
+  // the finished item: tile i = (row tile i >> 1, channel tile i & 1); a lane holds channels 4 lg .. + 3 of row li.
+  // MI355X + hipcc (ROCm 7.2): a VALU write to the FIRST data register of a buffer_store_dwordx4 in the instruction right behind it
+  // reached memory in lanes 12-15 of every sixteen (run-to-run varying; hipcc places no wait state there when the store's soffset is a
+  // register -- it had re-used the register for the next tile's address): each store is followed by s_nop 1, fenced.
+  const int st_voff = (li * argCo + 2 * wave * 16 + 4 * lg) * 4;
   auto store_item = [&]() {
+    const int ybase = c_ysoff + (c_m0 * argCo + c_n0) * 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int row = c_m0 + (i >> 1) * 16 + li;
-      const int voff = row < argM ? (row * argCo + c_n0 + (2 * wave + (i & 1)) * 16 + 4 * lg) * 4 : GS_OOB;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, c_ysoff, 0);
-      acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int rt = i >> 1;
+      const int voff = li < argM - c_m0 - rt * 16 ? st_voff : GS_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, ybase + (rt * 16 * argCo + (i & 1) * 16) * 4, 0);
+      OFFK_SB;
+      asm volatile("s_nop 1");
+      OFFK_SB;
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- prologue: V(0) cut into stage 0, V(1) in registers, U(0) in registers ----
@@ -204,17 +229,20 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
         const int n = q * 8 + i, rt = i >> 1, ct = i & 1;
         t[i] = mf(q == 0 ? z : t[i], wr[ST][ct][WP[q]], xb[rt][XP[q]]);
         // behind MFMA n: the step's loads one at a time, then the cut in slices, then the scratch tiles into their accumulators
-        if (n == 0) load_x(ST, 0);
-        else if (n == 1) load_x(ST, 1);
-        else if (n < 8) load_u(ST ^ 1, n - 2);
-        else if (n < 19) cut_slice(n - 8, ST ^ 1, 0, ST ^ 1);
-        else if (n < 30) cut_slice(n - 19, ST ^ 1, 1, ST ^ 1);
-        else if (n >= 44) { acc[n - 44] += t[n - 44]; asm volatile("" : "+v"(acc[n - 44])); }
+        if (n == 0) { if (!(OFFK_GS_EXP & 8)) load_x(ST, 0); }
+        else if (n == 1) { if (!(OFFK_GS_EXP & 8)) load_x(ST, 1); }
+        else if (n < 8) { if (!(OFFK_GS_EXP & 4)) load_u(ST ^ 1, n - 2); }
+        else if (n < 19) { if (!(OFFK_GS_EXP & 1)) cut_slice(n - 8, ST ^ 1, 0, ST ^ 1); }
+        else if (n < 30) { if (!(OFFK_GS_EXP & 1)) cut_slice(n - 19, ST ^ 1, 1, ST ^ 1); }
+        else if (n >= 44 && !(OFFK_GS_EXP & 2)) { acc[n - 44] += t[n - 44]; asm volatile("" : "+v"(acc[n - 44])); }
         OFFK_SB;
       }
     }
 #pragma unroll
-    for (int i = 4; i < 8; ++i) { acc[i] += t[i]; asm volatile("" : "+v"(acc[i])); }
+    for (int i = 4; i < 8; ++i) {
+      if (OFFK_GS_EXP & 2) acc[i] = t[i]; else acc[i] += t[i];
+      asm volatile("" : "+v"(acc[i]));
+    }
     OFFK_SB;
     // cursors: the multiply, then U, then V (an item's descriptors are handed down in that order)
     ++c_t;

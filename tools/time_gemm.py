@@ -1,8 +1,10 @@
 """Times offk_batched_gemm_nt on the shapes of the forward's Winograd GEMMs (B = 64: 384 rows per point), fp32 pipe vs split-fp32:
     python tools/time_gemm.py [reps]"""
+import os
 import sys
 
-import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
 
 import offk_amd  # noqa: F401
 from offk_amd import _lib, runtime
