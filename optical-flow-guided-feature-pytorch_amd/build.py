@@ -187,6 +187,37 @@ def check_counted_store_waits(src_name, code_objects):
     return rows
 
 
+# A VALU write to a data register of a 12- / 16-byte store in the instruction directly behind the store: on MI355X the new value reached
+# memory in some lanes (wino_gemm_split.hip, round 5: lanes 12-15 of every sixteen, run-to-run varying).  LLVM's hazard recogniser
+# places the wait state only when the store has no SGPR offset; hipcc had re-used the first data register for the next address.
+_WIDE_STORE_RE = re.compile(r"^(?:buffer|global|flat)_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
+_VALU_DST_RE = re.compile(r"^v_(?!cmp|cmpx|mfma|readlane|readfirstlane)\w+\s+(?:v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)")
+
+
+def store_data_hazards(disassembly):
+    body = [ln.split("//")[0].strip() for ln in disassembly.splitlines()]
+    body = [b for b in body if b and not b.endswith(":")]
+    bad = []
+    for a, b in zip(body, body[1:]):
+        m = _WIDE_STORE_RE.match(a)
+        d = _VALU_DST_RE.match(b) if m else None
+        if not d:
+            continue
+        lo, hi = (int(d.group(3)),) * 2 if d.group(3) else (int(d.group(1)), int(d.group(2)))
+        if lo <= int(m.group(2)) and hi >= int(m.group(1)):
+            bad.append("%s  ||  %s" % (a, b))
+    return bad
+
+
+def check_store_data_hazard(obj, code_objects):
+    bad = []
+    for path in code_objects:
+        bad += store_data_hazards(subprocess.run([_llvm_objdump(), "-d", path], capture_output=True, text=True).stdout)
+    if bad:
+        raise RuntimeError("ISA check failed for %s: %d wide store(s) with a VALU write to their data registers directly behind them "
+                           "(put `s_nop 1` between fences behind the store, see wino_gemm_split.hip), first: %s" % (obj, len(bad), bad[0]))
+
+
 def check_resources(src_name, kernels):
     """Applies ASM_SCHEDULED_KERNELS to the kernels of one translation unit; returns the rows it checked."""
     rows, matched = [], set()
@@ -224,6 +255,7 @@ def check_object(obj):
     cos = _code_objects(obj)
     try:
         check_isa(obj, cos)
+        check_store_data_hazard(obj, cos)
         src = os.path.basename(obj).replace(".o", ".hip")
         kernels = [k for co in cos for k in kernel_resources(co)]
         check_resources(src, kernels)

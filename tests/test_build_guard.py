@@ -52,3 +52,15 @@ def test_guard_fires(build_mod):
         build_mod.check_resources("chain_fused.hip", [dict(chain, sgpr_spill_count=3)])
     with pytest.raises(RuntimeError, match="no kernel of pw_tdiff.hip matches"):
         build_mod.check_resources("pw_tdiff.hip", [dict(ok, name="offk::renamed_kernel(offk::PtParams)")])
+
+
+def test_store_data_hazard_scanner(build_mod):
+    """A VALU write to a data register of a 16-byte store directly behind it (MI355X: the new value reached memory in some lanes,
+    wino_gemm_split.hip round 5) is refused; a write to another register, a compare, or any instruction in between is not."""
+    hit = "  buffer_store_dwordx4 v[42:45], v51, s[56:59], s25 offen   // 000000001A2C\n  v_add_u32_e32 v42, s17, v109\n"
+    assert len(build_mod.store_data_hazards(hit)) == 1
+    assert len(build_mod.store_data_hazards(hit.replace("v_add_u32_e32 v42", "v_pk_add_f32 v[44:45]"))) == 1
+    assert build_mod.store_data_hazards(hit.replace("v_add_u32_e32 v42", "v_add_u32_e32 v46")) == []
+    assert build_mod.store_data_hazards(hit.replace("v_add_u32_e32 v42,", "v_cmp_le_i32_e32 vcc,")) == []
+    assert build_mod.store_data_hazards(hit.replace("\n  v_add", "\n  s_nop 1\n  v_add")) == []
+    assert build_mod.store_data_hazards(hit.replace("dwordx4 v[42:45]", "dwordx2 v[42:43]")) == []
