@@ -282,10 +282,10 @@ int offk_winograd_between(void* stream, const float* M, const float* bias_in, in
 
 /* The batched GEMMs of a convolution on a Winograd path as a stage of their own (wino_gemm.hip / wino_gemm_split.hip; ABI v9):
  *   y[b] = x[b] . w[b]^T,  x [batch][M][K], w [batch][Co][K], y [batch][M][Co], all contiguous fp32; K % 32 == 0, Co % 64 == 0.
- * precision OFFK_PRECISION_FP32: the fp32 matrix pipe.  OFFK_PRECISION_F32SPLIT (Co % 128 == 0, K >= 64): split-fp32 arithmetic on the
+ * precision OFFK_PRECISION_FP32: the fp32 matrix pipe.  OFFK_PRECISION_F32SPLIT (K >= 64): split-fp32 arithmetic on the
  * bf16 pipe -- both operands cut into three bf16 planes, six plane products per multiply (the arithmetic of the split units kernel);
  * scratch (>= batch * Co * K * 6 bytes, device) receives the plane image of w.  What a handle created with that precision runs for the
- * fusion convolutions with Co % 128 == 0 (RGB_OFF.py:762, 766, 775-777, 833, 837). */
+ * fusion convolutions on a Winograd path (RGB_OFF.py:657, 762, 766, 775-777, 833, 837). */
 int offk_batched_gemm_nt(void* stream, const float* x, const float* w, float* y, int batch, int M, int K, int Co, int precision,
                          void* scratch, size_t scratch_bytes);
 

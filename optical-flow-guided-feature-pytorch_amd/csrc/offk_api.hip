@@ -194,6 +194,7 @@ struct offk_handle {
   float* wino_u7 = nullptr;      // transformed weights of C_T28 in the four groups of winograd7.hip (225 x Co x Ci floats)
   bool wino_7x7 = true;          // the 7x7 / stride 2 conv of fusion@28 in polyphase Winograd form F(5x5, 4x4) (OFFK_WINOGRAD_7X7=0: direct)
   int wino7_min_p = 12;          // ... from this many pairs (OFFK_WINOGRAD_7X7=<n> with n > 1 at offk_create: tools)
+  float* wino_u7s = nullptr;     // the same for wino_u7 (Co = 64: the 64-channel form of the kernel)
   float* wino_us[6] = {};        // split-fp32 handles: the plane images of wino_u (wino_gemm_split.hip), 6 bytes per element; nullptr: fp32 GEMMs
   float* wino_u[6] = {};         // transformed weights [121][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; 400 x Co x Ci floats of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
@@ -673,6 +674,14 @@ int finalize_wino(offk_handle* h, hipStream_t st) {
                                         grp[g].kmul * c.Ci, grp[g].batch, st));
   }
   if (h->wino_u7) HIP_TRY(h, wino7_weight_launch(h->conv_w[C_T28], kConvs[C_T28].Co, kConvs[C_T28].Ci, h->wino_u7, st));
+  if (h->wino_u7 && h->wino_u7s) {
+    const ConvSpec& c = kConvs[C_T28];
+    WinoGroup grp[4];
+    const int ngrp = wino7_groups(1, c.Ci, c.Co, grp);
+    for (int g = 0; g < ngrp; ++g)
+      HIP_TRY(h, wino_pack_split_launch(h->wino_u7 + grp[g].u_off, reinterpret_cast<char*>(h->wino_u7s) + grp[g].u_off * 6, c.Co,
+                                        grp[g].kmul * c.Ci, grp[g].batch, st));
+  }
   {
     const ConvId c2[3] = {C2_28A, C2_28B, C2_28C};
     for (int k = 0; k < 3; ++k)
@@ -819,9 +828,11 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     if (h->split_gemm)
       for (int k = 0; k < 6; ++k) {
         const size_t elems = (size_t)(k == 5 ? kWinoUnits4 : kWinoPoints) * kConvs[wid[k]].Co * kConvs[wid[k]].Ci;
-        if (kConvs[wid[k]].Co % 128 == 0 && kConvs[wid[k]].Ci >= 64 && !(h->split_gemm_skip & (1 << k)) &&
+        if (kConvs[wid[k]].Co % 64 == 0 && kConvs[wid[k]].Ci >= 64 && !(h->split_gemm_skip & (1 << k)) &&
             dev_alloc(h, &h->wino_us[k], (elems * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
       }
+    if (h->wino_7x7 && h->split_gemm && !(h->split_gemm_skip & 64) &&
+        dev_alloc(h, &h->wino_u7s, ((size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     { const char* e = getenv("OFFK_CHAIN_WINO"); h->chain_wino = h->chain && !(e && *e == '0'); }
     if (h->chain_wino)
@@ -1195,6 +1206,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     const char* why = nullptr;
     const void* planes = nullptr;
     for (int k = 0; k < 6; ++k) if (U == h->wino_u[k]) planes = h->wino_us[k];
+    if (U == h->wino_u7) planes = h->wino_u7s;
     hipError_t e = wino_gemms_launch(grp, ngrp, npoints, rows, Ci, Co, V, U, M, h->wino_gemm, s, &why, planes);
     if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(key) + " (winograd): " + (why ? why : hipGetErrorString(e)));
     return OFFK_OK;
@@ -1677,7 +1689,7 @@ int offk_batched_gemm_nt(void* stream, const float* x, const float* w, float* y,
   WinoGroup grp{batch, 1, 0, 0, 0};
   const void* planes = nullptr;
   if (precision == OFFK_PRECISION_F32SPLIT) {
-    if ((Co & 127) || K < 64) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": the split-fp32 form takes Co % 128 == 0, K >= 64");
+    if (K < 64) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": the split-fp32 form takes K >= 64");
     if (!scratch || scratch_bytes < (size_t)batch * Co * K * 6)
       return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch smaller than batch * Co * K * 6 bytes (the plane image of w)");
     hipError_t e = wino_pack_split_launch(w, scratch, Co, K, batch, st);

@@ -10,7 +10,7 @@
 //     operand order; a wave owns two channel tiles (32 channels) of all 64 rows and loads their six 1-KB pieces of the NEXT K-tile
 //     straight from L2 into registers;
 //   * V: thread (row = tid / 8 (+ 32), k chunk = tid % 8) loads 16 B of the K-tile TWO steps ahead into registers, cuts them one step
-//     ahead (22 vector instructions per four values) and writes 8 B per plane into the plane image of the next K-tile in LDS:
+//     ahead (18 vector instructions per four values) and writes 8 B per plane into the plane image of the next K-tile in LDS:
 //     [row tile][plane][k group g][slot = row ^ 2 g] x 16 B -- conflict-free for the cut's ds_write_b64 (banks mod 32, sixteen-lane
 //     groups = two rows x eight chunks) and for the MFMA operand's ds_read_b128 (MI355X_MICROARCH.md, LDS);
 //   * a step = one K-tile: 48 MFMAs per wave, product-major (eight independent chains of six), the cut / the loads / the folds in
@@ -34,17 +34,22 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int GS_BM = 64, GS_BN = 128;
+constexpr int GS_BM = 64;                   // rows per item; channels per item: 64 CT (four waves x CT channel tiles of 16)
 constexpr int GS_GRP = 256;                 // one k group of a plane: 16 row slots x 16 B (8 bf16 = k 8g .. 8g + 7)
 constexpr int GS_PLANE = 4 * GS_GRP;        // 32 k
 constexpr int GS_RT = 3 * GS_PLANE;         // a row tile (16 rows): planes h, m, l
 constexpr int GS_STAGE = 4 * GS_RT;         // 64 rows
 constexpr int GS_LDS = 2 * GS_STAGE;        // 24576 B
-constexpr int GS_RESIDENT = 2 * 256;        // blocks the chip holds at a time = the persistent grid
+constexpr int GS_RESIDENT = 2 * 256;        // blocks the chip holds at a time = the persistent grid (CT = 2: 179 VGPRs, two per CU)
+constexpr int GS_RESIDENT_CT1 = 3 * 256;    // CT = 1: 129 VGPRs, three per CU
 constexpr int GS_OOB = (int)0x80000000;     // a per-lane offset past every descriptor: loads return zeros, stores are dropped
 }  // namespace
 
+// CT = channel tiles per wave: 2 (128 channels per item), or 1 (64: the 7x7 conv's Co = 64 -- half the MFMAs per cut value and per step)
+template <int CT>
 __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p) {
+  constexpr int NT = 4 * CT;                // the wave's accumulator tiles: (row tile i / CT, channel tile i % CT)
+  constexpr int GS_BN = 64 * CT;
   extern __shared__ __attribute__((aligned(16))) char gs_planes[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
   const long long oX0 = p.g_x[0], oX1 = p.g_x[1], oX2 = p.g_x[2], oX3 = p.g_x[3];
   const long long oW0 = p.g_w[0], oW1 = p.g_w[1], oW2 = p.g_w[2], oW3 = p.g_w[3];
   const long long oY0 = p.g_y[0], oY1 = p.g_y[1], oY2 = p.g_y[2], oY3 = p.g_y[3];
-  const int ngroups = p.ngroups, argM = p.M, argCo = p.Co, gn = p.gn, total_items = p.total_items;
+  const int ngroups = p.ngroups, argM = p.M, argCo = p.Co, total_items = p.total_items;
   const int gm = p.gm;
   const int main_items = (total_items / gx / 8) * 8 * gx;      // the items of the problems that go to XCDs whole
   const int ukstep = (argCo >> 4) * 3072;          // bytes of one K-tile of a problem's plane image
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
       const int m = m0 + lrow + 32 * r2;
       x_off[r2] = m < argM ? (m * K + lc * 4) * 4 : GS_OOB;
     }
-    pu_soff = sc((int)((ow + (long long)b * argCo * K) * 6) + ((n0 >> 4) + 2 * wave) * 3072);
+    pu_soff = sc((int)((ow + (long long)b * argCo * K) * 6) + ((n0 >> 4) + CT * wave) * 3072);
     pu_nkt = x_nkt;
     pc_ysoff = sc((int)((oy + (long long)b * argM * argCo) * 4));
     pc_m0 = m0; pc_n0 = n0;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
   int c_l = x_l, c_t = 0, c_nkt = 0, c_ysoff = 0, c_m0 = 0, c_n0 = 0;
 
   u32x4 xr[2][2];                  // V registers [set = K-tile parity][row half]
-  u32x4 wr[2][2][3];               // U planes [set][channel tile][plane]
+  u32x4 wr[2][CT][3];              // U planes [set][channel tile][plane]
   auto load_x = [&](const int set, const int r) {
     xr[set][r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, x_off[r], x_soff + x_t * 128, 0));
   };
@@ -141,52 +146,64 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
     }
   };
 
-  // ---- the cut of register set `set`, row half r, in slices of two vector instructions (+ a store) ----
+  // ---- the cut of register set `set`, row half r, in seven slices (+ a store in the last three): 4 and, 2 packed subtractions, 4 and,
+  //      2 packed subtractions, 3 x (2 byte permutes + ds_write_b64) -- 18 vector instructions per four values ----
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   unsigned ch[4], cm[4];
-  float cr[4], cl[4];
+  f32x2 cr[2], cl[2];
   auto cut_slice = [&](const int s, const int set, const int r, const int st) {
     const u32x4& x = xr[set][r];
-    if (s < 8) {
-      const int e = s >> 1;
-      if ((s & 1) == 0) { ch[e] = x[e] & 0xffff0000u; cr[e] = __uint_as_float(x[e]) - __uint_as_float(ch[e]); }
-      else { cm[e] = __float_as_uint(cr[e]) & 0xffff0000u; cl[e] = cr[e] - __uint_as_float(cm[e]); }     // <= 8 significant bits left
-      return;
-    }
-    char* dst = pl_wr + st * GS_STAGE + r * 2 * GS_RT + (s - 8) * GS_PLANE;
-    u32x2 d;
-    if (s == 8) d = u32x2{__builtin_amdgcn_perm(ch[1], ch[0], 0x07060302), __builtin_amdgcn_perm(ch[3], ch[2], 0x07060302)};
-    else if (s == 9) d = u32x2{__builtin_amdgcn_perm(cm[1], cm[0], 0x07060302), __builtin_amdgcn_perm(cm[3], cm[2], 0x07060302)};
-    else d = u32x2{__builtin_amdgcn_perm(__float_as_uint(cl[1]), __float_as_uint(cl[0]), 0x07060302),
-                   __builtin_amdgcn_perm(__float_as_uint(cl[3]), __float_as_uint(cl[2]), 0x07060302)};
-    *reinterpret_cast<u32x2*>(dst) = d;
-  };
-
-  f32x4 acc[8];
+    if (s == 0) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 4; ++e) ch[e] = x[e] & 0xffff0000u;
+    } else if (s == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        cr[e] = f32x2{__uint_as_float(x[2 * e]), __uint_as_float(x[2 * e + 1])} - f32x2{__uint_as_float(ch[2 * e]), __uint_as_float(ch[2 * e + 1])};
+    } else if (s == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cm[e] = __float_as_uint(cr[e >> 1][e & 1]) & 0xffff0000u;
+    } else if (s == 3) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) cl[e] = cr[e] - f32x2{__uint_as_float(cm[2 * e]), __uint_as_float(cm[2 * e + 1])};     // <= 8 significant bits left
+    } else {
+      char* dst = pl_wr + st * GS_STAGE + r * 2 * GS_RT + (s - 4) * GS_PLANE;
+      u32x2 d;
+      if (s == 4) d = u32x2{__builtin_amdgcn_perm(x[1], x[0], 0x07060302), __builtin_amdgcn_perm(x[3], x[2], 0x07060302)};
+      else if (s == 5) d = u32x2{__builtin_amdgcn_perm(cm[1], cm[0], 0x07060302), __builtin_amdgcn_perm(cm[3], cm[2], 0x07060302)};
+      else d = u32x2{__builtin_amdgcn_perm(__float_as_uint(cl[0][1]), __float_as_uint(cl[0][0]), 0x07060302),
+                     __builtin_amdgcn_perm(__float_as_uint(cl[1][1]), __float_as_uint(cl[1][0]), 0x07060302)};
+      *reinterpret_cast<u32x2*>(dst) = d;
+    }
+  };
+  constexpr int CUT_SLICES = 7;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mf = [&](f32x4 c, const u32x4& a, const u32x4& b) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   };
 #define OFFK_SB __builtin_amdgcn_sched_barrier(0)
 
-  // the finished item: tile i = (row tile i >> 1, channel tile i & 1); a lane holds channels 4 lg .. + 3 of row li.
+  // the finished item: a lane holds channels 4 lg .. + 3 of row li.
   // MI355X + hipcc (ROCm 7.2): a VALU write to the FIRST data register of a buffer_store_dwordx4 in the instruction right behind it
   // reached memory in lanes 12-15 of every sixteen (run-to-run varying; hipcc places no wait state there when the store's soffset is a
   // register -- it had re-used the register for the next tile's address): each store is followed by s_nop 1, fenced.
-  const int st_voff = (li * argCo + 2 * wave * 16 + 4 * lg) * 4;
+  const int st_voff = (li * argCo + CT * wave * 16 + 4 * lg) * 4;
   auto store_item = [&]() {
     const int ybase = c_ysoff + (c_m0 * argCo + c_n0) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rt = i >> 1;
+    for (int i = 0; i < NT; ++i) {
+      const int rt = i / CT;
       const int voff = li < argM - c_m0 - rt * 16 ? st_voff : GS_OOB;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, ybase + (rt * 16 * argCo + (i & 1) * 16) * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, ybase + (rt * 16 * argCo + (i % CT) * 16) * 4, 0);
       OFFK_SB;
       asm volatile("s_nop 1");
       OFFK_SB;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- prologue: V(0) cut into stage 0, V(1) in registers, U(0) in registers ----
@@ -198,19 +215,19 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
   load_x(1, 0); load_x(1, 1);
   adv_x();
 #pragma unroll
-  for (int n = 0; n < 6; ++n) load_u(0, n);
+  for (int n = 0; n < 3 * CT; ++n) load_u(0, n);
   adv_u();
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int s = 0; s < 11; ++s) cut_slice(s, 0, r, 0);
+    for (int s = 0; s < CUT_SLICES; ++s) cut_slice(s, 0, r, 0);
   __syncthreads();
 
   // One step: K-tile c_t of the multiply's item out of plane stage ST with the U registers of set ST; the cut of the next tile (register
   // set ST ^ 1) into plane stage ST ^ 1; V two tiles ahead into register set ST; U of the next tile into set ST ^ 1.
   auto step = [&](const int ST) -> bool {
     u32x4 xb[4][3];
-    f32x4 t[8];
+    f32x4 t[NT];
     const char* const rd = xrd + ST * GS_STAGE;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) xb[rt][0] = *reinterpret_cast<const u32x4*>(rd + rt * GS_RT);
@@ -222,27 +239,33 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // planes 0 = h, 1 = m, 2 = l; smallest products first: w_l x_h, w_h x_l, w_m x_m, w_m x_h, w_h x_m, w_h x_h
     constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, XP[6] = {0, 2, 1, 0, 1, 0};
+    // the step's side jobs -- V loads [2], U loads [3 CT], cut slices [14] -- go out behind the MFMAs of the first five products, in
+    // that order, job j behind MFMA j * NS / NJ; the last product's MFMAs are followed by the folds (NT / 2 tiles behind)
+    constexpr int NJ = 2 + 3 * CT + 2 * CUT_SLICES, NS = 5 * NT;
+    auto job = [&](const int j) {
+      if (j < 2) { if (!(OFFK_GS_EXP & 8)) load_x(ST, j); }
+      else if (j < 2 + 3 * CT) { if (!(OFFK_GS_EXP & 4)) load_u(ST ^ 1, j - 2); }
+      else if (!(OFFK_GS_EXP & 1)) { const int c = j - 2 - 3 * CT; cut_slice(c % CUT_SLICES, ST ^ 1, c / CUT_SLICES, ST ^ 1); }
+    };
+    auto fold = [&](const int i) {
+      if (OFFK_GS_EXP & 2) acc[i] = t[i]; else acc[i] += t[i];
+      asm volatile("" : "+v"(acc[i]));
+    };
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int n = q * 8 + i, rt = i >> 1, ct = i & 1;
+      for (int i = 0; i < NT; ++i) {
+        const int n = q * NT + i, rt = i / CT, ct = i % CT;
         t[i] = mf(q == 0 ? z : t[i], wr[ST][ct][WP[q]], xb[rt][XP[q]]);
-        // behind MFMA n: the step's loads one at a time, then the cut in slices, then the scratch tiles into their accumulators
-        if (n == 0) { if (!(OFFK_GS_EXP & 8)) load_x(ST, 0); }
-        else if (n == 1) { if (!(OFFK_GS_EXP & 8)) load_x(ST, 1); }
-        else if (n < 8) { if (!(OFFK_GS_EXP & 4)) load_u(ST ^ 1, n - 2); }
-        else if (n < 19) { if (!(OFFK_GS_EXP & 1)) cut_slice(n - 8, ST ^ 1, 0, ST ^ 1); }
-        else if (n < 30) { if (!(OFFK_GS_EXP & 1)) cut_slice(n - 19, ST ^ 1, 1, ST ^ 1); }
-        else if (n >= 44 && !(OFFK_GS_EXP & 2)) { acc[n - 44] += t[n - 44]; asm volatile("" : "+v"(acc[n - 44])); }
+        if (n < NS) {
+#pragma unroll
+          for (int j = (n * NJ + NS - 1) / NS; j < ((n + 1) * NJ + NS - 1) / NS; ++j) job(j);
+        } else if (i >= NT / 2) fold(i - NT / 2);
         OFFK_SB;
       }
     }
 #pragma unroll
-    for (int i = 4; i < 8; ++i) {
-      if (OFFK_GS_EXP & 2) acc[i] = t[i]; else acc[i] += t[i];
-      asm volatile("" : "+v"(acc[i]));
-    }
+    for (int i = NT / 2; i < NT; ++i) fold(i);
     OFFK_SB;
     // cursors: the multiply, then U, then V (an item's descriptors are handed down in that order)
     ++c_t;
@@ -302,7 +325,7 @@ hipError_t wino_pack_split_launch(const float* U, void* img, int Co, int K, int 
 }
 
 bool wino_gemm_split_supported(const WinoGemmArgs& a) {
-  if (!a.w_planes || a.M <= 0 || a.Co % GS_BN || a.ngroups < 1 || a.ngroups > 4) return false;
+  if (!a.w_planes || a.M <= 0 || a.Co % 64 || a.ngroups < 1 || a.ngroups > 4) return false;
   long long problems = 0, xe = 0, we = 0, ye = 0;
   for (int g = 0; g < a.ngroups; ++g) {
     if (a.g_K[g] % 32 || a.g_K[g] < 64 || a.g_batch[g] <= 0) return false;
@@ -313,7 +336,7 @@ bool wino_gemm_split_supported(const WinoGemmArgs& a) {
     if ((long long)a.M * a.g_K[g] * 4 >= 0x7fffff00ll) return false;
   }
   if (xe * 4 >= 0x7fffff00ll || we * 6 >= 0x7fffff00ll || ye * 4 >= 0x7fffff00ll) return false;
-  const long long total = problems * ((a.M + GS_BM - 1) / GS_BM) * (a.Co / GS_BN);
+  const long long total = problems * ((a.M + GS_BM - 1) / GS_BM) * (a.Co / 64);
   return total > 0 && total < (1ll << 30);
 }
 
@@ -329,12 +352,15 @@ hipError_t wino_gemm_split_launch(const WinoGemmArgs& a_in, hipStream_t st) {
   }
   a.x_bytes = xe * 4; a.w_bytes = we * 6; a.y_bytes = ye * 4;
   a.gm = (a.M + GS_BM - 1) / GS_BM;
-  a.gn = a.Co / GS_BN;
+  const bool wide = a.Co % 128 == 0;         // 128 channels per item where Co allows it
+  a.gn = a.Co / (wide ? 128 : 64);
   a.total_items = (int)(problems * a.gm * a.gn);
-  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_gemm_split_kernel), GS_LDS);
+  hipError_t e = lds_attr_once(wide ? reinterpret_cast<const void*>(wino_gemm_split_kernel<2>) : reinterpret_cast<const void*>(wino_gemm_split_kernel<1>), GS_LDS);
   if (e != hipSuccess) return e;
-  const int grid = a.total_items < GS_RESIDENT ? a.total_items : GS_RESIDENT;
-  hipLaunchKernelGGL(wino_gemm_split_kernel, dim3(grid), dim3(256), GS_LDS, st, a);
+  const int resident = wide ? GS_RESIDENT : GS_RESIDENT_CT1;
+  const int grid = a.total_items < resident ? a.total_items : resident;
+  if (wide) hipLaunchKernelGGL(wino_gemm_split_kernel<2>, dim3(grid), dim3(256), GS_LDS, st, a);
+  else hipLaunchKernelGGL(wino_gemm_split_kernel<1>, dim3(grid), dim3(256), GS_LDS, st, a);
   return hipGetLastError();
 }
 

@@ -180,10 +180,11 @@ def gemm_inputs(batch, M, K, Co, kind, seed):
 
 
 @pytest.mark.parametrize("batch,M,K,Co", [(5, 384, 832, 256), (121, 384, 256, 256), (3, 100, 128, 128), (7, 64, 64, 512),
-                                          (2, 777, 1056, 128)])
+                                          (2, 777, 1056, 128), (9, 200, 320, 64), (3, 130, 1280, 192), (70, 3456, 64, 64)])
 def test_batched_gemm_split_shapes(rt, batch, M, K, Co):
-    """Item streams longer than the persistent grid (121 x 6 x 2 items), row tails (M % 64 != 0), the shortest K the kernel takes
-    (two K-tiles: the three cursors cross item boundaries on consecutive steps), every element against fp64."""
+    """Item streams longer than the persistent grid (121 x 6 x 2 items; 70 x 54 of the 64-channel form), row tails (M % 64 != 0), the
+    shortest K the kernel takes (two K-tiles: the three cursors cross item boundaries on consecutive steps), Co = 64 / 192 (the
+    64-channel form), every element against fp64."""
     x, w = gemm_inputs(batch, M, K, Co, "relu", 11)
     ref = torch.einsum("bmk,bnk->bmn", x.double(), w.double())
     y = rt.batched_gemm_nt(dev(x), dev(w), "f32split").double().cpu()
