@@ -40,14 +40,20 @@ constexpr int GS_PLANE = 4 * GS_GRP;        // 32 k
 constexpr int GS_RT = 3 * GS_PLANE;         // a row tile (16 rows): planes h, m, l
 constexpr int GS_STAGE = 4 * GS_RT;         // 64 rows
 constexpr int GS_LDS = 2 * GS_STAGE;        // 24576 B
-constexpr int GS_RESIDENT = 2 * 256;        // blocks the chip holds at a time = the persistent grid (CT = 2: 179 VGPRs, two per CU)
-constexpr int GS_RESIDENT_CT1 = 3 * 256;    // CT = 1: 129 VGPRs, three per CU
+#ifndef OFFK_GS_BLOCKS
+#define OFFK_GS_BLOCKS 3      /* blocks per CU the kernel is compiled for */
+#endif
+#ifndef OFFK_GS_BLOCKS_CT1
+#define OFFK_GS_BLOCKS_CT1 3
+#endif
+constexpr int GS_RESIDENT = OFFK_GS_BLOCKS * 256;        // blocks the chip holds at a time = the persistent grid (CT = 2: 162 VGPRs)
+constexpr int GS_RESIDENT_CT1 = OFFK_GS_BLOCKS_CT1 * 256;    // CT = 1: 120 VGPRs
 constexpr int GS_OOB = (int)0x80000000;     // a per-lane offset past every descriptor: loads return zeros, stores are dropped
 }  // namespace
 
 // CT = channel tiles per wave: 2 (128 channels per item), or 1 (64: the 7x7 conv's Co = 64 -- half the MFMAs per cut value and per step)
 template <int CT>
-__global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p) {
+__global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(WinoGemmArgs p) {
   constexpr int NT = 4 * CT;                // the wave's accumulator tiles: (row tile i / CT, channel tile i % CT)
   constexpr int GS_BN = 64 * CT;
   extern __shared__ __attribute__((aligned(16))) char gs_planes[];
@@ -239,13 +245,16 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(WinoGemmArgs p)
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // planes 0 = h, 1 = m, 2 = l; smallest products first: w_l x_h, w_h x_l, w_m x_m, w_m x_h, w_h x_m, w_h x_h
     constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, XP[6] = {0, 2, 1, 0, 1, 0};
-    // the step's side jobs -- V loads [2], U loads [3 CT], cut slices [14] -- go out behind the MFMAs of the first five products, in
+    // the step's side jobs -- V loads [2], cut slices [14], U loads [3 CT] -- go out behind the MFMAs of the first five products, in
     // that order, job j behind MFMA j * NS / NJ; the last product's MFMAs are followed by the folds (NT / 2 tiles behind)
     constexpr int NJ = 2 + 3 * CT + 2 * CUT_SLICES, NS = 5 * NT;
+// (the U loads LAST, planes l, m, h: the registers of the current tile's planes come free in that order -- w_l behind the first
+    //  product, w_m behind the fourth -- which keeps the kernel at 162 VGPRs = three blocks per CU; with the loads at the top of the step
+    //  it needed 174, and the third block is worth 5 - 8 % per launch)
     auto job = [&](const int j) {
       if (j < 2) { if (!(OFFK_GS_EXP & 8)) load_x(ST, j); }
-      else if (j < 2 + 3 * CT) { if (!(OFFK_GS_EXP & 4)) load_u(ST ^ 1, j - 2); }
-      else if (!(OFFK_GS_EXP & 1)) { const int c = j - 2 - 3 * CT; cut_slice(c % CUT_SLICES, ST ^ 1, c / CUT_SLICES, ST ^ 1); }
+      else if (j < 2 + 2 * CUT_SLICES) { if (!(OFFK_GS_EXP & 1)) { const int c = j - 2; cut_slice(c % CUT_SLICES, ST ^ 1, c / CUT_SLICES, ST ^ 1); } }
+      else if (!(OFFK_GS_EXP & 4)) { const int u = j - 2 - 2 * CUT_SLICES; load_u(ST ^ 1, (u % CT) * 3 + 2 - u / CT); }
     };
     auto fold = [&](const int i) {
       if (OFFK_GS_EXP & 2) acc[i] = t[i]; else acc[i] += t[i];
