@@ -183,6 +183,8 @@ struct offk_handle {
   float* fc_b[3] = {};
   // residual-branch 1x1 convs merged into their sibling: out = W3*t + Wb*x == [W3|Wb] * [t|x] (K-concatenated)
   float* merged_w[3] = {};
+  float* merged_ws[3] = {};      // split-fp32 handles: the plane images of merged_w[1], [2] and of motion_conv1_trans_14b's weights
+  float* c1_14b_ws = nullptr;    // (the 1x1 convs on 7x7 maps that run on wino_gemm_split.hip's kernel with its conv epilogue)
   float* merged_b[3] = {};
   int merged_cfg[3] = {3, 3, 3}, merged_sk[3] = {1, 1, 1};   // kMergedPlan at offk_create
   bool merged_dirty = true;
@@ -610,7 +612,22 @@ struct View { const float* p; int cs, coff; };
 
 int conv_raw(offk_handle* h, hipStream_t st, const char* name, int Co, int Ci, int K, int stride, int pad, const float* w,
              const float* bias, int cfg, int sk, int n_img, int H, View x, const float* res, int res_cs, int res_coff,
-             int flags, float* y, int y_cs, int y_coff) {
+             int flags, float* y, int y_cs, int y_coff, const void* w_planes = nullptr) {
+  if (w_planes && K == 1 && stride == 1 && pad == 0 && !res && !(flags & OFFK_CONV_RELU_IN_)) {
+    // a 1x1 conv of a split-fp32 handle: wino_gemm_split.hip's kernel with its conv epilogue (bias, ReLU, the folded pool)
+    WinoGemmArgs a{};
+    a.x = x.p; a.w = w; a.y = y; a.M = n_img * H * H; a.Co = Co; a.ngroups = 1; a.g_batch[0] = 1; a.g_K[0] = Ci;
+    a.w_planes = w_planes;
+    a.epilogue = 1; a.x_rs = x.cs; a.x_coff = x.coff; a.y_rs = y_cs; a.y_coff = y_coff; a.bias = bias;
+    a.relu = (flags & (OFFK_CONV_RELU_PRE_ | OFFK_CONV_RELU_POST_)) ? 1 : 0;
+    a.pool_part = h->cur_pool_part; a.pool_hw = h->cur_pool_part ? H * H : 0;
+    if (wino_gemm_split_supported(a)) {
+      { int rc = trace_mark(h, st, name); if (rc != OFFK_OK) return rc; }
+      hipError_t e = wino_gemm_split_launch(a, st);
+      if (e != hipSuccess) return fail_hip(h, e, name);
+      return OFFK_OK;
+    }
+  }
   ConvDesc d;
   d.x = x.p; d.x_cs = x.cs; d.x_coff = x.coff; d.n_img = n_img; d.H = H; d.W = H; d.Ci = Ci;
   d.w = w; d.bias = bias; d.Co = Co; d.KH = K; d.KW = K; d.stride = stride; d.pad = pad;
@@ -632,7 +649,7 @@ int conv(offk_handle* h, hipStream_t st, ConvId id, int n_img, int H, View x, co
   const ConvSpec& c = kConvs[id];
   const float* w = h->conv_w[id];
   return conv_raw(h, st, c.key, c.Co, c.Ci, c.K, c.stride, c.pad, w, h->conv_b[id], h->conv_cfg[id], h->conv_splitk[id], n_img,
-                  H, x, res, res_cs, res_coff, flags, y, y_cs, y_coff);
+                  H, x, res, res_cs, res_coff, flags, y, y_cs, y_coff, id == C1_14B ? h->c1_14b_ws : nullptr);
 }
 
 // main 1x1 + branch 1x1 as ONE conv over the channel-concatenated input [t | x]
@@ -641,7 +658,7 @@ int conv_merged(offk_handle* h, hipStream_t st, int m, int n_img, int H, View x,
   const ConvSpec& b = kConvs[kMerged[m].branch_id];
   const float* w = h->merged_w[m];
   return conv_raw(h, st, kMerged[m].name, a.Co, a.Ci + b.Ci, 1, 1, 0, w, h->merged_b[m], h->merged_cfg[m], h->merged_sk[m], n_img,
-                  H, x, nullptr, 0, 0, flags, y, y_cs, y_coff);
+                  H, x, nullptr, 0, 0, flags, y, y_cs, y_coff, h->merged_ws[m]);
 }
 
 // (re)build the merged weights after any conv weight changed: [Co][Ci_main | Ci_branch], bias = b_main + b_branch
@@ -656,7 +673,9 @@ int finalize_merged(offk_handle* h, hipStream_t st) {
     HIP_TRY(h, hipMemcpy2DAsync(h->merged_w[m] + a.Ci, K * 4, h->conv_w[kMerged[m].branch_id], (size_t)b.Ci * 4, (size_t)b.Ci * 4,
                                 a.Co, hipMemcpyDeviceToDevice, st));
     HIP_TRY(h, vec_add_launch(h->conv_b[kMerged[m].main_id], h->conv_b[kMerged[m].branch_id], h->merged_b[m], a.Co, st));
+    if (h->merged_ws[m]) HIP_TRY(h, wino_pack_split_launch(h->merged_w[m], h->merged_ws[m], a.Co, (int)K, 1, st));
   }
+  if (h->c1_14b_ws) HIP_TRY(h, wino_pack_split_launch(h->conv_w[C1_14B], h->c1_14b_ws, kConvs[C1_14B].Co, kConvs[C1_14B].Ci, 1, st));
   h->merged_dirty = false;
   return OFFK_OK;
 }
@@ -831,6 +850,13 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
         if (kConvs[wid[k]].Co % 64 == 0 && kConvs[wid[k]].Ci >= 64 && !(h->split_gemm_skip & (1 << k)) &&
             dev_alloc(h, &h->wino_us[k], (elems * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
       }
+    if (h->split_gemm && !(h->split_gemm_skip & 128)) {      // the 1x1 convs on 7x7 maps
+      for (int m = 1; m < 3; ++m) {
+        const size_t elems = (size_t)kConvs[kMerged[m].main_id].Co * (kConvs[kMerged[m].main_id].Ci + kConvs[kMerged[m].branch_id].Ci);
+        if (dev_alloc(h, &h->merged_ws[m], (elems * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+      }
+      if (dev_alloc(h, &h->c1_14b_ws, ((size_t)kConvs[C1_14B].Co * kConvs[C1_14B].Ci * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    }
     if (h->wino_7x7 && h->split_gemm && !(h->split_gemm_skip & 64) &&
         dev_alloc(h, &h->wino_u7s, ((size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     if (h->wino_7x7 && dev_alloc(h, &h->wino_u7, (size_t)kWino7Units * kConvs[C_T28].Co * kConvs[C_T28].Ci) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }

@@ -87,6 +87,11 @@ struct WinoGemmArgs {
   // split-fp32 form (wino_gemm_split.hip): the plane image of w (6 bytes per element at the same element offsets; wino_pack_split_launch)
   const void* w_planes = nullptr;
   long long x_bytes = 0, w_bytes = 0, y_bytes = 0;      // filled by wino_gemm_split_launch: extents of x, the plane image, y
+  // split-fp32 form as a 1x1 convolution (epilogue != 0; one problem): channels-last rows with a channel stride and offset, + bias, ReLU,
+  // the folded average pool of conv_igemm.hip (pool_part [ceil(M / 32)][2][Co], pool_hw rows per image)
+  int epilogue = 0, x_rs = 0, x_coff = 0, y_rs = 0, y_coff = 0, relu = 0, pool_hw = 0;
+  const float* bias = nullptr;
+  float* pool_part = nullptr;
 };
 bool wino_gemm_supported(const WinoGemmArgs& a);
 hipError_t wino_gemm_launch(const WinoGemmArgs& a, hipStream_t st);

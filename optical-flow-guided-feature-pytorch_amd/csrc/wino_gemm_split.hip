@@ -52,7 +52,10 @@ constexpr int GS_OOB = (int)0x80000000;     // a per-lane offset past every desc
 }  // namespace
 
 // CT = channel tiles per wave: 2 (128 channels per item), or 1 (64: the 7x7 conv's Co = 64 -- half the MFMAs per cut value and per step)
-template <int CT>
+// EPI: the epilogue of a 1x1 convolution (conv_igemm.hip's, for the launches a split-fp32 handle sends here): x rows / y rows with a
+// channel stride and offset, + bias, ReLU, and the folded average pool of a head (per 32-row slab and channel the sums over the slab's
+// rows of its first / second image)
+template <int CT, bool EPI>
 __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(WinoGemmArgs p) {
   constexpr int NT = 4 * CT;                // the wave's accumulator tiles: (row tile i / CT, channel tile i % CT)
   constexpr int GS_BN = 64 * CT;
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
   const int ngroups = p.ngroups, argM = p.M, argCo = p.Co, total_items = p.total_items;
   const int gm = p.gm;
   const int main_items = (total_items / gx / 8) * 8 * gx;      // the items of the problems that go to XCDs whole
+  const int x_rs = p.x_rs, y_rs = EPI ? p.y_rs : p.Co;      // (EPI: x_coff / y_coff are part of the descriptors' base addresses)
   const int ukstep = (argCo >> 4) * 3072;          // bytes of one K-tile of a problem's plane image
   const int grid = (int)gridDim.x;
   auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
       const int m = m0 + lrow + 32 * r2;
-      x_off[r2] = m < argM ? (m * K + lc * 4) * 4 : GS_OOB;
+      x_off[r2] = m < argM ? (m * (EPI ? x_rs : K) + lc * 4) * 4 : GS_OOB;
     }
     pu_soff = sc((int)((ow + (long long)b * argCo * K) * 6) + ((n0 >> 4) + CT * wave) * 3072);
     pu_nkt = x_nkt;
@@ -196,14 +200,60 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
   // MI355X + hipcc (ROCm 7.2): a VALU write to the FIRST data register of a buffer_store_dwordx4 in the instruction right behind it
   // reached memory in lanes 12-15 of every sixteen (run-to-run varying; hipcc places no wait state there when the store's soffset is a
   // register -- it had re-used the register for the next tile's address): each store is followed by s_nop 1, fenced.
-  const int st_voff = (li * argCo + CT * wave * 16 + 4 * lg) * 4;
+  const int st_voff = (li * y_rs + CT * wave * 16 + 4 * lg) * 4;
   auto store_item = [&]() {
-    const int ybase = c_ysoff + (c_m0 * argCo + c_n0) * 4;
+    const int ybase = c_ysoff + (c_m0 * y_rs + c_n0) * 4;
+    if (EPI) {
+      // + bias, ReLU
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + c_n0 + (CT * wave + ct) * 16 + 4 * lg);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          f32x4& a = acc[rt * CT + ct];
+          a += b4;
+          if (p.relu) a = f32x4{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)};
+        }
+      }
+      if (p.pool_part) {
+        // column sums per 32-row slab (row tiles 2 s, 2 s + 1), split at the image boundary inside the slab (an image has >= 32 rows: a
+        // slab touches at most two); fixed order: the slab's two row tiles, then the sixteen rows of a tile by xor-shuffles 1, 2, 4, 8
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const int slab = (c_m0 >> 5) + sl;
+          const int b1 = ((slab * 32) / p.pool_hw + 1) * p.pool_hw;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const int m = slab * 32 + h2 * 16 + li;
+              const f32x4 v = acc[(2 * sl + h2) * CT + ct];
+              const bool in = m < argM, first = m < b1;
+              const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+              s0 += in && first ? v : z4;
+              s1 += in && !first ? v : z4;
+            }
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { s0[e] += __shfl_xor(s0[e], d); s1[e] += __shfl_xor(s1[e], d); }
+            }
+            if (li == 0 && slab * 32 < argM) {
+              float* pp = p.pool_part + (size_t)slab * 2 * argCo + c_n0 + (CT * wave + ct) * 16 + 4 * lg;
+              *reinterpret_cast<f32x4*>(pp) = s0;
+              *reinterpret_cast<f32x4*>(pp + argCo) = s1;
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int rt = i / CT;
       const int voff = li < argM - c_m0 - rt * 16 ? st_voff : GS_OOB;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, ybase + (rt * 16 * argCo + (i % CT) * 16) * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), yrs, voff, ybase + (rt * 16 * y_rs + (i % CT) * 16) * 4, 0);
       OFFK_SB;
       asm volatile("s_nop 1");
       OFFK_SB;
@@ -364,12 +414,27 @@ hipError_t wino_gemm_split_launch(const WinoGemmArgs& a_in, hipStream_t st) {
   const bool wide = a.Co % 128 == 0;         // 128 channels per item where Co allows it
   a.gn = a.Co / (wide ? 128 : 64);
   a.total_items = (int)(problems * a.gm * a.gn);
-  hipError_t e = lds_attr_once(wide ? reinterpret_cast<const void*>(wino_gemm_split_kernel<2>) : reinterpret_cast<const void*>(wino_gemm_split_kernel<1>), GS_LDS);
+  const bool epi = a.epilogue != 0;
+  if (epi) {
+    // one problem; the rows of x / y are x_rs / y_rs floats apart and start x_coff / y_coff floats into them
+    if (problems != 1 || a.x_rs < a.g_K[0] || a.y_rs < a.Co || ((a.x_rs | a.y_rs | a.x_coff | a.y_coff) & 3) || a.x_coff < 0 || a.y_coff < 0 ||
+        (a.pool_part && a.pool_hw < 32))
+      return hipErrorInvalidValue;
+    a.x += a.x_coff; a.y += a.y_coff;
+    a.x_bytes = ((long long)(a.M - 1) * a.x_rs + a.g_K[0]) * 4;
+    a.y_bytes = ((long long)(a.M - 1) * a.y_rs + a.Co) * 4;
+    if (a.x_bytes >= 0x7fffff00ll || a.y_bytes >= 0x7fffff00ll) return hipErrorInvalidValue;
+  }
+  const void* fn = wide ? (epi ? reinterpret_cast<const void*>(wino_gemm_split_kernel<2, true>) : reinterpret_cast<const void*>(wino_gemm_split_kernel<2, false>))
+                        : (epi ? reinterpret_cast<const void*>(wino_gemm_split_kernel<1, true>) : reinterpret_cast<const void*>(wino_gemm_split_kernel<1, false>));
+  hipError_t e = lds_attr_once(fn, GS_LDS);
   if (e != hipSuccess) return e;
   const int resident = wide ? GS_RESIDENT : GS_RESIDENT_CT1;
   const int grid = a.total_items < resident ? a.total_items : resident;
-  if (wide) hipLaunchKernelGGL(wino_gemm_split_kernel<2>, dim3(grid), dim3(256), GS_LDS, st, a);
-  else hipLaunchKernelGGL(wino_gemm_split_kernel<1>, dim3(grid), dim3(256), GS_LDS, st, a);
+  if (wide && epi) hipLaunchKernelGGL((wino_gemm_split_kernel<2, true>), dim3(grid), dim3(256), GS_LDS, st, a);
+  else if (wide) hipLaunchKernelGGL((wino_gemm_split_kernel<2, false>), dim3(grid), dim3(256), GS_LDS, st, a);
+  else if (epi) hipLaunchKernelGGL((wino_gemm_split_kernel<1, true>), dim3(grid), dim3(256), GS_LDS, st, a);
+  else hipLaunchKernelGGL((wino_gemm_split_kernel<1, false>), dim3(grid), dim3(256), GS_LDS, st, a);
   return hipGetLastError();
 }
 
