@@ -23,8 +23,9 @@ What the line's `value` is: the library's fp32 mode (v_mfma_f32_* : fp32 product
 arithmetic type; the k x k fusion convs run in Winograd forms, i.e. a different fp32 summation, measured ~1e-5 of max|ref|
 against the reference-pinned oracle) at the full --steps.  The split-fp32 mode of the same library (OFFK_PRECISION_F32SPLIT:
 every fp32 operand as three bf16 planes = the fp32 value exactly, six exact plane products on the bf16 matrix pipe, fp32
-accumulation -- so far the units kernel, 36 % of the step) is timed beside it as the named secondary object `f32split_mode`,
-with `error_vs_fp64` for BOTH modes (the split mode's error against fp64 is the smaller one on every input kind).
+accumulation -- the units kernel, the batched GEMMs of every conv on a Winograd path and the 1x1 convs on 7x7 maps: `split_launches`)
+is timed beside it as the named secondary object `f32split_mode`, with `error_vs_fp64` / `gemm_error_vs_fp64` for BOTH modes (the
+split mode's error against fp64 is the smaller one on every input kind).
 """
 import argparse
 import contextlib
@@ -323,7 +324,7 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
     unit_f, _fus = spec.flops_per_clip(L)
     hw = sum(H * H for _n, _c, H in spec.SITES)
     dw_f = 2.0 * P * hw * spec.DOWN_CH * 9
-    peak = MFMA_F32_PEAK_TFLOPS          # (f32split: every kernel but the units kernel runs the fp32 pipe)
+    peak = MFMA_F32_PEAK_TFLOPS          # (f32split: the launches on the bf16 pipe are priced there in f32split_mode.split_launches)
     kernels, small_ms, small_fl = [], 0.0, 0.0
     big = ("motion_conv_trans_28", "motion_conv_trans_14", "motion_conv_trans")
     for name, (ms, calls) in lt.items():
@@ -536,6 +537,36 @@ def split_error_vs_fp64(L, variant, weights, dev, kinds=("synth", "full_mantissa
                     n += e.numel()
             table.setdefault(prec, {})[kind] = {"max_over_max": mx, "rms_over_max": (se / n) ** 0.5, "c_max": cmx, "c_rms": (sc / n) ** 0.5}
             del h
+    return table
+
+
+def split_gemm_error_vs_fp64(dev, batch=6, M=384, K=832, Co=256):
+    """Both forms of the batched GEMMs of the Winograd convs (offk_batched_gemm_nt: wino_gemm.hip on the fp32 pipe, wino_gemm_split.hip
+    in split-fp32) against an fp64 contraction of the same fp32 inputs, at the shape of motion_conv_trans's GEMMs (K = 832, Co = 256,
+    384 rows per point): the four numbers of split_error_vs_fp64 per mode and input kind.  Asserted in tests/test_gpu_split.py."""
+    eps = 2.0 ** -24
+    table = {}
+    for kind in ("relu", "normal", "heavy_tail", "cancellation"):
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(batch, M, K, generator=g)
+        w = torch.randn(batch, Co, K, generator=g) * (1.0 / K ** 0.5)
+        if kind == "relu":
+            x = torch.relu(x)
+        elif kind == "heavy_tail":
+            x = x * torch.exp(2.0 * torch.randn(batch, M, 1, generator=g))
+        elif kind == "cancellation":
+            w = w - w.mean(dim=2, keepdim=True)
+            x = 3.0 + torch.randn(batch, M, 1, generator=g) + torch.randn(batch, M, K, generator=g) * 2.0 ** -12
+        x, w = x.float().contiguous(), w.float().contiguous()
+        ref = torch.einsum("bmk,bnk->bmn", x.double(), w.double())
+        mag = torch.einsum("bmk,bnk->bmn", x.double().abs(), w.double().abs())
+        for prec in ("fp32", "f32split"):
+            y = runtime.batched_gemm_nt(x.to(dev), w.to(dev), prec).double().cpu()
+            e = (y - ref).abs()
+            c = e / (mag.clamp_min(1e-30) * eps)
+            sN = ref.abs().max()
+            table.setdefault(prec, {})[kind] = {"max_over_max": (e.max() / sN).item(), "rms_over_max": ((e / sN) ** 2).mean().sqrt().item(),
+                                                "c_max": c.max().item(), "c_rms": (c ** 2).mean().sqrt().item()}
     return table
 
 
@@ -948,11 +979,32 @@ def main():
                    "stage_ms": dict((k, v[0] / max(v[1], 1)) for k, v in st2.items())}
             ip2 = roofline_in_path(_h2, _h2._feat_array(feats), out, B, L, other, min(args.steps, 20))
             sec["units_kernel"] = next((k for k in ip2["kernels"] if k["launch"].startswith("units:pw_tdiff")), None)
+            if other == "f32split" and in_path is not None:
+                # every launch that runs in split-fp32 arithmetic in that mode (the units kernel, the batched GEMMs of every conv on a
+                # Winograd path, the 1x1 convs on 7x7 maps), with the same launch's time in the fp32 mode beside it
+                fp32_ms = dict((k["launch"], k["avg_ms"]) for k in in_path["kernels"])
+                rows = []
+                for k in ip2["kernels"]:
+                    nm = k["launch"]
+                    if not (nm.startswith("units:pw_tdiff") or "GEMMs]" in nm or nm in ("merged_14a", "merged_7", "motion_conv1_trans_14b")):
+                        continue
+                    if "flops" not in k:
+                        continue
+                    rows.append({"launch": nm, "avg_ms": k["avg_ms"], "fp32_mode_avg_ms": fp32_ms.get(nm), "flops_fp32_equivalent": k["flops"],
+                                 "fp32_equivalent_tflops": k["flops"] / k["avg_ms"] / 1e9,
+                                 "frac_of_bf16_peak": 6.0 * k["flops"] / k["avg_ms"] / 1e9 / BF16_DENSE_PEAK_TFLOPS,
+                                 "fp32_equivalent_over_fp32_pipe_peak": k["flops"] / k["avg_ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS})
+                sec["split_launches"] = {"kernels": rows, "sum_ms": sum(r["avg_ms"] for r in rows),
+                                         "sum_ms_fp32_mode": sum(r["fp32_mode_avg_ms"] or 0.0 for r in rows),
+                                         "note": "frac_of_bf16_peak = six bf16 plane products per fp32 product / 2.5 PF dense bf16; "
+                                                 "everything else in the forward (transforms, bottleneck chains, what sits between two "
+                                                 "Winograd convs, heads) is the same code in both modes"}
             del _h2
             sp = sec if other == "f32split" else res
             sp["error_vs_fp64"] = split_error_vs_fp64(L, variant, weights, dev)
+            sp["gemm_error_vs_fp64"] = split_gemm_error_vs_fp64(dev)
             sp["max_rel_diff_vs_fp32_mode"] = split_vs_fp32_forward(B, L, variant, weights, dev)
-            sp["error_note"] = ("error_vs_fp64: the units kernel (the kernel with a split form) in BOTH modes against an fp64 contraction of "
+            sp["error_note"] = ("error_vs_fp64 / gemm_error_vs_fp64: the units kernel / the batched GEMMs of a Winograd conv in BOTH modes against an fp64 contraction of "
                                 "the same fp32 inputs -- the split mode's error is the smaller one on every input kind (asserted in "
                                 "tests/test_gpu_split.py): the operands are represented exactly, the products are exact, the running sum is "
                                 "rounded once per 32 k where the fp32 pipe's FMA chain rounds it eight times.  max_rel_diff_vs_fp32_mode: "
