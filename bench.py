@@ -655,7 +655,8 @@ def rccl_smoke_object(B, L, variant, weights, feats, dev, steps):
     rec = {"what": "single-rank RCCL smoke, not a scaling number", "world_size": 1}
     try:
         if not dist.is_initialized():
-            init_single_rank_rccl(dev)
+            with stdout_to_stderr():      # (device_id = eager communicator: RCCL's banner comes with the init)
+                init_single_rank_rccl(dev)
         rec["backend"] = dist.get_backend()
         h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, True, device=dev, precision="fp32")
         h.load_state_dict(weights)
