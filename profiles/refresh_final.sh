@@ -16,4 +16,5 @@ echo "split stats done"
 bash profiles/collect_pmc.sh $TAG/pmc || exit 1
 bash profiles/collect_pmc.sh $TAG/pmc_f32split --precision f32split || exit 1
 timeout -k 10 300 python tools/bench_small.py 1,7 8,7 16,7 42,7 55,7 128,7 10,25 --fp32 > $OUT/batch_table.txt 2>&1 || exit 1
+timeout -k 10 300 python tools/bench_small.py 1,7 8,7 16,7 42,7 55,7 128,7 10,25 --f32split > $OUT/batch_table_f32split.txt 2>&1 || exit 1
 echo "table done"

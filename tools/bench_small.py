@@ -11,9 +11,9 @@ import torch  # noqa: E402
 import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec, synth  # noqa: E402
 
-# usage: bench_small.py [B,L ...] [--fp32]   (default: the three shapes below, both arithmetic modes)
+# usage: bench_small.py [B,L ...] [--fp32 | --f32split]   (default: the three shapes below, both arithmetic modes)
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if "," in a] or [(1, 7), (4, 7), (10, 25)]
-precs = ("fp32",) if "--fp32" in sys.argv else ("fp32", "bf16x3")
+precs = ("fp32",) if "--fp32" in sys.argv else ("f32split",) if "--f32split" in sys.argv else ("fp32", "f32split")
 for B, L in shapes:
     for prec in precs:
         h = runtime.OffForward(B, L, spec.VARIANT_RGB, precision=prec)
