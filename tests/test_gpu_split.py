@@ -207,3 +207,25 @@ def test_batched_gemm_split_error_is_no_larger_than_the_fp32_pipes(rt, kind):
               % (prec, kind, stats[prec]["max_over_max"], stats[prec]["rms_over_max"], stats[prec]["c_max"], stats[prec]["c_rms"]))
     for key in ("max_over_max", "rms_over_max", "c_max", "c_rms"):
         assert stats["f32split"][key] <= stats["fp32"][key], (kind, key, stats)
+
+
+@pytest.mark.parametrize("B", [2, 12])
+def test_forward_split_gemms_against_fp32_pipe_gemms(rt, monkeypatch, B):
+    """A split-fp32 handle with its GEMMs / 1x1 convs on the bf16 pipe (default) against the same handle with OFFK_SPLIT_GEMM=0 (only the
+    units kernel split): same logits and stage tensors to summation-order noise (the convs' own Winograd error is 1e-5 of max |ref|), and
+    the 7-head's folded pool of the split kernel's epilogue gives the same logits."""
+    L = 7
+    feats = [dev(f) for f in synth.make_features(B, L, 3)]
+    h1, _ = make_handle(rt, B, L, "f32split")
+    monkeypatch.setenv("OFFK_SPLIT_GEMM", "0")
+    h0, _ = make_handle(rt, B, L, "f32split")
+    monkeypatch.delenv("OFFK_SPLIT_GEMM")
+    a, b = h1.forward(feats), h0.forward(feats)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert ((x - y).abs().max() / y.abs().max()).item() < 2e-5
+        sig = (y - y.mean(dim=0, keepdim=True)).abs().max().item()        # the logits are bias-dominated: compare on the row-to-row signal
+        assert (x - y).abs().max().item() < 1e-3 * sig
+    for name, ch in (("sum_7", 1024), ("fusion_7", 832)):
+        x, y = h1.region(name, ch), h0.region(name, ch)
+        assert ((x - y).abs().max() / y.abs().max()).item() < 5e-5, name
