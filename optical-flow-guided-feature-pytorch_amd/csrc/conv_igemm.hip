@@ -59,7 +59,8 @@ struct ConvArgs {
 #endif
 };
 
-// PREC 0 / 2 / 4: exact fp32 MFMA core.  PREC 1 / 3: bf16x3 core (see offk_common.h; 3 = behind the PREC 2 loader).
+// PREC 0 / 2 / 4: three loaders in front of the fp32 MFMA core (PREC 1 / 3 were the two-plane bf16x3 core of rounds 1 - 4, retired with that
+// mode in round 5: a 512-thread producer / consumer form of this kernel -- git history).
 // PREC 2 is PREC 0 with a LEAN K loop (round 2).  On gfx950 the fp32 MFMA shares the SIMD's fp32 lanes with the vector ALU:
 // tools/mfma_f32_probe.hip shows every VALU instruction in the loop coming straight out of the matrix throughput, at any
 // occupancy (92 % with none, 76 % with 32 extra per 16 MFMAs, 63 % with 64).  The PREC 0 loop spends ~12 VALU instructions
@@ -76,18 +77,12 @@ struct ConvArgs {
 // the row's 16-byte chunk slot ^ ((row >> 1) & 7) -- the swizzle goes into each lane's SOURCE offset -- and the
 // ds_read_b128 of 16 consecutive rows stays conflict-free.  No ReLU-on-load (the data never passes a register): convs
 // with OFFK_CONV_RELU_IN use PREC 2.
-// Threads: fp32 = 256 (4 waves, every wave loads and multiplies).  bf16x3 = 512: waves 0-3 are
-// CONSUMERS (ds_read + MFMA only), waves 4-7 are PRODUCERS (global loads two K-tiles ahead, the
-// fp32 -> bf16 hi/lo split and the LDS stores).  Each SIMD then holds one wave of each kind, so the
-// split's VALU work and the LDS stores run beside the other wave's MFMAs instead of in front of
-// them (measured before the split: 39 % matrix-pipe busy with 20 % VALU and 26 % LDS time serialised
-// in the same waves).  One s_barrier per K-tile hands a filled LDS stage over.
+// Threads: 256 (4 waves, every wave loads and multiplies).
 constexpr int kDmaStages = 2;   // 3 (tiles two ahead, 48 KB for the 64x64 tile = 3 blocks per CU) measured 2 % slower than 2
 template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
-// second launch-bound = waves per SIMD (HIP), 4 = two 8-wave blocks per CU: keeps the bf16x3 tiles within 128 VGPRs
-// (the 128x128 tile compiled to 131 and ran one block per CU)
-__global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
-  constexpr bool F32 = !(PREC & 1), LEAN = PREC >= 2;      // PREC 3: the bf16x3 core with the same buffer-addressed loader
+__global__ __launch_bounds__(256, 1) void conv_igemm_kernel(ConvArgs p) {
+  static_assert(PREC == 0 || PREC == 2 || PREC == 4, "fp32 core only");
+  constexpr bool LEAN = PREC >= 2;
 #ifdef OFFK_CONV_TIMING
   const unsigned long long tm_t0 = __builtin_readcyclecounter();
   unsigned long long tm_t1 = 0, tm_t2 = 0, tm_ta = 0;
@@ -245,9 +240,8 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   };
   constexpr int NRG = NRA * VA + NRB * VB;
   // prefetch registers: A rows then B rows (one array per set: separate A / B arrays end up in scratch).
-  // rg0 is the only set of the fp32 path; the bf16x3 producers alternate rg0 / rg1 (loads two tiles ahead).
-  float4 rg0[NRG], rg1[F32 ? 1 : NRG];
-  unsigned okm0 = 0, okm1 = 0;   // bit r: activation row r of the set is inside the image (else it reads as zero)
+  float4 rg0[NRG];
+  unsigned okm0 = 0;   // bit r: activation row r of the set is inside the image (else it reads as zero)
   // Loads are branch-free and nothing touches the loaded values here: a padding tap reads pixel 0 through a
   // selected pointer and is zeroed by store_tile, ReLU-on-load is applied there as well.  With
   // `t = 0; if (ok) t = load; rg = relu_in ? relu(t) : t` every load was followed by s_waitcnt vmcnt(0): the
@@ -298,13 +292,6 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       rg[NRA * VA + r] = *reinterpret_cast<const float4*>(wbase + (size_t)32 * r * K + kt * BK);
     }
   };
-  // bf16x3 LDS image per stage: A_hi [BM] | A_lo [BM] | B_hi [BN] | B_lo [BN], rows of 64 B (32 bf16), the
-  // 16-B chunk c of row r stored at chunk c ^ ((r >> 2) & 3): conflict-free for the 16-B stores (8
-  // consecutive lanes = 2 whole rows = one 128-B bank row) and for the ds_read_b128 operand reads (the 16
-  // lanes of a read group hit 16 distinct 16-B slots of the 256-B bank row).
-  constexpr int B3R = 64;
-  constexpr int A_PLANE = BM * B3R, B_PLANE = BN * B3R, B3_STAGE = 2 * (A_PLANE + B_PLANE);
-  char* smem_c = reinterpret_cast<char*>(smem);
   auto a_value = [&](const float4 (&rg)[NRG], unsigned okm, int r) {
     float4 t = rg[r];
     if (!LEAN && !((okm >> r) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -319,7 +306,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
 #ifdef OFFK_TUNING_KNOBS
     if (p.ablate & 4) return;
 #endif
-    if (F32) {
+    {
       float* As = As0 + stage * BM * LDS_K;
 #pragma unroll
       for (int r = 0; r < NRA; ++r)
@@ -328,53 +315,6 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
 #pragma unroll
       for (int r = 0; r < NRB; ++r)
         *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[NRA + r];
-    } else {
-      char* st = smem_c + stage * B3_STAGE;
-      const int c8 = tid & 7;
-#pragma unroll
-      for (int r = 0; r < NRA; ++r) {
-        const int row = (tid >> 3) + 32 * r;
-        uint2 h, l;
-        split4(a_value(rg, okm, r), h, l);
-        char* q = st + row * B3R + ((((c8 >> 1) ^ ((row >> 2) & 3)) << 4) | ((c8 & 1) << 3));
-        *reinterpret_cast<uint2*>(q) = h;
-        *reinterpret_cast<uint2*>(q + A_PLANE) = l;
-      }
-#pragma unroll
-      for (int r = 0; r < NRB; ++r) {
-        const int row = (tid >> 3) + 32 * r;
-        char* q = st + 2 * A_PLANE + (c8 >> 2) * B_PLANE + row * B3R + (((c8 & 3) ^ ((row >> 2) & 3)) << 4);
-        *reinterpret_cast<float4*>(q) = rg[NRA * VA + r];
-      }
-    }
-  };
-  auto mma_b3 = [&](f32x16 (&acc)[TM][TN], int stage) {
-    const char* Ahi = smem_c + stage * B3_STAGE + wm * (32 * TM) * B3R;
-    const char* Bhi = smem_c + stage * B3_STAGE + 2 * A_PLANE + wn * (32 * TN) * B3R;
-    const int r = lane & 31, hh = lane >> 5;
-    const int base = r * B3R + ((hh ^ ((r >> 2) & 3)) << 4);    // chunk (2s + h) ^ swz == ((h ^ swz) ^ 2s)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int off = base ^ (s2 << 5);
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        ah[t] = *reinterpret_cast<const bf16x8*>(Ahi + t * 32 * B3R + off);
-        al[t] = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + t * 32 * B3R + off);
-      }
-#pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        bh[t] = *reinterpret_cast<const bf16x8*>(Bhi + t * 32 * B3R + off);
-        bl[t] = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + t * 32 * B3R + off);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-        }
     }
   };
 
@@ -481,7 +421,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
 #ifdef OFFK_CONV_TIMING
     tm_t2 = __builtin_readcyclecounter();
 #endif
-  } else if constexpr (F32) {
+  } else {
     load_tile(rg0, okm0, kt_begin);
     store_tile(rg0, okm0, 0);
     __syncthreads();
@@ -513,61 +453,6 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
       step(kt + 1, 1);
     }
     if (kt < kt_end) step(kt, 0);
-  } else {
-    if (wave >= 4) {
-      // ---- producers: tile t is stored one step before it is consumed and loaded two steps before that
-      load_tile(rg0, okm0, kt_begin);
-      store_tile(rg0, okm0, 0);
-      // unconditional loads / stores with a clamped tile index (see the fp32 loop): no phi copies of in-flight loads
-      // LEAN: unconditional loads / stores with a clamped tile index (see the fp32 loop)
-      auto prefetch = [&](float4 (&rg)[NRG], unsigned& okm, int t) {
-        if constexpr (LEAN) load_tile(rg, okm, min(t, kt_end - 1));
-        else if (t < kt_end) load_tile(rg, okm, t);
-      };
-      prefetch(rg0, okm0, kt_begin + 1);
-      prefetch(rg1, okm1, kt_begin + 2);
-      __syncthreads();
-      int kt = kt_begin;
-#ifdef OFFK_CONV_TIMING
-      unsigned long long t_st = 0, t_ld = 0, t_pb = 0;
-#define OFFK_T(var, stmt) { const unsigned long long q0 = __builtin_readcyclecounter(); stmt; var += __builtin_readcyclecounter() - q0; }
-#else
-#define OFFK_T(var, stmt) stmt;
-#endif
-      for (; kt + 1 < kt_end; kt += 2) {
-        OFFK_T(t_st, store_tile(rg0, okm0, 1))                 // tile kt+1 while tile kt is multiplied
-        OFFK_T(t_ld, prefetch(rg0, okm0, kt + 3))
-        OFFK_T(t_pb, __syncthreads())
-        OFFK_T(t_st, if (LEAN || kt + 2 < kt_end) store_tile(rg1, okm1, 0))   // tile kt+2 while tile kt+1 is multiplied
-        OFFK_T(t_ld, prefetch(rg1, okm1, kt + 4))
-        OFFK_T(t_pb, __syncthreads())
-      }
-#undef OFFK_T
-      if (kt < kt_end) __syncthreads();
-#ifdef OFFK_CONV_TIMING
-      if (p.dbg && threadIdx.x == 256) { atomicAdd(p.dbg + 3, t_st); atomicAdd(p.dbg + 4, t_ld); atomicAdd(p.dbg + 5, t_pb); }
-#endif
-      return;
-    }
-    // ---- consumers
-    __syncthreads();
-#ifdef OFFK_CONV_TIMING
-    unsigned long long t_mma = 0, t_bar = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const unsigned long long a0 = __builtin_readcyclecounter();
-      mma_b3(acc.acc, (kt - kt_begin) & 1);
-      const unsigned long long a1 = __builtin_readcyclecounter();
-      __syncthreads();
-      const unsigned long long a2 = __builtin_readcyclecounter();
-      t_mma += a1 - a0; t_bar += a2 - a1;
-    }
-    if (p.dbg && threadIdx.x == 0) { atomicAdd(p.dbg + 0, t_mma); atomicAdd(p.dbg + 1, t_bar); atomicAdd(p.dbg + 2, (unsigned long long)(kt_end - kt_begin)); }
-#else
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      mma_b3(acc.acc, (kt - kt_begin) & 1);
-      __syncthreads();
-    }
-#endif
   }
 
   const int r32 = lane & 31, h = lane >> 5;
@@ -604,7 +489,7 @@ __global__ __launch_bounds__((PREC & 1) ? 512 : 256, ((PREC & 1) && TM * TN <= 4
   // accumulator tile plus a scalar per register, no compare / exec mask / 64-bit address per store (the pointer form spent ~11 k cycles
   // issuing a block's 16 stores per wave, with every co-resident block in its epilogue at the same time: tools/conv_dma_timing.py)
   const unsigned long long ybytes = ((unsigned long long)(p.M > 0 ? p.M - 1 : 0) * p.y_cs + p.y_coff + p.co_limit) * 4ull;
-  const bool fast_store = LEAN && F32 && !p.res && !p.pool_part && p.M > 0 && ybytes < 0x7f000000ull;
+  const bool fast_store = LEAN && !p.res && !p.pool_part && p.M > 0 && ybytes < 0x7f000000ull;
   if (fast_store) {
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
     const int ycs4 = p.y_cs * 4;
@@ -726,10 +611,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// "Patch" variant of the bf16x3 kernel (tile_cfg 6: 128 output channels per block, 7: 64) for the k x k convs.
+// "Patch" variant of the kernel (tile_cfg 6: 128 output channels per block, 7: 64) for the k x k convs (first built for the bf16x3 core).
 // Every k x k conv of the fusion stages produces 196 output pixels per image (14x14) or per four images (7x7), from
 // 784 or 196 input pixels.  A block owns one such 196-pixel output group (seven 32-row MFMA tiles) and, per 32-channel
-// chunk, keeps the WHOLE input patch of the group in LDS (split into bf16 hi / lo once): the KH*KW taps then read
+// chunk, keeps the WHOLE input patch of the group in LDS: the KH*KW taps then read
 // their A operand straight from that patch at shifted pixel slots, so an input value crosses L2 -> LDS once per chunk
 // instead of once per tap, and only the weight tile of the (chunk, tap) streams through the two-stage LDS ring.
 // Operand traffic per FLOP drops ~4x against the 128x128 im2col tile; the generic kernel was bound by exactly that
@@ -742,23 +627,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
 // Waves 0-3 multiply (wave = one 32-column tile x all seven row tiles for 128 channels; column tile x alternate row
 // tiles for 64), waves 4-7 stream the weight tiles two steps ahead and hold the next chunk's patch in registers.
 // ---------------------------------------------------------------------------------------------------
-// PREC 1 = bf16x3 (hi / lo bf16 planes, rows of 64 B).  PREC 0 = exact fp32 (v_mfma_f32_32x32x2_f32): ONE plane of fp32
-// rows of 128 B -- the same LDS bytes -- whose 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7): a
+// fp32 (v_mfma_f32_32x32x2_f32): ONE plane of fp32 rows of 128 B whose 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7): a
 // ds_read_b128 lane group (16 consecutive rows, same chunk) then covers all 16 slots of the 256-byte bank row.  The fp32
 // form exists because the generic fp32 kernel re-fetches every input value once per tap from L2: its load / LDS-store
 // pipeline alone took as long as the MFMAs (tools/conv_ablate.py: 0.93 ms of staging beside 0.96 ms of MFMAs on the 7x7),
 // so the matrix pipe sat at 68-70 %; with the patch in LDS the fp32 consumers are purely MFMA-bound.
 template <int KH, int S, int W, int NT, int PREC>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
+  static_assert(PREC == 0, "fp32 only (PREC 1 was the two-plane bf16x3 form, retired in round 5)");
   constexpr int KW = KH, TAPS = KH * KW, PAD = KH / 2, H = W, HW = H * W;
   constexpr int WO = (W + 2 * PAD - KW) / S + 1, HOWO = WO * WO, IMG = 196 / HOWO, NP = IMG * HW;
   static_assert(196 % HOWO == 0 && (S == 1 || (W % 2) == 0), "196-pixel output groups only");
-  constexpr int BN = 32 * NT, RT = NT == 4 ? 7 : 4, B3R = PREC == 0 ? 128 : 64;
-  constexpr int PATCH_PLANE = ((NP + 1) * B3R + 127) / 128 * 128, B_PLANE = BN * B3R, B_STAGE = PREC == 0 ? B_PLANE : 2 * B_PLANE;
+  constexpr int BN = 32 * NT, RT = NT == 4 ? 7 : 4, B3R = 128;
+  constexpr int PATCH_PLANE = ((NP + 1) * B3R + 127) / 128 * 128, B_PLANE = BN * B3R, B_STAGE = B_PLANE;
   constexpr int NJ = (NP + 31) / 32;   // patch pixels per producer thread
   extern __shared__ __attribute__((aligned(16))) char lds_c[];
-  char* const patch = lds_c;                        // bf16x3: hi plane, then lo plane; fp32: one plane
-  char* const bst = lds_c + (PREC == 0 ? 1 : 2) * PATCH_PLANE;   // two stages of (B_hi | B_lo) / of B
+  char* const patch = lds_c;
+  char* const bst = lds_c + PATCH_PLANE;            // two stages of B
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tid = threadIdx.x & 255;
@@ -806,15 +691,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
           const int img = pp / HW, rem = pp - img * HW, y = rem / W, x = rem - y * W;
           const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
           const int slot = img * HW + y * W + xp;
-          if constexpr (PREC == 0) {
-            *reinterpret_cast<float4*>(patch + slot * B3R + ((c8 ^ ((slot >> 1) & 7)) << 4)) = t;
-          } else {
-            uint2 hh, ll;
-            split4(t, hh, ll);
-            char* q = patch + slot * B3R + ((((c8 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c8 & 1) << 3));
-            *reinterpret_cast<uint2*>(q) = hh;
-            *reinterpret_cast<uint2*>(q + PATCH_PLANE) = ll;
-          }
+          *reinterpret_cast<float4*>(patch + slot * B3R + ((c8 ^ ((slot >> 1) & 7)) << 4)) = t;
         }
       }
     };
@@ -828,19 +705,11 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
         const int row = (tid >> 3) + 32 * r;
-        if constexpr (PREC == 0)
-          *reinterpret_cast<float4*>(bst + stage * B_STAGE + row * B3R + ((c8 ^ ((row >> 1) & 7)) << 4)) = rgP[set + r];
-        else
-          *reinterpret_cast<float4*>(bst + stage * B_STAGE + (c8 >> 2) * B_PLANE + row * B3R + (((c8 & 3) ^ ((row >> 2) & 3)) << 4)) = rgP[set + r];
+        *reinterpret_cast<float4*>(bst + stage * B_STAGE + row * B3R + ((c8 ^ ((row >> 1) & 7)) << 4)) = rgP[set + r];
       }
     };
     if (tid < 8) {   // the zero pixel
-      if constexpr (PREC == 0) {
-        *reinterpret_cast<float4*>(patch + NP * B3R + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        *reinterpret_cast<uint2*>(patch + NP * B3R + tid * 8) = make_uint2(0u, 0u);
-        *reinterpret_cast<uint2*>(patch + PATCH_PLANE + NP * B3R + tid * 8) = make_uint2(0u, 0u);
-      }
+      *reinterpret_cast<float4*>(patch + NP * B3R + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     load_patch(c_begin);
     load_b(B0, 0);
@@ -896,7 +765,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   const int brow = ct * 32 + r32;
-  const int bbase = PREC == 0 ? brow * B3R + ((h ^ ((brow >> 1) & 7)) << 4) : brow * B3R + ((h ^ ((r32 >> 2) & 3)) << 4);
+  const int bbase = brow * B3R + ((h ^ ((brow >> 1) & 7)) << 4);
   __syncthreads();
   int tap = 0;
   for (int g = 0; g < G; ++g) {
@@ -908,10 +777,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
       const bool inb = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
       const int xp = S == 2 ? (x & 1) * (W / 2) + (x >> 1) : x;
       const int slot = inb ? ib(i) + y * W + xp : NP;
-      aoff(i) = PREC == 0 ? slot * B3R + ((h ^ ((slot >> 1) & 7)) << 4) : slot * B3R + ((h ^ ((slot >> 2) & 3)) << 4);
+      aoff(i) = slot * B3R + ((h ^ ((slot >> 1) & 7)) << 4);
     }
-    if constexpr (PREC == 0) {
-      // fp32: chunk (2 q + h) ^ swz == ((h ^ swz) ^ 2 q): a lane reads four consecutive k of its row per visit
+    {
+      // chunk (2 q + h) ^ swz == ((h ^ swz) ^ 2 q): a lane reads four consecutive k of its row per visit
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 b = *reinterpret_cast<const float4*>(bh_p + ((bbase ^ (q << 5)) - bbase));
@@ -924,23 +793,6 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i], 0, 0, 0);
           }
-        }
-      }
-    } else
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int boff = (bbase ^ (s2 << 5)) - bbase;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bh_p + boff);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bh_p + B_PLANE + boff);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        if (NT == 4 || (wave >> 1) + 2 * i < 7) {
-          const int off = aoff(i) ^ (s2 << 5);
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(patch + off);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(patch + PATCH_PLANE + off);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
         }
       }
     }
@@ -1013,9 +865,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(ConvArgs p) {
 template <int KH, int S, int W, int NT, int PREC>
 static hipError_t launch_patch(ConvArgs a, hipStream_t st) {
   constexpr int PAD = KH / 2, WO = (W + 2 * PAD - KH) / S + 1, IMG = 196 / (WO * WO), NP = IMG * W * W, BN = 32 * NT;
-  // bf16x3: hi + lo planes of 64-byte rows; fp32: one plane of 128-byte rows -- the same bytes
-  constexpr size_t lds = PREC == 0 ? (size_t)(NP + 1) * 128 + 2 * (size_t)(BN * 128)
-                                   : 2 * (size_t)(((NP + 1) * 64 + 127) / 128 * 128) + 2 * (size_t)(2 * BN * 64);
+  constexpr size_t lds = (size_t)(NP + 1) * 128 + 2 * (size_t)(BN * 128);
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_patch_kernel<KH, S, W, NT, PREC>;
   {
@@ -1051,7 +901,7 @@ template <int KH, int KW, int S, int TM, int TN, int WM, int WN, int PREC>
 static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr size_t lds = PREC == 4 ? kDmaStages * (size_t)(BM + BN) * 128
-                                   : (!(PREC & 1) ? 2 * (size_t)(BM + BN) * LDS_K * sizeof(float) : 2 * (size_t)(BM + BN) * 2 * 64);
+                                   : 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   if (a.Co % BN) return hipErrorInvalidConfiguration;
   auto kern = conv_igemm_kernel<KH, KW, S, TM, TN, WM, WN, PREC>;
   {
@@ -1061,7 +911,7 @@ static hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
   a.gm = (a.M + BM - 1) / BM;
   a.gn = a.Co / BN;
   a.spread = (long long)a.gm * a.gn * a.splitk * a.batch >= 1024 ? 1 : 0;      // >= four blocks per CU
-  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk, a.batch), dim3(!(PREC & 1) ? 256 : 512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.gm * a.gn * a.splitk, a.batch), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.splitk == 1) return e;
   size_t n4 = (size_t)a.M * (a.Co / 4);

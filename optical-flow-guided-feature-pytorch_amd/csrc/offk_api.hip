@@ -155,9 +155,7 @@ struct offk_handle {
   std::map<std::string, int> index;
   // packed device weights
   float* pw_w[kNumSites] = {};   // [160][C]
-  float* pw_wb3[kNumSites] = {}; // (always null: the pre-split copy of the retired two-plane bf16x3 mode)
-  float* pw_wt[kNumSites] = {};  // the same matrix in MFMA-operand order for the fused units kernel (pw_pack_direct_launch)
-  float* pw_wt16[kNumSites] = {};   // ... in the operand order of its 16-pixel form (fp32)
+  float* pw_wt16[kNumSites] = {};   // the same matrix in the operand order of the fused units kernel's 16-pixel form (fp32)
   float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
   bool split_gemm = false;          // a split-fp32 handle runs the Winograd GEMMs with Co % 128 == 0 in split-fp32 too (OFFK_SPLIT_GEMM=0: fp32 pipe)
   int split_gemm_skip = 0;          // (tuning builds: OFFK_SPLIT_GEMM_SKIP, bit k = wino_u[k] stays on the fp32 pipe)
@@ -428,17 +426,9 @@ int site_weights_ready(offk_handle* h, int site, bool need_pw, bool need_dw) {
   return OFFK_OK;
 }
 
-// bf16x3: K1 reads the library's pre-split weight copies unless a contraction weight is bound in place -- then every site
-// takes fp32 weights (its bound tensors, or the library's fp32 copy) and the kernel splits them on the way into LDS
-bool pw_presplit_now(const offk_handle* h) {
-  if (true) return false;       // (pre-split weights existed for the two-plane bf16x3 mode, retired in ABI v9)
-  for (int s = 0; s < kNumSites; ++s)
-    if (h->bnd_gen_w[s] || h->bnd_down_w[s]) return false;
-  return true;
-}
-void pw_weight_ptrs(const offk_handle* h, int site, bool presplit, const float** w, const float** w_down, const float** b,
+void pw_weight_ptrs(const offk_handle* h, int site, const float** w, const float** w_down, const float** b,
                     const float** b_down) {
-  const float* own = presplit ? h->pw_wb3[site] : h->pw_w[site];
+  const float* own = h->pw_w[site];
   *w = h->bnd_gen_w[site] ? h->bnd_gen_w[site] : own;
   *w_down = h->bnd_down_w[site] ? h->bnd_down_w[site] : own + (size_t)kGenCh * kSites[site].C;
   *b = h->bnd_gen_b[site] ? h->bnd_gen_b[site] : h->pw_b[site];
@@ -448,7 +438,7 @@ void pw_weight_ptrs(const offk_handle* h, int site, bool presplit, const float**
 void fill_pw_site(const offk_handle* h, int site, const offk_feat_parts& fp, float* G, float* D, PwSite* o) {
   for (int q = 0; q < 4; ++q) { o->xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o->cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
   o->nparts = fp.n_parts;
-  pw_weight_ptrs(h, site, pw_presplit_now(h), &o->w, &o->w_down, &o->bias, &o->bias_down);
+  pw_weight_ptrs(h, site, &o->w, &o->w_down, &o->bias, &o->bias_down);
   o->G = G; o->D = D;
   o->C = kSites[site].C; o->HW = kSites[site].H * kSites[site].H; o->M = h->N * o->HW;
   o->blk_begin = 0;
@@ -541,8 +531,6 @@ int run_off_units(offk_handle* h, hipStream_t st, const offk_feat_parts feats[],
   memset(&pp, 0, sizeof(pp));
   pp.nsites = kNumSites; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
-  pp.precision = h->cfg.precision;
-  pp.presplit = pw_presplit_now(h);
   pp.zeros = h->zero_page;
   int blk = 0;
   for (int i = 0; i < kNumSites; ++i) {
@@ -571,8 +559,6 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   memset(&pt, 0, sizeof(pt));
   pt.nsites = kNumSites; pt.B = h->cfg.batch; pt.L = h->cfg.length; pt.P = h->P; pt.slice_mode = h->cfg.slice_mode;
   pt.tgroups = pt_tgroups(h->cfg.length);
-  pt.precision = h->cfg.precision;
-  pt.presplit = pw_presplit_now(h);
   pt.zeros = h->zero_page;
   // the operand-order weight image is the library's own copy: not with contraction weights bound in place
   pt.bdirect = 1;
@@ -588,8 +574,8 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
     const offk_feat_parts& fp = feats[s];
     for (int q = 0; q < 4; ++q) { o.xp[q] = q < fp.n_parts ? fp.data[q] : nullptr; o.cp[q] = q < fp.n_parts ? fp.channels[q] : 0; }
     o.nparts = fp.n_parts;
-    pw_weight_ptrs(h, s, pt.presplit, &o.w, &o.w_down, &o.bias, &o.bias_down);
-    o.wt = h->pw_wt[s];
+    pw_weight_ptrs(h, s, &o.w, &o.w_down, &o.bias, &o.bias_down);
+    o.wt = nullptr;
     o.wt16 = h->pw_wt16[s];
     o.wt16s = h->pw_wt16s[s];
     o.D = region(h, ws, (std::string("D_") + kSites[s].name).c_str());
@@ -1088,8 +1074,6 @@ int offk_pw_reduce(offk_handle* h, void* stream, int site, const float* feat, fl
   memset(&pp, 0, sizeof(pp));
   pp.nsites = 1; pp.L = h->cfg.length; pp.P = h->P; pp.slice_mode = h->cfg.slice_mode;
   pp.nhwc = h->cfg.feat_layout == OFFK_FEAT_NHWC;
-  pp.precision = h->cfg.precision;
-  pp.presplit = pw_presplit_now(h);
   pp.zeros = h->zero_page;
   TRY(finalize_pw(h, static_cast<hipStream_t>(stream)));
   fill_pw_site(h, site, whole_map(site, feat), G, D, &pp.s[0]);

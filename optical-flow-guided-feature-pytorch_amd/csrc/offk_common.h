@@ -71,42 +71,9 @@ struct WaveAcc {
   }
 };
 
-// ---------------------------------------------------------------------------------
-// "bf16x3" tile core: fp32 operands split into two bf16 halves, x = hi + lo with
-// hi = the upper 16 bits of x (truncation) and lo = bf16_rne(x - hi); the product
-// a*b is formed as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16 with
-// fp32 accumulation (the a_lo*b_lo term, <= 2^-16 relative, is dropped).  Per-operand
-// representation error <= 2^-17, so results agree with the exact-fp32 core to ~1e-5
-// relative -- two orders inside the 1e-3 parity budget -- at 3/16 of its MFMA cycles.
-// LDS image: four planes per stage (A_hi, A_lo, B_hi, B_lo), each [row][32 k] bf16; a lane's 8
-// consecutive k (16 B) are one ds_read_b128.  K1 (pw_reduce.hip) pads rows to 80 bytes (16
-// consecutive rows hit 16 distinct 16-B slots of the 256-B bank row, 80*i mod 256); K4
-// (conv_igemm.hip) uses unpadded 64-B rows with an XOR swizzle of the 16-B chunk index.
-// ---------------------------------------------------------------------------------
+// (Rounds 1 - 4: the two-plane "bf16x3" tile core lived here -- split4 / b3_store; retired with that mode in round 5.  The split-fp32
+//  kernels, pw_tdiff_split.hip and wino_gemm_split.hip, cut their operands into THREE planes themselves.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int B3_ROW = 80;   // bytes per LDS row of one plane (32 bf16 + 8 pad)
-
-// split four fp32 values (consecutive k) into packed bf16 hi / lo quads
-__device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
-  const unsigned x0 = __float_as_uint(v.x), x1 = __float_as_uint(v.y), x2 = __float_as_uint(v.z), x3 = __float_as_uint(v.w);
-  hi.x = __builtin_amdgcn_perm(x1, x0, 0x07060302);   // [x1.hi16 | x0.hi16]
-  hi.y = __builtin_amdgcn_perm(x3, x2, 0x07060302);
-  const f32x2 ra = {v.x - __uint_as_float(x0 & 0xffff0000u), v.y - __uint_as_float(x1 & 0xffff0000u)};
-  const f32x2 rb = {v.z - __uint_as_float(x2 & 0xffff0000u), v.w - __uint_as_float(x3 & 0xffff0000u)};
-  const bf16x2 la = __builtin_convertvector(ra, bf16x2), lb = __builtin_convertvector(rb, bf16x2);
-  lo.x = __builtin_bit_cast(unsigned, la);
-  lo.y = __builtin_bit_cast(unsigned, lb);
-}
-// store one split quad of row `row` at k offset 4*kq into the hi / lo planes starting at `hi_plane`
-__device__ __forceinline__ void b3_store(char* hi_plane, int plane_bytes, int row, int kq, float4 v) {
-  uint2 h, l;
-  split4(v, h, l);
-  char* p = hi_plane + row * B3_ROW + kq * 8;
-  *reinterpret_cast<uint2*>(p) = h;
-  *reinterpret_cast<uint2*>(p + plane_bytes) = l;
-}
 
 // XCD-aware tile order inside one group of n blocks that start at any block id: blocks are dealt round-robin over the
 // 8 XCDs (private 4 MiB L2 each), so blocks j, j+8, j+16 ... of the group share an XCD; they get a CONTIGUOUS range

@@ -142,8 +142,6 @@ struct PwParams {
   PwSite s[kNumSites];
   int nsites, total_blocks;
   int L, P, slice_mode, nhwc;
-  int precision;       // 0 = exact fp32 MFMA, 1 = bf16x3
-  int presplit;        // bf16x3: w is already in the split format
   const float* zeros;  // >= 16 bytes of zeros in device memory: what a masked-out load reads
 #ifdef OFFK_TUNING_KNOBS
   int ablate;          // tools only (OFFK_PW_ABLATE): 1 no feature-map loads, 2 no weight loads, 4 no LDS stores, 8 no MFMAs
@@ -159,8 +157,8 @@ struct PtSite {
   int nparts;
   const float* w;       // gen rows [128][C] fp32, or pre-split for bf16x3 (as PwSite)
   const float* w_down;  // down rows [32][C]
-  const float* wt;      // PtParams.bdirect: all 160 rows packed in MFMA-operand order (pw_pack_direct_launch), read straight into registers
-  const float* wt16;    // the same rows in the operand order of the 16-pixel form (pw_pack_direct16_launch)
+  const float* wt;      // (kernel-local: the image the kernel reads -- wt16 or wt16s)
+  const float* wt16;    // PtParams.bdirect: all 160 rows in the operand order of the 16-pixel form (pw_pack_direct16_launch), read straight into registers
   const void* wt16s;    // PtParams.f32split: the rows as three bf16 planes in the operand order of pw_tdiff_split_kernel (pw_pack_split16_launch)
   const float* bias;    // [128]
   const float* bias_down;   // [32]
@@ -184,11 +182,10 @@ struct PtParams {
   PtSite s[kNumSites];
   int nsites, total_blocks;
   int B, L, P, slice_mode, tgroups;
-  int precision, presplit;
-  int f32split;              // precision 0 with bdirect: the split-fp32 form (pw_tdiff_split.hip) instead of pw_tdiff16_kernel
+  int f32split;              // with bdirect: the split-fp32 form (pw_tdiff_split.hip) instead of pw_tdiff16_kernel
   int split_pc;              // builds with -DOFFK_WITH_PC only (tools/experiments/pw_tdiff_pc.hip): 2 = the producer / consumer form (OFFK_SPLIT_PC=2)
-  int bdirect;               // every site carries wt / wt16: the weight operand bypasses LDS.  Exact fp32 then runs the 16-pixel LDS-DMA
-                             // form (pw_tdiff16_kernel), bf16x3 the register-staged kernel with two LDS stages for the feature-map tile
+  int bdirect;               // every site carries wt16 (/ wt16s): the weight operand bypasses LDS -- the 16-pixel forms (pw_tdiff16_kernel,
+                             // pw_tdiff_split_kernel); 0 (weights bound in the caller's tensors): the fallback pw_tdiff_kernel
   const float* zeros;
 #ifdef OFFK_PT_TIMING
   unsigned long long* dbg;   // cycle-counter sums (tools only)
@@ -196,8 +193,7 @@ struct PtParams {
 };
 int pt_tgroups(int L);
 hipError_t pw_tdiff_launch(const PtParams& p, hipStream_t st);
-// w160: [160][C] fp32 (gen rows, then down rows) -> out (160 * C floats), the operand-order image pw_tdiff reads with bdirect
-hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float* out, hipStream_t st);
+// w160: [160][C] fp32 (gen rows, then down rows) -> out (160 * C floats), the operand-order image pw_tdiff16_kernel reads
 hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStream_t st);
 // pw_tdiff_split.hip: out = 160 * C * 6 bytes; p with the 16-pixel form's block layout (pw_tdiff_launch fills it and calls this)
 hipError_t pw_pack_split16_launch(const float* w160, int C, void* out, hipStream_t st);

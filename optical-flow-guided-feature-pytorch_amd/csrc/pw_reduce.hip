@@ -51,31 +51,6 @@ __device__ __forceinline__ void pw_mma(f32x16 (&acc)[PW_TN], const float* As, co
   }
 }
 
-// bf16x3 twin of pw_mma (see offk_common.h): planes A_hi | A_lo | B_hi | B_lo
-template <int NT>
-__device__ __forceinline__ void pw_mma_b3(f32x16 (&acc)[PW_TN], const char* Ahi, const char* Bhi, int lane) {
-  constexpr int A_PLANE = PW_BM * B3_ROW, B_PLANE = PW_BN * B3_ROW;
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll 1
-  for (int s = 0; s < BK / 16; ++s) {
-    const int off = r * B3_ROW + (16 * s + 8 * h) * 2;
-    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + off);
-    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + off);
-    bf16x8 bh[NT], bl[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bh[t] = *reinterpret_cast<const bf16x8*>(Bhi + t * 32 * B3_ROW + off);
-      bl[t] = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + t * 32 * B3_ROW + off);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
-    }
-  }
-}
-
 typedef float f4v __attribute__((ext_vector_type(4)));
 // NT bit 0: the feature map is read exactly once -> non-temporal loads (weights keep the default policy: every block
 // re-reads them); bit 1: G / D are not read again before K1 ends -> non-temporal stores.
@@ -95,15 +70,12 @@ __device__ __forceinline__ void stf(float* q, float v) {
 
 // LEAN: buffer-descriptor addressing of the weights and of the NCHW quad loader (mode 0), unconditional prefetch pinned
 // in front of the MFMAs -- as pw_tdiff.hip; needs every feature-map part and the weight tables below 2^31 bytes.
-template <int PREC, int NT, int LEAN>
+template <int NT, int LEAN>
 __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
-  constexpr int A_PLANE = PW_BM * B3_ROW, B_PLANE = PW_BN * B3_ROW;
-  constexpr int LDS_BYTES = PREC == 0 ? (PW_BM + PW_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
+  constexpr int LDS_BYTES = (PW_BM + PW_BN) * LDS_K * 4;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   float* As = reinterpret_cast<float*>(lds);                    // fp32: [128][LDS_K] then [160][LDS_K]
   float* Bs = As + PW_BM * LDS_K;
-  char* Ahi = lds;                                              // bf16x3: A_hi | A_lo | B_hi | B_lo
-  char* Bhi = lds + 2 * A_PLANE;
 
   // block -> site: field-wise scalar select chain over the (few) table entries; indexing
   // the by-value kernarg array with a runtime index (or copying a whole entry) goes
@@ -247,31 +219,6 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
 #ifdef OFFK_TUNING_KNOBS
     if (p.ablate & 4) return;
 #endif
-    if (PREC == 1) {
-      if (mode == 0) {
-        const int row = 4 * (tid >> 3), kq = tid & 7;
-        b3_store(Ahi, A_PLANE, row, kq, make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x));
-        b3_store(Ahi, A_PLANE, row + 1, kq, make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y));
-        b3_store(Ahi, A_PLANE, row + 2, kq, make_float4(rg[0].z, rg[1].z, rg[2].z, rg[3].z));
-        b3_store(Ahi, A_PLANE, row + 3, kq, make_float4(rg[0].w, rg[1].w, rg[2].w, rg[3].w));
-      } else if (mode == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b3_store(Ahi, A_PLANE, tid & 127, (tid >> 7) + 2 * r, rg[r]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b3_store(Ahi, A_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[r]);
-      }
-      if (p.presplit) {
-        // weights arrive pre-split: chunks 0-3 of a row's 128-B K-tile line are the hi plane, 4-7 the lo plane
-#pragma unroll
-        for (int r = 0; r < PW_TN; ++r)
-          *reinterpret_cast<float4*>(Bhi + ((tid & 7) >> 2) * B_PLANE + ((tid >> 3) + 32 * r) * B3_ROW + ((tid & 3) << 4)) = rg[4 + r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < PW_TN; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[4 + r]);
-      }
-      return;
-    }
     if (mode == 0) {
       float* dst = As + 4 * (tid >> 3) * LDS_K + 4 * (tid & 7);
       *reinterpret_cast<float4*>(dst) = make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x);
@@ -313,12 +260,9 @@ __global__ __launch_bounds__(256, 2) void pw_reduce_kernel(PwParams p) {
     if (p.ablate & 8) {
     } else
 #endif
-    if (PREC == 0) {
+    {
       if (down_active) pw_mma<5>(acc, As + wave * 32 * LDS_K, Bs, lane);
       else pw_mma<4>(acc, As + wave * 32 * LDS_K, Bs, lane);
-    } else {
-      if (down_active) pw_mma_b3<5>(acc, Ahi + wave * 32 * B3_ROW, Bhi, lane);
-      else pw_mma_b3<4>(acc, Ahi + wave * 32 * B3_ROW, Bhi, lane);
     }
     __syncthreads();
   }
@@ -375,23 +319,18 @@ hipError_t pw_reduce_launch(const PwParams& p_in, hipStream_t st) {
 #ifdef OFFK_TUNING_KNOBS
   const char* e = getenv("OFFK_PW_NT");
   const int nt = e ? atoi(e) : kNT;
-  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = false; }
-#define OFFK_PW_LAUNCH(P)                                                                                             \
-  if (lean) hipLaunchKernelGGL((pw_reduce_kernel<P, 0, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);               \
-  else switch (nt & 3) {                                                                                              \
-    case 0: hipLaunchKernelGGL((pw_reduce_kernel<P, 0, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;        \
-    case 1: hipLaunchKernelGGL((pw_reduce_kernel<P, 1, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;        \
-    case 2: hipLaunchKernelGGL((pw_reduce_kernel<P, 2, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;        \
-    default: hipLaunchKernelGGL((pw_reduce_kernel<P, 3, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;       \
+  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !(atoi(le) & 1)) lean = false; }
+  if (lean) hipLaunchKernelGGL((pw_reduce_kernel<0, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);
+  else switch (nt & 3) {
+    case 0: hipLaunchKernelGGL((pw_reduce_kernel<0, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((pw_reduce_kernel<1, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((pw_reduce_kernel<2, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((pw_reduce_kernel<3, 0>), dim3(p.total_blocks), dim3(256), 0, st, p); break;
   }
 #else
-#define OFFK_PW_LAUNCH(P)                                                                                             \
-  if (lean) hipLaunchKernelGGL((pw_reduce_kernel<P, kNT, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);             \
-  else hipLaunchKernelGGL((pw_reduce_kernel<P, kNT, 0>), dim3(p.total_blocks), dim3(256), 0, st, p);
+  if (lean) hipLaunchKernelGGL((pw_reduce_kernel<kNT, 1>), dim3(p.total_blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((pw_reduce_kernel<kNT, 0>), dim3(p.total_blocks), dim3(256), 0, st, p);
 #endif
-  if (p.precision != 0) return hipErrorInvalidValue;      // (the bf16x3 core is no longer instantiated: retired in round 5)
-  OFFK_PW_LAUNCH(0)
-#undef OFFK_PW_LAUNCH
   return hipGetLastError();
 }
 

@@ -39,9 +39,6 @@ __device__ __forceinline__ int pt_down_row(int b, int t, int L, int P, int slice
 
 int pt_tgroups(int L) { return L <= PT_FT ? 1 : (L - 2) / (PT_FT - 1) + 1; }
 
-// PC = 1 (bf16x3 only): 512 threads, waves 0-3 multiply, waves 4-7 load two K-tiles ahead, split and store into a
-// two-stage LDS ring (one block per CU); the 256-thread form holds one tile of prefetch beside 144 accumulator
-// registers and waits a memory latency per K-tile.
 typedef float f4v __attribute__((ext_vector_type(4)));
 // NT bit 0: non-temporal loads of the feature map (read once); bit 1: non-temporal stores of T and D
 // LEAN: buffer-descriptor addressing (every feature-map part and the weight tables < 2^31 bytes): the per-K-tile address
@@ -50,23 +47,12 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // are never written), and the prefetch is unconditional and pinned in front of the MFMAs as in conv_igemm.hip.  The
 // fp32 MFMA shares its lanes with the VALU: the ~90 64-bit address / select / shift instructions of the pointer form
 // per K-tile were matrix time.
-//
-// BD ("B direct", needs LEAN): the weight operand never touches LDS.  A packed copy of the 160 weight rows in MFMA-operand
-// order (pw_pack_direct_kernel: per K-tile and 32-row slab, one 1-KB line per register of the wave) is read straight into
-// the registers the MFMAs consume, each register group re-loaded for the next K-tile right after its last use.  LDS then
-// holds the feature-map tile only, in TWO stages: tile k + 1 is stored while tile k is multiplied, one barrier per K-tile,
-// and the loads run two tiles ahead (registers -> stage -> MFMA).  In bf16x3 the kernel was LDS-bound (208 KB of LDS traffic
-// per block and K-tile at two blocks per CU = ~90 % of the 128 B/clk): without the weight tile's store and its four
-// per-wave re-reads that is 140 KB.
-template <int PREC, int PC, int NT, int LEAN, int BD>
-__global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p) {
-  static_assert(!(PC && LEAN), "producer / consumer form keeps the pointer loader");
-  static_assert(PC == 0 || PREC == 1, "producer / consumer form is bf16x3 only");
-  static_assert(!BD || (LEAN && !PC), "B-direct builds on the buffer-addressed loader");
-  constexpr int A_PLANE = PT_BM * B3_ROW, B_PLANE = PT_BN * B3_ROW;
-  constexpr int STAGE = BD ? (PREC == 0 ? PT_BM * LDS_K * 4 : 2 * A_PLANE)
-                           : (PREC == 0 ? (PT_BM + PT_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE));
-  extern __shared__ __attribute__((aligned(16))) char lds[];     // STAGE bytes, two stages with PC
+// (Rounds 1 - 4 carried a two-plane bf16x3 form, a producer / consumer form and a "B direct" form of this kernel as template branches;
+//  they were retired with the bf16x3 mode in round 5.  What is left is the fp32 fallback of pw_tdiff16_kernel: weights bound in the
+//  caller's tensors (offk_bind_weight) or a tensor past 2^31 bytes.)
+template <int NT, int LEAN>
+__global__ __launch_bounds__(256, 2) void pw_tdiff_kernel(PtParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];     // (PT_BM + PT_BN) * LDS_K * 4 bytes
   float* As = reinterpret_cast<float*>(lds);                    // fp32: [224][LDS_K] then [160][LDS_K]
   float* Bs = As + PT_BM * LDS_K;
 
@@ -74,7 +60,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
   int nblk_site;
 #define OFFK_PT_PICK(i)                                                                                \
   S.w = p.s[i].w; S.bias = p.s[i].bias; S.D = p.s[i].D; S.M = p.s[i].M; S.m_cs = p.s[i].m_cs;           \
-  S.w_down = p.s[i].w_down; S.bias_down = p.s[i].bias_down; S.wt = p.s[i].wt;                            \
+  S.w_down = p.s[i].w_down; S.bias_down = p.s[i].bias_down;                                              \
   S.m_coff = p.s[i].m_coff; S.C = p.s[i].C; S.HW = p.s[i].HW; S.chunks = p.s[i].chunks;                \
   S.nrem = p.s[i].nrem; S.rsh = p.s[i].rsh;                                                            \
   S.blk_begin = p.s[i].blk_begin; S.nparts = p.s[i].nparts;                                           \
@@ -119,7 +105,7 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     }
   };
   constexpr int NRG = 8 + 5;          // A: frame fs (4 k-rows), frame fs+4 (4 k-rows); B: 5 weight rows
-  float4 rg[PC ? 2 * NRG : NRG];      // PC: two sets (one array: separate ones go to scratch)
+  float4 rg[NRG];
   const float* wbase = S.w + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   const float* wdbase = S.w_down + (size_t)(tid >> 3) * C + 4 * (tid & 7);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -153,7 +139,6 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
           rg[set + 4 * half + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
       }
-      if constexpr (BD) return;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, (32 * r * C + k0) * 4, 0);
@@ -183,67 +168,26 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
     if (LEAN || sh == 0) return v;
     return sh == 1 ? make_float4(v.y, v.z, v.w, 0.f) : (sh == 2 ? make_float4(v.z, v.w, 0.f, 0.f) : make_float4(v.w, 0.f, 0.f, 0.f));
   };
-  auto store_tile = [&](const int set, int stage) {
-    char* Ahi = lds + stage * STAGE;                              // bf16x3: A_hi | A_lo | B_hi | B_lo
-    char* Bhi = Ahi + 2 * A_PLANE;
+  auto store_tile = [&](const int set) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int j = fs + 4 * half;
       if (j < PT_FT) {
         const float4 a0 = shifted(rg[set + 4 * half]), a1 = shifted(rg[set + 4 * half + 1]), a2 = shifted(rg[set + 4 * half + 2]), a3 = shifted(rg[set + 4 * half + 3]);
         const int row = j * 32 + 4 * pq;
-        if (PREC == 1) {
-          b3_store(Ahi, A_PLANE, row, kq, make_float4(a0.x, a1.x, a2.x, a3.x));
-          b3_store(Ahi, A_PLANE, row + 1, kq, make_float4(a0.y, a1.y, a2.y, a3.y));
-          b3_store(Ahi, A_PLANE, row + 2, kq, make_float4(a0.z, a1.z, a2.z, a3.z));
-          b3_store(Ahi, A_PLANE, row + 3, kq, make_float4(a0.w, a1.w, a2.w, a3.w));
-        } else {
-          float* dst = reinterpret_cast<float*>(lds + stage * STAGE) + row * LDS_K + 4 * kq;
-          *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a1.x, a2.x, a3.x);
-          *reinterpret_cast<float4*>(dst + LDS_K) = make_float4(a0.y, a1.y, a2.y, a3.y);
-          *reinterpret_cast<float4*>(dst + 2 * LDS_K) = make_float4(a0.z, a1.z, a2.z, a3.z);
-          *reinterpret_cast<float4*>(dst + 3 * LDS_K) = make_float4(a0.w, a1.w, a2.w, a3.w);
-        }
+        float* dst = As + row * LDS_K + 4 * kq;
+        *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a1.x, a2.x, a3.x);
+        *reinterpret_cast<float4*>(dst + LDS_K) = make_float4(a0.y, a1.y, a2.y, a3.y);
+        *reinterpret_cast<float4*>(dst + 2 * LDS_K) = make_float4(a0.z, a1.z, a2.z, a3.z);
+        *reinterpret_cast<float4*>(dst + 3 * LDS_K) = make_float4(a0.w, a1.w, a2.w, a3.w);
       }
     }
-    if constexpr (BD) return;
-    if (PREC == 1) {
-      if (p.presplit) {
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
-          *reinterpret_cast<float4*>(Bhi + ((tid & 7) >> 2) * B_PLANE + ((tid >> 3) + 32 * r) * B3_ROW + ((tid & 3) << 4)) = rg[set + 8 + r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 5; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[set + 8 + r]);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 5; ++r)
-        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[set + 8 + r];
-    }
+    for (int r = 0; r < 5; ++r)
+      *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * r) * LDS_K + 4 * (tid & 7)) = rg[set + 8 + r];
   };
 
   const int nkt = C / BK;
-  if (PC && wave >= 4) {
-    // ---- producers (as in conv_igemm.hip): tile t is stored one step before it is multiplied, loaded two before that
-    load_tile(0, 0);
-    store_tile(0, 0);
-    if (1 < nkt) load_tile(0, BK);
-    if (2 < nkt) load_tile(NRG, 2 * BK);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-      store_tile(0, 1);
-      if (kt + 3 < nkt) load_tile(0, (kt + 3) * BK);
-      __syncthreads();
-      if (kt + 2 < nkt) store_tile(NRG, 0);
-      if (kt + 4 < nkt) load_tile(NRG, (kt + 4) * BK);
-      __syncthreads();
-    }
-    if (kt < nkt) __syncthreads();
-    return;
-  }
-
   f32x16 acc[PT_FT + 2];   // 0..6: gen tile of frame j; 7, 8: down tiles of frames wave and wave + 4
 #pragma unroll
   for (int t = 0; t < PT_FT + 2; ++t)
@@ -252,140 +196,26 @@ __global__ __launch_bounds__(PC ? 512 : 256, 2) void pw_tdiff_kernel(PtParams p)
 
   const int r32 = lane & 31, h = lane >> 5;
   const bool d1 = wave + 4 < PT_FT;          // waves 0-2 own a second down tile
-  if constexpr (BD) {
-    // ---- B-direct K loop -------------------------------------------------------------------------------------------
-    // bq[0..3]: this wave's 32 gen rows, bq[4..7]: the 32 down rows; index = k-group g (fp32: 4 consecutive k of row r32
-    // at 8g + 4h) or plane * 2 + s2 (bf16x3: 8 consecutive bf16 at 16 s2 + 8h of the hi / lo plane)
-    float4 bq[8];
-    const __amdgpu_buffer_rsrc_t wtrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.wt), 0, kUnitCh * C * 4, 0x00020000);
-    auto load_b = [&](const int sel, const int i, int kt) {
-      const int slab = sel ? 4 : wave;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wtrs, lane * 16, ((kt * 5 + slab) * 4 + i) * 1024, 0);
-      bq[sel * 4 + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    };
-    auto mm4 = [&](f32x16& c, const float4& w, const float4& x) {
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, x.x, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, x.y, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, x.z, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, x.w, c, 0, 0, 0);
-    };
-    auto mm3 = [&](f32x16& c, const bf16x8& wh, const bf16x8& wl, const bf16x8& xh, const bf16x8& xl) {
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, c, 0, 0, 0);     // same order as the LDS form (and as K1)
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, c, 0, 0, 0);
-    };
-    // multiply tile kt out of LDS stage `st` (a literal at both call sites); every weight register group is re-loaded
-    // for tile ktn right behind its last MFMA
-    auto mma = [&](const int st, int ktn) {
-      const char* Ast = lds + st * STAGE;
-      if constexpr (PREC == 0) {
-        const float* Af = reinterpret_cast<const float*>(Ast);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-#pragma unroll
-          for (int j = 0; j < PT_FT; ++j)
-            mm4(acc[j], bq[g], *reinterpret_cast<const float4*>(Af + (j * 32 + r32) * LDS_K + 8 * g + 4 * h));
-          mm4(acc[PT_FT], bq[4 + g], *reinterpret_cast<const float4*>(Af + (wave * 32 + r32) * LDS_K + 8 * g + 4 * h));
-          if (d1) mm4(acc[PT_FT + 1], bq[4 + g], *reinterpret_cast<const float4*>(Af + ((wave + 4) * 32 + r32) * LDS_K + 8 * g + 4 * h));
-          load_b(0, g, ktn);
-          load_b(1, g, ktn);
-        }
-      } else {
-#pragma unroll
-        for (int s2 = 0; s2 < BK / 16; ++s2) {
-          const int off = r32 * B3_ROW + (16 * s2 + 8 * h) * 2;
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[s2]), bl = __builtin_bit_cast(bf16x8, bq[2 + s2]);
-          const bf16x8 dh = __builtin_bit_cast(bf16x8, bq[4 + s2]), dl = __builtin_bit_cast(bf16x8, bq[6 + s2]);
-#pragma unroll
-          for (int j = 0; j < PT_FT; ++j)
-            mm3(acc[j], bh, bl, *reinterpret_cast<const bf16x8*>(Ast + j * 32 * B3_ROW + off),
-                *reinterpret_cast<const bf16x8*>(Ast + A_PLANE + j * 32 * B3_ROW + off));
-          mm3(acc[PT_FT], dh, dl, *reinterpret_cast<const bf16x8*>(Ast + wave * 32 * B3_ROW + off),
-              *reinterpret_cast<const bf16x8*>(Ast + A_PLANE + wave * 32 * B3_ROW + off));
-          if (d1)
-            mm3(acc[PT_FT + 1], dh, dl, *reinterpret_cast<const bf16x8*>(Ast + (wave + 4) * 32 * B3_ROW + off),
-                *reinterpret_cast<const bf16x8*>(Ast + A_PLANE + (wave + 4) * 32 * B3_ROW + off));
-          load_b(0, s2, ktn); load_b(0, 2 + s2, ktn);
-          load_b(1, s2, ktn); load_b(1, 2 + s2, ktn);
-        }
-      }
-    };
-    auto step = [&](int kt, const int st) {
-      store_tile(0, st ^ 1);                           // tile kt + 1 (past the end: the clamped tile into the idle stage)
-      load_tile(0, min(kt + 2, nkt - 1) * BK);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(st, min(kt + 1, nkt - 1));
-      __syncthreads();
-    };
-    load_tile(0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { load_b(0, i, 0); load_b(1, i, 0); }
-    store_tile(0, 0);
-    load_tile(0, min(1, nkt - 1) * BK);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-      step(kt, 0);
-      step(kt + 1, 1);
-    }
-    if (kt < nkt) step(kt, 0);
-  }
-  if (PC) __syncthreads();
-  else if (!BD) load_tile(0, 0);
+  load_tile(0, 0);
 #ifdef OFFK_PT_TIMING
   unsigned long long t_st = 0, t_s1 = 0, t_ld = 0, t_mm = 0, t_s2 = 0, c0 = __builtin_readcyclecounter(), c1;
 #define OFFK_TICK(var) c1 = __builtin_readcyclecounter(); var += c1 - c0; c0 = c1;
 #else
 #define OFFK_TICK(var)
 #endif
-  for (int kt = 0; kt < (BD ? 0 : nkt); ++kt) {
-    if (!PC) {
-      store_tile(0, 0);
-      OFFK_TICK(t_st)
-      __syncthreads();
-      OFFK_TICK(t_s1)
-      if constexpr (LEAN) {
-        load_tile(0, min(kt + 1, nkt - 1) * BK);      // unconditional (no phi copies of in-flight loads), and kept in
-        __builtin_amdgcn_sched_barrier(0);            // front of the MFMAs
-      } else {
-        if (kt + 1 < nkt) load_tile(0, (kt + 1) * BK);
-      }
-      OFFK_TICK(t_ld)
-    }
-    const char* Ahi = lds + (PC ? (kt & 1) * STAGE : 0);
-    const char* Bhi = Ahi + 2 * A_PLANE;
-    if (PREC == 1) {
-#pragma unroll 1
-      for (int s2 = 0; s2 < BK / 16; ++s2) {
-        const int off = r32 * B3_ROW + (16 * s2 + 8 * h) * 2;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + wave * 32 * B3_ROW + off);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + wave * 32 * B3_ROW + off);
-        const bf16x8 dh = *reinterpret_cast<const bf16x8*>(Bhi + kGenCh * B3_ROW + off);
-        const bf16x8 dl = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + kGenCh * B3_ROW + off);
-#pragma unroll
-        for (int j = 0; j < PT_FT; ++j) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + j * 32 * B3_ROW + off);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + j * 32 * B3_ROW + off);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[j], 0, 0, 0);   // weights first: rows of the
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[j], 0, 0, 0);   // accumulator tile = channels,
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[j], 0, 0, 0);   // lanes = pixels (16-B stores)
-        }
-        {   // down tile of frame `wave` (its rows are read again: a runtime row offset, not a runtime register index)
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + wave * 32 * B3_ROW + off);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + wave * 32 * B3_ROW + off);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, al, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, ah, acc[PT_FT], 0, 0, 0);
-          acc[PT_FT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, ah, acc[PT_FT], 0, 0, 0);
-        }
-        if (d1) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + (wave + 4) * 32 * B3_ROW + off);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + (wave + 4) * 32 * B3_ROW + off);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, al, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, ah, acc[PT_FT + 1], 0, 0, 0);
-          acc[PT_FT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, ah, acc[PT_FT + 1], 0, 0, 0);
-        }
-      }
+  for (int kt = 0; kt < nkt; ++kt) {
+    store_tile(0);
+    OFFK_TICK(t_st)
+    __syncthreads();
+    OFFK_TICK(t_s1)
+    if constexpr (LEAN) {
+      load_tile(0, min(kt + 1, nkt - 1) * BK);      // unconditional (no phi copies of in-flight loads), and kept in
+      __builtin_amdgcn_sched_barrier(0);            // front of the MFMAs
     } else {
+      if (kt + 1 < nkt) load_tile(0, (kt + 1) * BK);
+    }
+    OFFK_TICK(t_ld)
+    {
 #pragma unroll 1
       for (int g = 0; g < BK / 8; ++g) {
         const float4 bw = *reinterpret_cast<const float4*>(Bs + (wave * 32 + r32) * LDS_K + 8 * g + 4 * h);
@@ -793,36 +623,6 @@ hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStre
   return hipGetLastError();
 }
 
-// Operand-order image of a site's 160 weight rows for the BD form.  One 16-byte item per (K-tile, slab, i, lane):
-//   fp32  : i = k-group g          -> W[slab*32 + r32][kt*32 + 8g + 4h + 0..3]
-//   bf16x3: i = plane*2 + s2       -> bf16 hi (plane 0) / lo (plane 1) of W[slab*32 + r32][kt*32 + 16 s2 + 8h + 0..7]
-// with r32 = lane & 31, h = lane >> 5; split exactly as split4() does (hi = upper 16 bits, lo = bf16_rne(x - hi)).
-__global__ void pw_pack_direct_kernel(const float* __restrict__ w, int C, int prec, float4* __restrict__ out) {
-  const int item = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nitems = (C / BK) * 5 * 4 * 64;
-  if (item >= nitems) return;
-  const int lane = item & 63, i = (item >> 6) & 3, slab = (item >> 8) % 5, kt = (item >> 8) / 5;
-  const int r32 = lane & 31, h = lane >> 5;
-  const float* row = w + (size_t)(slab * 32 + r32) * C + kt * BK;
-  if (prec == 0) {
-    out[item] = *reinterpret_cast<const float4*>(row + 8 * i + 4 * h);
-    return;
-  }
-  const int plane = i >> 1, s2 = i & 1;
-  const float4 v0 = *reinterpret_cast<const float4*>(row + 16 * s2 + 8 * h), v1 = *reinterpret_cast<const float4*>(row + 16 * s2 + 8 * h + 4);
-  uint2 h0, l0, h1, l1;
-  split4(v0, h0, l0);
-  split4(v1, h1, l1);
-  const uint4 r = plane ? make_uint4(l0.x, l0.y, l1.x, l1.y) : make_uint4(h0.x, h0.y, h1.x, h1.y);
-  out[item] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
-}
-
-hipError_t pw_pack_direct_launch(const float* w160, int C, int precision, float* out, hipStream_t st) {
-  const int nitems = (C / BK) * 5 * 4 * 64;
-  hipLaunchKernelGGL(pw_pack_direct_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, w160, C, precision, reinterpret_cast<float4*>(out));
-  return hipGetLastError();
-}
-
 hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   PtParams p = p_in;
   if (p.nsites <= 0 || p.B <= 0) return hipSuccess;
@@ -858,7 +658,7 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   constexpr size_t kStage32 = (size_t)(PT_BM + PT_BN) * LDS_K * 4;
   constexpr int kNT = 0;     // product default (tools/sweep_pw.py, profiles/r02)
   // exact fp32 + the library's own weight image: always the 16-pixel LDS-DMA form
-#define OFFK_PT_LAUNCH_BD(P)                                                                                         \
+#define OFFK_PT_LAUNCH_BD                                                                                            \
   {                                                                                                                  \
     constexpr int k16Lds = 2 * PT_FT * 32 * 64 + 1024;                                                               \
     hipError_t er = lds_attr_once(reinterpret_cast<const void*>(pw_tdiff16_kernel), k16Lds);                         \
@@ -877,9 +677,9 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #ifdef OFFK_TUNING_KNOBS
   { const char* pe = getenv("OFFK_PW_PACK"); if (pe && *pe == '0') pack = false; }
   { const char* be = getenv("OFFK_PW_BDIRECT"); if (be && *be == '0') bd = false; }
-  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !((atoi(le) >> (p.precision & 1)) & 1)) lean = bd = pack = false; }   // bit 0 fp32, bit 1 bf16x3
+  { const char* le = getenv("OFFK_PW_LEAN"); if (le && !(atoi(le) & 1)) lean = bd = pack = false; }
 #endif
-  const bool form16 = p.precision == 0 && bd;      // exact fp32 with the library's own weight image: the 16-pixel form (pw_tdiff16_kernel)
+  const bool form16 = bd;      // the library's own weight image: the 16-pixel forms (pw_tdiff16_kernel / pw_tdiff_split_kernel)
   auto layout = [&]() {      // block layout of every site (PtSite)
     if (form16) {
       int blk = 0;
@@ -904,9 +704,8 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
     for (int i = 0; i < p.nsites; ++i) {
       PtSite& o = p.s[i];
       const int rem = o.HW % 32;
-      // 16-byte pieces (4 leftover pixels per clip) cost a whole sector each: worth it where the kernel is MFMA-bound
-      // (fp32: 1.45 -> 1.36 ms), a loss where it is bound by the feature-map reads (bf16x3: 0.68 -> 0.76 ms)
-      const bool packed = pack && (rem == 16 || (p.precision == 0 && (rem == 4 || rem == 8)));
+      // 16-byte pieces (4 leftover pixels per clip) cost a whole sector each: worth it where the kernel is MFMA-bound (1.45 -> 1.36 ms)
+      const bool packed = pack && (rem == 16 || rem == 4 || rem == 8);
       o.chunks = packed ? o.HW / 32 : (o.HW + 31) / 32;
       o.rsh = packed ? (rem == 4 ? 2 : rem == 8 ? 3 : 4) : 5;
       o.nrem = packed ? (p.B + (32 >> o.rsh) - 1) / (32 >> o.rsh) : 0;
@@ -917,23 +716,24 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
     p.total_blocks = blk;
   };
   layout();
+  // (not form16: the fallback kernel -- buffer-addressed loader where every tensor is below 2^31 bytes, pointer loader otherwise)
 #ifdef OFFK_TUNING_KNOBS
   const char* e = getenv("OFFK_PW_NT");
   const int nt = e ? atoi(e) : kNT;
-#define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
-  if (bd) OFFK_PT_LAUNCH_BD(P)                                                                                       \
-  else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);  \
-  else switch (nt & 3) {                                                                                             \
-    case 0: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 0, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;   \
-    case 1: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 1, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;   \
-    case 2: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 2, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;   \
-    default: hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, 3, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;  \
+#define OFFK_PT_LAUNCH(LDS)                                                                                       \
+  if (bd) OFFK_PT_LAUNCH_BD                                                                                       \
+  else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<0, 1>), dim3(p.total_blocks), dim3(256), LDS, st, p);        \
+  else switch (nt & 3) {                                                                                          \
+    case 0: hipLaunchKernelGGL((pw_tdiff_kernel<0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
+    case 1: hipLaunchKernelGGL((pw_tdiff_kernel<1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
+    case 2: hipLaunchKernelGGL((pw_tdiff_kernel<2, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;      \
+    default: hipLaunchKernelGGL((pw_tdiff_kernel<3, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); break;     \
   }
 #else
-#define OFFK_PT_LAUNCH(P, LDS)                                                                                       \
-  if (bd) OFFK_PT_LAUNCH_BD(P)                                                                                       \
-  else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 1, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p); \
-  else hipLaunchKernelGGL((pw_tdiff_kernel<P, 0, kNT, 0, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);
+#define OFFK_PT_LAUNCH(LDS)                                                                                       \
+  if (bd) OFFK_PT_LAUNCH_BD                                                                                       \
+  else if (lean) hipLaunchKernelGGL((pw_tdiff_kernel<kNT, 1>), dim3(p.total_blocks), dim3(256), LDS, st, p);      \
+  else hipLaunchKernelGGL((pw_tdiff_kernel<kNT, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);
 #endif
   if (form16 && p.f32split) {
 #ifdef OFFK_WITH_PC
@@ -942,8 +742,7 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
 #endif
     return pw_tdiff_split_launch(p, st);
   }
-  if (p.precision != 0) return hipErrorInvalidValue;      // (the two-plane bf16x3 mode is no longer instantiated: retired in round 5)
-  OFFK_PT_LAUNCH(0, kStage32)
+  OFFK_PT_LAUNCH(kStage32)
 #undef OFFK_PT_LAUNCH
 #undef OFFK_PT_LAUNCH_BD
   return hipGetLastError();

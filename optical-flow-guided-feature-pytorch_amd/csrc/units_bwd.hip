@@ -264,19 +264,14 @@ __device__ __forceinline__ int wg_down_row(int f, int L, int P, int slice_mode) 
 }
 }  // namespace
 
-template <int PREC>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
-  // PREC 0: exact fp32 MFMA, LDS [row][k] fp32 (stride LDS_K);  PREC 1: bf16x3 (offk_common.h), planes
-  // A_hi | A_lo | B_hi | B_lo of [row][32 k] bf16 with 80-byte rows, both operands split on the way in
-  constexpr int A_PLANE = WG_BM * B3_ROW, B_PLANE = WG_BN * B3_ROW;
-  constexpr int LDS_BYTES = PREC == 0 ? (WG_BM + WG_BN) * LDS_K * 4 : 2 * (A_PLANE + B_PLANE);
+  // fp32 MFMA, LDS [row][k] fp32 (stride LDS_K)
+  constexpr int LDS_BYTES = (WG_BM + WG_BN) * LDS_K * 4;
   static_assert(LDS_BYTES >= (8 * kGenCh + 32 * kDownCh) * 4, "bias reduction reuses the tile memory");
   __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
   float* lds = reinterpret_cast<float*>(lds_raw);
   float* As = lds;                   // [160][LDS_K]: rows = stacked output channel, k = pixel
   float* Bs = lds + WG_BM * LDS_K;   // [128][LDS_K]: rows = input channel of this slab
-  char* Ahi = lds_raw;
-  char* Bhi = lds_raw + 2 * A_PLANE;
 
   // XCD-aware order: consecutive logical blocks (the channel slabs of one K-chunk, which share the A operand)
   // land on the same XCD / L2
@@ -376,26 +371,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
     bs_g.x += (rg[0].x + rg[1].x) + (rg[2].x + rg[3].x); bs_g.y += (rg[0].y + rg[1].y) + (rg[2].y + rg[3].y);
     bs_g.z += (rg[0].z + rg[1].z) + (rg[2].z + rg[3].z); bs_g.w += (rg[0].w + rg[1].w) + (rg[2].w + rg[3].w);
     bs_d.x += rg[4].x; bs_d.y += rg[4].y; bs_d.z += rg[4].z; bs_d.w += rg[4].w;
-    if (PREC == 1) {
-      b3_store(Ahi, A_PLANE, 4 * cq, pq, make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x));
-      b3_store(Ahi, A_PLANE, 4 * cq + 1, pq, make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y));
-      b3_store(Ahi, A_PLANE, 4 * cq + 2, pq, make_float4(rg[0].z, rg[1].z, rg[2].z, rg[3].z));
-      b3_store(Ahi, A_PLANE, 4 * cq + 3, pq, make_float4(rg[0].w, rg[1].w, rg[2].w, rg[3].w));
-      uint2 dh, dl;
-      split4(rg[4], dh, dl);   // four channels of one pixel: one bf16 each into four rows
-      char* dd = Ahi + (kGenCh + 4 * dcq) * B3_ROW + dpx * 2;
-      *reinterpret_cast<unsigned short*>(dd) = (unsigned short)dh.x;
-      *reinterpret_cast<unsigned short*>(dd + B3_ROW) = (unsigned short)(dh.x >> 16);
-      *reinterpret_cast<unsigned short*>(dd + 2 * B3_ROW) = (unsigned short)dh.y;
-      *reinterpret_cast<unsigned short*>(dd + 3 * B3_ROW) = (unsigned short)(dh.y >> 16);
-      *reinterpret_cast<unsigned short*>(dd + A_PLANE) = (unsigned short)dl.x;
-      *reinterpret_cast<unsigned short*>(dd + A_PLANE + B3_ROW) = (unsigned short)(dl.x >> 16);
-      *reinterpret_cast<unsigned short*>(dd + A_PLANE + 2 * B3_ROW) = (unsigned short)dl.y;
-      *reinterpret_cast<unsigned short*>(dd + A_PLANE + 3 * B3_ROW) = (unsigned short)(dl.y >> 16);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b3_store(Bhi, B_PLANE, (tid >> 3) + 32 * r, tid & 7, rg[5 + r]);
-      return;
-    }
     float* a = As + 4 * cq * LDS_K + 4 * pq;
     *reinterpret_cast<float4*>(a) = make_float4(rg[0].x, rg[1].x, rg[2].x, rg[3].x);
     *reinterpret_cast<float4*>(a + LDS_K) = make_float4(rg[0].y, rg[1].y, rg[2].y, rg[3].y);
@@ -423,23 +398,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
       if (kin >= HW) { kin = 0; ++frame; }
       load_tile();
     }
-    if (wave_on && PREC == 1) {
-      const int r32 = lane & 31, h = lane >> 5;
-#pragma unroll 1
-      for (int s2 = 0; s2 < BK / 16; ++s2) {
-        const int off = r32 * B3_ROW + (16 * s2 + 8 * h) * 2;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bhi + wave * 32 * B3_ROW + off);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bhi + B_PLANE + wave * 32 * B3_ROW + off);
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + t * 32 * B3_ROW + off);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ahi + A_PLANE + t * 32 * B3_ROW + off);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-        }
-      }
-    } else if (wave_on) {
+    if (wave_on) {
       const int r32 = lane & 31, h = lane >> 5;
       const float* bsrc = Bs + (wave * 32 + r32) * LDS_K + 4 * h;
       const float* asrc = As + r32 * LDS_K + 4 * h;
@@ -494,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgParams p) {
 hipError_t pw_wgrad_launch(const WgParams& p, hipStream_t st) {
   if (p.total_blocks <= 0) return hipSuccess;
   if (p.precision != 0) return hipErrorInvalidValue;      // (the bf16x3 core is no longer instantiated: retired in round 5)
-  hipLaunchKernelGGL(pw_wgrad_kernel<0>, dim3(p.total_blocks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(pw_wgrad_kernel, dim3(p.total_blocks), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 
