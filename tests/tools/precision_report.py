@@ -33,7 +33,7 @@ for variant, B, L in ((0, 2, 3), (1, 2, 3), (0, 3, 7)):
     c7 = c14 = c28 = None
     if B * L <= 6:
         c7, c14, c28 = c_binding.forward(feats, [w[k] for k in spec.weight_shapes(variant)], B, L, variant, 0, False)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "f32split"):
         h = runtime.OffForward(B, L, variant, consensus=False, precision=prec)
         h.load_state_dict(w)
         o7, o14, o28 = (t.cpu().numpy() for t in h.forward([torch.from_numpy(f).cuda() for f in feats]))

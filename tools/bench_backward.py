@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--length", type=int, default=7)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="fp32")
     ap.add_argument("--variant", type=int, default=spec.VARIANT_RGB)
     a = ap.parse_args()
     B, L = a.batch, a.length

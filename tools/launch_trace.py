@@ -1,4 +1,4 @@
-"""Per-launch trace of one forward shape (offk_set_profiling(h, 2)): tools/launch_trace.py B L [fp32|bf16x3] [steps].  GPU only."""
+"""Per-launch trace of one forward shape (offk_set_profiling(h, 2)): tools/launch_trace.py B L [fp32|f32split] [steps].  GPU only."""
 import os
 import sys
 

@@ -28,7 +28,7 @@ def timed(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-for prec in ("fp32", "bf16x3"):
+for prec in ("fp32",):
     h = runtime.OffForward(B, L, spec.VARIANT_RGB, precision=prec)
     h.load_state_dict(synth.make_weights(spec.VARIANT_RGB))
     h.off_units(feats)

@@ -16,7 +16,7 @@ w = synth.make_weights(spec.VARIANT_RGB)
 print("fused prec    nt | units stage ms (K1 or K1T) | K2-part ms | whole forward ms")
 for fused in ("1", "0"):
     os.environ["OFFK_FUSED_UNITS"] = fused
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("fp32",):
         h = runtime.OffForward(B, L, spec.VARIANT_RGB, precision=prec)
         h.load_state_dict(w)
         arr = h._feat_array(feats)

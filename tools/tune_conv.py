@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import offk_amd  # noqa: E402,F401
 from offk_amd import runtime, spec  # noqa: E402
 
-TILE_BN = (128, 64, 64, 64, 128, 256, 128, 64)   # 6 / 7: the LDS-patch kernel (bf16x3, k x k convs)
+TILE_BN = (128, 64, 64, 64, 128, 256, 128, 64)   # 6 / 7: the LDS-patch kernel (k x k convs)
 TILE_BM = (128, 128, 256, 64, 64, 128, 196, 196)
 
 
@@ -47,10 +47,6 @@ def main():
         wp = torch.empty(co, k, k, ci, device="cuda")
         from offk_amd import _lib
         _lib.check(_lib.load().offk_pack_conv_weight(runtime._stream(), runtime._ptr(w), co, ci, k, k, runtime._ptr(wp)))
-        if args.precision == 1:
-            ws = torch.empty_like(wp)
-            _lib.check(_lib.load().offk_split_bf16x3(runtime._stream(), runtime._ptr(wp), wp.numel(), runtime._ptr(ws)))
-            wp = ws
         Ho = (H + 2 * p - k) // s + 1
         M = P * Ho * Ho
         flops = 2.0 * M * co * ci * k * k
@@ -60,7 +56,7 @@ def main():
         for cfg in range(8):
             if co % TILE_BN[cfg]:
                 continue
-            if cfg >= 6 and (args.precision != 1 or k == 1):
+            if cfg >= 6 and k == 1:
                 continue
             for sk in (1, 2, 3, 4, 6, 8, 12):
                 if sk > 1 and (nkt // sk < 8 or sk * M * co * 4 > 1.2e9):

@@ -1,7 +1,7 @@
 """In-situ plan tuning: coordinate descent over (tile_cfg, splitk) of the heavy fusion convs and the three merged
 1x1 convs, timing the WHOLE forward (the isolated per-conv optimum of tools/tune_conv.py ignores L2 state and
 neighbouring kernels).  Prints the plans that beat the built-in table.
-    python tools/tune_forward.py [--batch 64] [--length 7] [--precision bf16x3]"""
+    python tools/tune_forward.py [--batch 64] [--length 7] [--precision f32split]"""
 import argparse
 import os
 import sys
@@ -67,7 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--length", type=int, default=7)
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="fp32")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--wide", action="store_true", help="every generic tile x a split-K ladder per conv (other batch shapes)")
