@@ -191,7 +191,7 @@ def check_counted_store_waits(src_name, code_objects):
 # memory in some lanes (wino_gemm_split.hip, round 5: lanes 12-15 of every sixteen, run-to-run varying).  LLVM's hazard recogniser
 # places the wait state only when the store has no SGPR offset; hipcc had re-used the first data register for the next address.
 _WIDE_STORE_RE = re.compile(r"^(?:buffer|global|flat)_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
-_VALU_DST_RE = re.compile(r"^v_(?!cmp|cmpx|mfma|readlane|readfirstlane)\w+\s+(?:v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)")
+_VALU_DST_RE = re.compile(r"^v_(?!cmp|cmpx|readlane|readfirstlane)\w+\s+(?:v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)")
 
 
 def store_data_hazards(disassembly):
