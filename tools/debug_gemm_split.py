@@ -4,6 +4,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
+PREC = os.environ.get("DEBUG_PREC", "f32split")
 
 import offk_amd  # noqa: F401
 from offk_amd import runtime
@@ -15,8 +16,8 @@ if len(sys.argv) > 5 and sys.argv[5] == "relu":
     x = torch.relu(x)
 w = torch.randn(batch, Co, K, generator=g) / K ** 0.5
 ref = torch.einsum("bmk,bnk->bmn", x.double(), w.double())
-y = runtime.batched_gemm_nt(x.cuda(), w.cuda(), "f32split").double().cpu()
-y2 = runtime.batched_gemm_nt(x.cuda(), w.cuda(), "f32split").double().cpu()
+y = runtime.batched_gemm_nt(x.cuda(), w.cuda(), PREC).double().cpu()
+y2 = runtime.batched_gemm_nt(x.cuda(), w.cuda(), PREC).double().cpu()
 print("run-to-run identical:", bool(torch.equal(y, y2)))
 err = (y - ref).abs()
 print("max err", err.max().item(), "of", ref.abs().max().item())
