@@ -15,6 +15,8 @@
 // (motion_conv2_trans_14b -> motion_conv3_trans_14b).
 // The transforms are the arithmetic of wino_output_kernel / wino_input_kernel element for element; only the 1x1 conv's summation
 // order differs from the generic kernel's (k in steps of 4 instead of 2).
+#include <type_traits>
+
 #include "offk_common.h"
 #include "offk_internal.h"
 #include "winograd_common.h"
@@ -33,12 +35,13 @@ __device__ __forceinline__ int tile_off(int px, int c) { return px * (C * 4) + (
 // stage A for one class: M -> relu(A^T M A + bias) -> LDS tile (+ HBM), lane = channel within a group of 64.  TWO channel groups at
 // a time: their 2 x NY x NX loads -- every one a 256-byte row of a different point plane -- are in flight together (one group at a
 // time, the four groups of a 256-channel image were four exposed HBM latencies per block: the first version's 60 us at P = 384).
-template <int NPH, int CY, int CX, int CIN>
+// (G0 .. G1: the channel groups of 64 this call covers; LC: channels per row of the LDS tile, which starts at channel 64 G0)
+template <int NPH, int CY, int CX, int CIN, int G0 = 0, int G1 = CIN / 64, int LC = CIN>
 __device__ __forceinline__ void mid_out_class(const WinoMidArgs& a, int img, int lane, char* xt, float* xg) {
   constexpr int NY = CY ? 5 : 6, NX = CX ? 5 : 6, OY = CY ? 3 : 4, OX = CX ? 3 : 4, oy = CY ? 4 : 0, ox = CX ? 4 : 0;
   const size_t pstride = (size_t)a.n_img * CIN;
 #pragma unroll
-  for (int g0 = 0; g0 < CIN / 64; g0 += 2) {
+  for (int g0 = G0; g0 < G1; g0 += 2) {
     float m[2][NY][NX];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -70,7 +73,7 @@ __device__ __forceinline__ void mid_out_class(const WinoMidArgs& a, int img, int
         for (int j = 0; j < OX; ++j) {
           const int px = (oy + i) * 7 + ox + j;
           const float v = fmaxf(yv[j] + bv, 0.f);
-          *reinterpret_cast<float*>(xt + tile_off<CIN>(px, c)) = v;
+          *reinterpret_cast<float*>(xt + tile_off<LC>(px, c - 64 * G0)) = v;
           if (xg) xg[((size_t)img * 49 + px) * a.x_cs + a.x_coff + c] = v;
         }
       }
@@ -119,12 +122,17 @@ __device__ __forceinline__ void mid_in_class(const WinoMidArgs& a, int img, int 
 // NPH: point order of M (1: a 3x3 / stride 1 conv in front, 4: the polyphase 5x5 / stride 2 conv).  NS: the 1x1 conv's output
 // channels are split over NS blocks per image (blockIdx.y), each of which repeats stage A for all CIN channels (M comes out of L2 the
 // second time): P = 384 images alone are 1.5 blocks per CU, and a 256 -> 256 block is 33 k cycles of MFMAs per wave.
-template <int CIN, int CMID, bool GEMM, int NPH, int NS>
-__global__ __launch_bounds__(256, 2) void wino_mid_kernel(WinoMidArgs a) {
+// KH = 2 (CIN = 256, NS = 2): the x tile in two k halves of 128 channels -- stage A and stage B alternate per half, the
+// accumulators stay in registers -- so that x, and t behind it, take 32 KB instead of 64 KB and three blocks fit a CU.  Same k order:
+// bit-identical to KH = 1.
+template <int CIN, int CMID, bool GEMM, int NPH, int NS, int KH = 1>
+__global__ __launch_bounds__(256, KH == 2 ? 3 : 2) void wino_mid_kernel(WinoMidArgs a) {
   // (CIN % 128: mid_out_class walks the channel groups of 64 two at a time)
   static_assert(CIN % 128 == 0 && CMID % (64 * NS) == 0 && (GEMM || (CIN == CMID && NS == 1)), "whole waves of channels");
+  static_assert(KH == 1 || (KH == 2 && GEMM && CIN == 256), "k halves: the 256 -> 256 form");
   constexpr int CM = CMID / NS;                                   // output channels of this block
-  extern __shared__ __attribute__((aligned(16))) char lds[];      // [64 slots][max(CIN, CM)] fp32: x, then t in the same place
+  constexpr int XC = CIN / KH;                                    // channels per row of the x tile
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // [64 slots][max(XC, CM)] fp32: x (a k half of it), then t in the same place
   const int img = blockIdx.x;
   const int c_first = (int)blockIdx.y * CM;                       // first output channel of this block
   const int tid = threadIdx.x, lane = tid & 63;
@@ -133,22 +141,28 @@ __global__ __launch_bounds__(256, 2) void wino_mid_kernel(WinoMidArgs a) {
   // ---- stage A: wave w = class w (its 6x6 / 6x5 / 5x6 / 5x5 points), every channel group; the activation goes to HBM from the first
   //      of the NS blocks ----
   float* const xg = blockIdx.y == 0 ? a.x : nullptr;
-  if constexpr (GEMM) {
+  auto zero_tail = [&]() {
     // pixel slots 49 .. 63 of the x tile: stage A never writes them and stage B multiplies them (MFMA columns that are dropped behind
     // it) -- zeroed so that no uninitialised LDS word is ever read
-    for (int i = tid; i < 15 * CIN / 4; i += 256) reinterpret_cast<f32x4*>(lds + 49 * (CIN * 4))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  switch (wave) {
-    case 0: mid_out_class<NPH, 0, 0, CIN>(a, img, lane, lds, xg); break;
-    case 1: mid_out_class<NPH, 0, 1, CIN>(a, img, lane, lds, xg); break;
-    case 2: mid_out_class<NPH, 1, 0, CIN>(a, img, lane, lds, xg); break;
-    default: mid_out_class<NPH, 1, 1, CIN>(a, img, lane, lds, xg); break;
-  }
+    for (int i = tid; i < 15 * XC / 4; i += 256) reinterpret_cast<f32x4*>(lds + 49 * (XC * 4))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto stage_a = [&](auto half) {
+    constexpr int H = decltype(half)::value;
+    constexpr int G0 = KH == 2 ? 2 * H : 0, G1 = KH == 2 ? 2 * H + 2 : CIN / 64;
+    switch (wave) {
+      case 0: mid_out_class<NPH, 0, 0, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
+      case 1: mid_out_class<NPH, 0, 1, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
+      case 2: mid_out_class<NPH, 1, 0, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
+      default: mid_out_class<NPH, 1, 1, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
+    }
+  };
+  if constexpr (GEMM) zero_tail();
+  stage_a(std::integral_constant<int, 0>{});
   __syncthreads();
 
   if constexpr (GEMM) {
     // ---- stage B: t[ch][px] = relu(sum_k W1[ch][k] x[px][k] + b1[ch]); wave w owns the block's channels [w CM / 4, (w + 1) CM / 4) ----
-    constexpr int CT = CM / 64, PT = 4, KS = CIN / 16;              // channel tiles per wave, pixel tiles (49 of 64 slots used), k steps
+    constexpr int CT = CM / 64, PT = 4, KS = CIN / 16, KSH = KS / KH;  // channel tiles per wave, pixel tiles (49 of 64 slots used), k steps (per half)
     const int li = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1), 0, CMID * CIN * 4, 0x00020000);
     const int wvoff = ((c_first + wave * (CM / 4) + li) * CIN + 4 * kq) * 4;
@@ -159,45 +173,56 @@ __global__ __launch_bounds__(256, 2) void wino_mid_kernel(WinoMidArgs a) {
         w[ct] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
       }
     };
-    const char* const xrd = lds + li * (CIN * 4);                   // + pt * 16 rows, + chunk (4 s + kq) ^ li
+    const char* const xrd = lds + li * (XC * 4);                    // + pt * 16 rows, + chunk (4 s + kq) ^ li   (s within the half)
     auto x_load = [&](f32x4 (&x)[PT], const int s) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
-        x[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * (CIN * 4) + (((4 * s + kq) ^ li) << 4));
+        x[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * (XC * 4) + (((4 * s + kq) ^ li) << 4));
     };
     f32x4 acc[PT][CT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 wq[3][CT], xv[2][PT];
-    w_load(wq[0], 0);
-    if (KS > 1) w_load(wq[1], 1);
-    x_load(xv[0], 0);
+    // the k steps [s0, s0 + KSH) out of the tile in LDS (which holds the channels from 16 s0 on)
+    auto stage_b = [&](const int s0) {
+      f32x4 wq[3][CT], xv[2][PT];
+      w_load(wq[0], s0);
+      if (KSH > 1) w_load(wq[1], s0 + 1);
+      x_load(xv[0], 0);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s + 2 < KS) w_load(wq[(s + 2) % 3], s + 2);               // weights two steps ahead of their MFMAs (L2 latency)
-      if (s + 1 < KS) x_load(xv[(s + 1) & 1], s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const f32x4 (&w)[CT] = wq[s % 3];
-      const f32x4 (&x)[PT] = xv[s & 1];
+      for (int s = 0; s < KSH; ++s) {
+        if (s + 2 < KSH) w_load(wq[(s + 2) % 3], s0 + s + 2);         // weights two steps ahead of their MFMAs (L2 latency)
+        if (s + 1 < KSH) x_load(xv[(s + 1) & 1], s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 (&w)[CT] = wq[s % 3];
+        const f32x4 (&x)[PT] = xv[s & 1];
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].x, x[pt].x, acc[pt][ct], 0, 0, 0);
+          for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].x, x[pt].x, acc[pt][ct], 0, 0, 0);
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].y, x[pt].y, acc[pt][ct], 0, 0, 0);
+          for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].y, x[pt].y, acc[pt][ct], 0, 0, 0);
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].z, x[pt].z, acc[pt][ct], 0, 0, 0);
+          for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].z, x[pt].z, acc[pt][ct], 0, 0, 0);
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].w, x[pt].w, acc[pt][ct], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct].w, x[pt].w, acc[pt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    stage_b(0);
+    if constexpr (KH == 2) {
+      __syncthreads();                                              // every wave has read the first half of x
+      zero_tail();
+      stage_a(std::integral_constant<int, 1>{});
+      __syncthreads();
+      stage_b(KSH);
     }
     __syncthreads();                                                // every wave has read x: t takes its place
     // lane = (pixel slot li of tile pt, channels ch0 + 16 ct + 4 kq .. + 3)
@@ -235,22 +260,28 @@ hipError_t wino_mid_launch(const WinoMidArgs& a, hipStream_t st) {
   if (!wino_mid_supported(a.Cin, a.Cmid, gemm, a.phases_in) || a.n_img < 1 || !a.M || !a.V || (gemm && !a.b1) ||
       (a.x && (a.x_cs % 4 || a.x_coff % 4)))
     return hipErrorInvalidValue;
-#define OFFK_MID_LAUNCH(CI, CM, G, PH, NSP)                                                                        \
+#define OFFK_MID_LAUNCH_KH(CI, CM, G, PH, NSP, KHV)                                                                \
   {                                                                                                                \
-    constexpr int kLds = 64 * (CI > CM / NSP ? CI : CM / NSP) * 4;                                                 \
-    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_mid_kernel<CI, CM, G, PH, NSP>), kLds);        \
+    constexpr int kLds = 64 * (CI / KHV > CM / NSP ? CI / KHV : CM / NSP) * 4;                                     \
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_mid_kernel<CI, CM, G, PH, NSP, KHV>), kLds);   \
     if (e != hipSuccess) return e;                                                                                 \
-    hipLaunchKernelGGL((wino_mid_kernel<CI, CM, G, PH, NSP>), dim3(a.n_img, NSP), dim3(256), kLds, st, a);         \
+    hipLaunchKernelGGL((wino_mid_kernel<CI, CM, G, PH, NSP, KHV>), dim3(a.n_img, NSP), dim3(256), kLds, st, a);    \
   }
+#define OFFK_MID_LAUNCH(CI, CM, G, PH, NSP) OFFK_MID_LAUNCH_KH(CI, CM, G, PH, NSP, 1)
   // blocks per image (tools/bench_between.py, P = 384, device time): 128 -> 128: 20.8 us with one block per image, 18.7 with two;
-  // 256 -> 256: 56.8 / 60.1 / 61.3 us with 1 / 2 / 4 (its x tile is 64 KB whatever the split: two blocks per CU either way)
-  const int ns = a.nsplit > 0 ? a.nsplit : (gemm && a.Cin == 128 ? 2 : 1);
+  // 256 -> 256: 56.8 / 60.1 / 61.3 us with 1 / 2 / 4 (its x tile is 64 KB whatever the split: two blocks per CU either way); [r5] two
+  // blocks per image with the x tile in two k halves (32 KB, three blocks per CU): 51.9 us against 60.7 in the forward, bit-identical
+#ifndef OFFK_MID_NS256
+#define OFFK_MID_NS256 22     /* the 256 -> 256 form: blocks per image (1, 2, 4), or 22 = two blocks per image with the x tile in two k halves (60.7 -> 51.9 us at P = 384; 2: 64.0) */
+#endif
+  const int ns = a.nsplit > 0 ? a.nsplit : (gemm && a.Cin == 128 ? 2 : OFFK_MID_NS256);
   if (gemm && a.Cin == 128 && a.phases_in == 4) { if (ns == 2) OFFK_MID_LAUNCH(128, 128, true, 4, 2) else OFFK_MID_LAUNCH(128, 128, true, 4, 1) }
   else if (gemm && a.Cin == 128) { if (ns == 2) OFFK_MID_LAUNCH(128, 128, true, 1, 2) else OFFK_MID_LAUNCH(128, 128, true, 1, 1) }
-  else if (gemm) { if (ns == 4) OFFK_MID_LAUNCH(256, 256, true, 1, 4) else if (ns == 2) OFFK_MID_LAUNCH(256, 256, true, 1, 2) else OFFK_MID_LAUNCH(256, 256, true, 1, 1) }
+  else if (gemm) { if (ns == 4) OFFK_MID_LAUNCH(256, 256, true, 1, 4) else if (ns == 2) OFFK_MID_LAUNCH(256, 256, true, 1, 2) else if (ns == 22) OFFK_MID_LAUNCH_KH(256, 256, true, 1, 2, 2) else OFFK_MID_LAUNCH(256, 256, true, 1, 1) }
   else if (a.Cin == 128) OFFK_MID_LAUNCH(128, 128, false, 1, 1)
   else OFFK_MID_LAUNCH(256, 256, false, 1, 1)
 #undef OFFK_MID_LAUNCH
+#undef OFFK_MID_LAUNCH_KH
   return hipGetLastError();
 }
 
