@@ -720,7 +720,8 @@ def main():
     backend = None
     smoke = bool(args.collective_smoke) and world == 1
     if smoke:
-        init_single_rank_rccl(dev)
+        with stdout_to_stderr():
+            init_single_rank_rccl(dev)
         backend = dist.get_backend()
     coll = world > 1 or smoke            # the step ends with the score exchange
     if world > 1:
