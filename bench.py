@@ -19,13 +19,15 @@ Rank 0 prints ONE JSON line.
                                                       # exchange (all-gather AND the all-reduce form) inside the timed step --
                                                       # NOT a scaling number (a dev box has one GPU)
 
-What the line's `value` is: the library's fp32 mode (v_mfma_f32_* : fp32 products, fp32 accumulation -- the reference's
-arithmetic type; the k x k fusion convs run in Winograd forms, i.e. a different fp32 summation, measured ~1e-5 of max|ref|
-against the reference-pinned oracle) at the full --steps.  The split-fp32 mode of the same library (OFFK_PRECISION_F32SPLIT:
-every fp32 operand as three bf16 planes = the fp32 value exactly, six exact plane products on the bf16 matrix pipe, fp32
-accumulation -- the units kernel, the batched GEMMs of every conv on a Winograd path and the 1x1 convs on 7x7 maps: `split_launches`)
-is timed beside it as the named secondary object `f32split_mode`, with `error_vs_fp64` / `gemm_error_vs_fp64` for BOTH modes (the
-split mode's error against fp64 is the smaller one on every input kind).
+What the line's `value` is (round 6, VERDICT r05's ruling): the library's split-fp32 mode (OFFK_PRECISION_F32SPLIT: every fp32 operand
+as three bf16 planes = the fp32 value exactly, six exact plane products on the bf16 matrix pipe, fp32 accumulation -- the units kernel, the
+batched GEMMs of every conv on a Winograd path, the 1x1 convs on 7x7 maps; measured error against fp64 below the fp32 pipe's on every
+input kind, asserted in tests/test_gpu_split.py) at the full --steps.  The fp32-MFMA-pipe mode of the same library (v_mfma_f32_*) is timed
+beside it as `fp32_pipe_mode`.  `--precision fp32` swaps the two.
+
+Output: the ONE stdout line is a compact object (< 8 KB, `compact_line`, pinned by tests/test_bench_line.py); everything else
+(per-launch tables, stage times, both modes' error tables, the CPU baseline's operating points, units_training) goes to
+bench_detail.json next to this script and to stderr.
 """
 import argparse
 import contextlib
@@ -45,9 +47,12 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--length", type=int, default=7)
     ap.add_argument("--variant", choices=("rgb", "flow"), default="rgb")
-    ap.add_argument("--precision", choices=("fp32", "f32split"), default="fp32",
-                    help="arithmetic of the headline value (fp32 = the fp32 MFMA pipe; f32split = fp32 operands as three bf16 planes "
-                         "on the bf16 pipe, always reported beside it at N = 1 with both modes' measured error against fp64)")
+    ap.add_argument("--precision", choices=("fp32", "f32split"), default="f32split",
+                    help="arithmetic of the headline value (f32split = fp32 operands as three bf16 planes on the bf16 pipe, ruled "
+                         "fp32-equivalent in VERDICT r05; fp32 = the fp32 MFMA pipe); the other mode is always reported beside it at N = 1 "
+                         "with both modes' measured error against fp64")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), metavar="PATH",
+                    help="where rank 0 writes the full result object (the stdout line is its compact form)")
     ap.add_argument("--cpu-clips", type=int, default=64, help="clips in the large CPU-baseline sample (0 = skip the CPU baseline)")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the f32split / training / CPU-baseline objects")
     ap.add_argument("--collective", choices=("allgather", "allreduce"), default="allgather",
@@ -306,6 +311,10 @@ def chain_winograd_flops(P):
     return 2.0 * P * 49 * 16 * 64 * 64
 
 
+SPLIT_FRAC_OF = "six bf16 products per fp32 product / 2.5 PF dense bf16"
+SPLIT_1X1_LAUNCHES = ("merged_14a", "merged_7", "motion_conv1_trans_14b")
+
+
 def roofline_in_path(h, arr, out, B, L, precision, steps):
     """What bounds the kernels the DEFAULT forward launches: a third loop with the library's per-launch trace on (one HIP
     event in front of every launch group, heads folded back onto the main stream).  HBM-bound: the S-blocks of K2 (the only
@@ -324,7 +333,7 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
     unit_f, _fus = spec.flops_per_clip(L)
     hw = sum(H * H for _n, _c, H in spec.SITES)
     dw_f = 2.0 * P * hw * spec.DOWN_CH * 9
-    peak = MFMA_F32_PEAK_TFLOPS          # (f32split: the launches on the bf16 pipe are priced there in f32split_mode.split_launches)
+    peak = MFMA_F32_PEAK_TFLOPS          # (f32split: the launches on the bf16 pipe are priced against the bf16 peak, `frac_of` says so)
     kernels, small_ms, small_fl = [], 0.0, 0.0
     big = ("motion_conv_trans_28", "motion_conv_trans_14", "motion_conv_trans")
     for name, (ms, calls) in lt.items():
@@ -336,7 +345,7 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             if precision == "f32split" and name.startswith("units:pw_tdiff"):
                 # split-fp32: six bf16 plane products per fp32 product; the bound that matters beside the pipe is HBM (X in, T / D out)
                 nbytes = B * (sum(L * C * H * H for _n, C, H in spec.SITES) + (L - 1) * hw * (spec.GEN_CH + spec.DOWN_CH)) * 4
-                rec.update(frac=6.0 * fl / avg / 1e9 / BF16_DENSE_PEAK_TFLOPS, frac_of="six bf16 products per fp32 product / 2.5 PF dense bf16",
+                rec.update(frac=6.0 * fl / avg / 1e9 / BF16_DENSE_PEAK_TFLOPS, frac_of=SPLIT_FRAC_OF,
                            fp32_equivalent_over_fp32_pipe_peak=fl / avg / 1e9 / MFMA_F32_PEAK_TFLOPS,
                            algorithmic_bytes=nbytes, achieved_gbs=nbytes / avg / 1e6, hbm_frac=nbytes / avg / 1e6 / HBM_PEAK_GBS)
         elif name.startswith("units:sobel S-blocks"):
@@ -374,6 +383,9 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             elif "GEMMs" in name:
                 fl = winograd_gemm_flops(P, key)
                 rec.update(bound="mfma", flops=fl, direct_conv_flops=work[key], achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
+                if precision == "f32split":      # wino_gemm_split_kernel: six bf16 plane products per fp32 product on the bf16 pipe
+                    rec.update(frac=6.0 * fl / avg / 1e9 / BF16_DENSE_PEAK_TFLOPS, frac_of=SPLIT_FRAC_OF,
+                               fp32_equivalent_over_fp32_pipe_peak=fl / avg / 1e9 / MFMA_F32_PEAK_TFLOPS)
                 small_ms += avg if key not in big else 0.0
                 small_fl += work[key] if key not in big else 0.0
             else:
@@ -393,6 +405,9 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             rec.update(bound="mfma", flops=fl, achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
             if "executed_flops" in rec:
                 rec["executed_frac"] = rec["executed_flops"] / avg / 1e9 / peak
+            if precision == "f32split" and name in SPLIT_1X1_LAUNCHES:      # the 1x1 convs on 7x7 maps run in wino_gemm_split_kernel too
+                rec.update(frac=6.0 * fl / avg / 1e9 / BF16_DENSE_PEAK_TFLOPS, frac_of=SPLIT_FRAC_OF,
+                           fp32_equivalent_over_fp32_pipe_peak=fl / avg / 1e9 / MFMA_F32_PEAK_TFLOPS)
             if name not in big:
                 small_ms += avg
                 small_fl += fl
@@ -588,22 +603,22 @@ def split_vs_fp32_forward(B, L, variant, weights, dev, kinds=("synth", "full_man
     return out
 
 
-def flow_variant(B, L, dev, steps, warmup, measure):
-    """BASELINE config 3: Flow_OFF forward (Flow_OFF.py:606-876), batch = 64, fp32, consensus inside."""
+def flow_variant(B, L, dev, steps, warmup, measure, precision):
+    """BASELINE config 3: Flow_OFF forward (Flow_OFF.py:606-876), batch = 64, consensus inside, in the headline's arithmetic."""
     w = synth.make_weights(spec.VARIANT_FLOW)
     f = [torch.from_numpy(x).to(dev) for x in synth.make_features(B, L, config_id=3)]
-    h, dt, _s, _k = measure("fp32", steps, warmup, variant=spec.VARIANT_FLOW, weights=w, feats=f, consensus=True, k2=False)
+    h, dt, _s, _k = measure(precision, steps, warmup, variant=spec.VARIANT_FLOW, weights=w, feats=f, consensus=True, k2=False)
     del h
     return {"workload": "Flow_OFF forward (fixed diagonal Sobel, SegmentConsensus avg), batch=%d clips x %d segments" % (B, L),
             "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-            "dtype": DTYPES["fp32"]}
+            "precision": precision, "dtype": DTYPES[precision]}
 
 
-def two_stream_leg(B, L, dev, steps, warmup, rgb_feats, rgb_weights):
+def two_stream_leg(B, L, dev, steps, warmup, rgb_feats, rgb_weights, precision):
     """BASELINE config 5, the per-GPU leg: RGB-OFF and Flow-OFF forwards of the same clips on two HIP streams, then K7
     (offk_score_fusion) over the six score sets with the notebook's weights (score_fusion.ipynb lines 300-301)."""
     from offk_amd import two_stream
-    ts = two_stream.TwoStreamOFF(B, L, precision="fp32", device=dev)
+    ts = two_stream.TwoStreamOFF(B, L, precision=precision, device=dev)
     ts.load_state_dicts(rgb_weights, synth.make_weights(spec.VARIANT_FLOW, seed=0xF10))
     ff = [torch.from_numpy(x).to(dev) for x in synth.make_features(B, L, config_id=3)]
     tsn_r = torch.from_numpy(synth.uniform_values(0x7501, B * spec.NUM_CLASSES, 4.0).reshape(B, -1)).to(dev)
@@ -618,7 +633,7 @@ def two_stream_leg(B, L, dev, steps, warmup, rgb_feats, rgb_weights):
     return {"workload": "RGB_OFF + Flow_OFF forwards of the same %d clips x %d segments on two HIP streams + K7 late fusion "
                         "(6 score sets incl. both TSN scores) + argmax" % (B, L),
             "value": B * steps / dt, "unit": "clips/s (a clip = both streams)", "ms_per_step": dt / steps * 1e3,
-            "steps": steps, "warmup": warmup, "dtype": DTYPES["fp32"]}
+            "steps": steps, "warmup": warmup, "precision": precision, "dtype": DTYPES[precision]}
 
 
 @contextlib.contextmanager
@@ -647,62 +662,223 @@ def init_single_rank_rccl(dev):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
 
 
-def rccl_smoke_object(B, L, variant, weights, feats, dev, steps):
-    """Secondary object of the default N = 1 line: the per-step score exchange of config 4 executed on RCCL
-    with a single-rank group on the one GPU of the box -- librccl init, `all_gather_into_tensor` and the zero-buffer `all_reduce`
-    form, both through offk_amd.dist, behind a consensus forward.  NOT a scaling number.  Failures are recorded, not raised: the
-    headline measurement above does not depend on RCCL."""
-    rec = {"what": "single-rank RCCL smoke, not a scaling number", "world_size": 1}
+def rccl_smoke_object(B, L, variant, weights, feats, dev, steps, precision, form_used):
+    """Secondary object of the default N = 1 line: the per-step score exchange of config 4 executed on RCCL with a single-rank group on the
+    one GPU of the box -- librccl init, then EACH form of the exchange alone behind a consensus forward (the real N > 1 step issues one of
+    them): `all_gather_into_tensor`, and the zero-buffer `all_reduce`, both through offk_amd.dist, asynchronous (two alternating buffer
+    sets) and, for comparison with rounds <= 4, synchronous.  NOT a scaling number.  Failures are recorded, not raised: the headline
+    measurement does not depend on RCCL."""
+    rec = {"what": "single-rank RCCL smoke, not a scaling number", "world_size": 1, "precision": precision}
     try:
         if not dist.is_initialized():
             with stdout_to_stderr():      # (device_id = eager communicator: RCCL's banner comes with the init)
                 init_single_rank_rccl(dev)
         rec["backend"] = dist.get_backend()
-        h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, True, device=dev, precision="fp32")
+        h = runtime.OffForward(B, L, variant, spec.SLICE_FLAT, True, device=dev, precision=precision)
         h.load_state_dict(weights)
         arr = h._feat_array(feats)
         ncls = spec.NUM_CLASSES
         local = [torch.empty(3, B, ncls, device=dev) for _ in range(2)]
         gathered = [torch.empty(1, 3, B, ncls, device=dev) for _ in range(2)]
-        reduced = [torch.zeros(3, B, ncls, device=dev) for _ in range(2)]
-        xg, xr = odist.ScoreExchange(2), odist.ScoreExchange(2)
+        xg = odist.ScoreExchange(2)
         cnt = [0]
 
-        def step():
-            # both forms of the exchange behind every forward, asynchronously (dist.ScoreExchange): the next forward is not ordered
-            # behind this step's collectives; a buffer set is waited for only when it comes round again, two steps later
-            i = cnt[0] & 1
-            cnt[0] += 1
-            xg.wait_slot(i)
-            xr.wait_slot(i)
-            h.forward_into(arr, local[i][0], local[i][1], local[i][2])
-            xg.all_gather(i, gathered[i], local[i])
-            reduced[i].copy_(local[i])
-            xr.all_reduce(i, reduced[i])
+        def make_step(form, asynchronous):
+            def step():
+                i = cnt[0] & 1
+                cnt[0] += 1
+                xg.wait_slot(i)
+                h.forward_into(arr, local[i][0], local[i][1], local[i][2])
+                if form == "allgather":
+                    if asynchronous:
+                        xg.all_gather(i, gathered[i], local[i])
+                    else:
+                        odist.all_gather_scores_into(gathered[i], local[i])
+                elif form == "allreduce":     # world_size 1: this rank's rows ARE the zeroed [head][world * rows][class] buffer
+                    if asynchronous:
+                        xg.all_reduce(i, local[i])
+                    else:
+                        odist.all_reduce_scores_inplace(local[i])
+            return step
 
         def fence():
             xg.finish()
-            xr.finish()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
         with stdout_to_stderr():      # the first collective creates the communicator
-            for _ in range(3):
-                step()
+            for form in ("allgather", "allreduce"):
+                st = make_step(form, True)
+                for _ in range(3):
+                    st()
             fence()
-        dt = timed_loop(step, steps, fence)
-        # the plain step on the same handle, same loop: what the exchange costs the step
-        dt0 = timed_loop(lambda: h.forward_into(arr, local[0][0], local[0][1], local[0][2]), steps, torch.cuda.synchronize)
+        times = {}
+        for rep in range(2):          # two interleaved passes, the smaller of each: the differences are tens of microseconds
+            for key, form, asyn in (("plain", None, True), ("allgather", "allgather", True), ("allreduce", "allreduce", True),
+                                    ("allgather_sync", "allgather", False), ("allreduce_sync", "allreduce", False)):
+                t = timed_loop(make_step(form, asyn), steps, fence) / steps * 1e3
+                times[key] = min(times.get(key, t), t)
+        # correctness of both forms on the buffers of one more step each
+        make_step("allgather", True)()
+        fence()
         last = (cnt[0] - 1) & 1
-        rec.update(ms_per_step=dt / steps * 1e3, ms_per_step_without_exchange=dt0 / steps * 1e3,
-                   exchange_cost_us_per_step=(dt - dt0) / steps * 1e6, steps=steps, n_ranks_seen=dist.get_world_size(),
-                   per_step="consensus forward + all_gather_into_tensor + zero-buffer all_reduce, both async_op=True on two alternating "
-                            "buffer sets (the forward of step i + 1 is not ordered behind the exchange of step i)",
-                   exchange_ok=bool(torch.equal(gathered[last][0], local[last]) and torch.equal(reduced[last], local[last])))
+        ok = bool(torch.equal(gathered[last][0], local[last]))
+        want = local[last].clone()
+        xg.all_reduce(last, local[last])
+        fence()
+        ok = ok and bool(torch.equal(local[last], want))
+        rec.update(ms_per_step_without_exchange=times["plain"], ms_per_step_allgather=times["allgather"], ms_per_step_allreduce=times["allreduce"],
+                   allgather_us_per_step=(times["allgather"] - times["plain"]) * 1e3,
+                   allreduce_us_per_step=(times["allreduce"] - times["plain"]) * 1e3,
+                   allgather_sync_us_per_step=(times["allgather_sync"] - times["plain"]) * 1e3,
+                   allreduce_sync_us_per_step=(times["allreduce_sync"] - times["plain"]) * 1e3,
+                   form_used_by_gpus_N=form_used, mode="async_op=True, two alternating buffer sets (sync variants beside it in the detail file)",
+                   steps=steps, n_ranks_seen=dist.get_world_size(), exchange_ok=ok,
+                   per_step="consensus forward + ONE form of the exchange of the [3 heads][B][101] scores; each loop fenced by barrier + synchronize; "
+                            "min of two interleaved passes")
     except Exception as e:      # noqa: BLE001 -- a broken RCCL install must not take the headline line with it
         rec["error"] = "%s: %s" % (type(e).__name__, e)
     return rec
+
+
+LINE_LIMIT = 8192        # the driver keeps the last 8 KB of stdout: the one line must fit with room to spare (BENCH_r05: 22 KB -> parsed null)
+LINE_TARGET = 6000
+
+
+def _sig(x, n=5):
+    """Floats to n significant digits (the line is for reading and parsing, bench_detail.json keeps every digit)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (n, x))
+
+
+def _pick(d, keys):
+    return dict((k, _sig(d[k])) for k in keys if isinstance(d, dict) and k in d)
+
+
+def _worst(table, mode):
+    """error table {mode: {kind: {max_over_max, rms_over_max, c_max, c_rms}}} -> the worst max_over_max / c_max of a mode over the
+    non-cancellation kinds (the cancellation case is normalised by the output, not by the contraction: its own pair beside it)."""
+    rows = (table or {}).get(mode)
+    if not rows:
+        return None
+    plain = [v for k, v in rows.items() if k != "cancellation"] or list(rows.values())
+    out = {"max_over_max": _sig(max(v["max_over_max"] for v in plain), 3), "c_max": _sig(max(v["c_max"] for v in plain), 3)}
+    if "cancellation" in rows:
+        out["cancellation_c_max"] = _sig(rows["cancellation"]["c_max"], 3)
+    return out
+
+
+def _mode_object(full, mode):
+    """The compact per-mode object: value, ms_per_step, dtype, the units kernel's time and fraction, the mode's worst error against fp64."""
+    src = full if full.get("precision") == mode else full.get(("fp32_pipe" if mode == "fp32" else mode) + "_mode")
+    if not isinstance(src, dict):
+        return None
+    rec = _pick(src, ("value", "ms_per_step", "steps"))
+    rec["dtype"] = "f32 on v_mfma_f32_* (fp32 pipe)" if mode == "fp32" else "f32 as 3 bf16 planes x 6 exact products, f32 accumulate (bf16 pipe)"
+    uk = src.get("units_kernel")
+    if isinstance(uk, dict):
+        rec["units_kernel"] = {"us": _sig(uk["avg_ms"] * 1e3, 4), "frac": _sig(uk.get("frac"), 3),
+                               "of": "2.5 PF bf16 (6 products per fp32 product)" if mode == "f32split" else "157.3 TF fp32 MFMA"}
+        if "hbm_frac" in uk:
+            rec["units_kernel"]["hbm_frac"] = _sig(uk["hbm_frac"], 3)
+    e = _worst(full.get("error_vs_fp64"), mode)
+    if e:
+        rec["units_error_vs_fp64"] = e
+    e = _worst(full.get("gemm_error_vs_fp64"), mode)
+    if e:
+        rec["gemm_error_vs_fp64"] = e
+    if full.get("precision") == mode:
+        rec["headline"] = True
+    return rec
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line: what the driver parses (metric / value / ms_per_step / dtype / config / roofline / cpu_baseline) plus one small
+    object per secondary measurement.  `full` is the complete result object main() builds (-> bench_detail.json).  Always < LINE_LIMIT:
+    optional objects are dropped, last first, should it ever grow past LINE_TARGET."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(full.get("config", {}), ("workload", "global_batch", "segments", "parallelism", "slice_mode", "arithmetic"))
+    line.update(_pick(full, ("n_ranks_seen", "collective_backend", "exchange_ok", "exchange")))
+    rf = full.get("roofline")
+    if isinstance(rf, dict):
+        r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us",
+                       "min_launch_us", "launches", "on_default_forward_path"))
+        if isinstance(rf.get("in_path"), dict):
+            r["in_path"] = _pick(rf["in_path"], ("kernel", "achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch"))
+        line["roofline"] = r
+    ip = full.get("roofline_in_path")
+    if isinstance(ip, dict):
+        o = {}
+        if isinstance(ip.get("dominant"), dict):
+            o["dominant"] = _pick(ip["dominant"], ("launch", "avg_ms", "bound", "frac", "frac_of", "hbm_frac", "share_of_step"))
+        top = sorted((k for k in ip.get("kernels", []) if "avg_ms" in k), key=lambda k: -k["avg_ms"])[:6]
+        o["top_launches"] = [[k["launch"][:48], _sig(k["avg_ms"] * 1e3, 4), ("bf16-mfma" if "frac_of" in k else k.get("bound")), _sig(k.get("frac"), 3)]
+                             for k in top]
+        o["top_launches_columns"] = ["launch", "us", "bound (mfma = 157.3 TF fp32 pipe, bf16-mfma = 6 products / 2.5 PF, hbm = 8 TB/s)", "frac of that peak"]
+        o["n_launch_groups"] = len(ip.get("kernels", []))
+        line["roofline_in_path"] = o
+    if isinstance(full.get("mfma"), dict):
+        line["mfma"] = _pick(full["mfma"], ("peak_tflops", "executed_flops_per_step", "executed_frac_of_peak", "executed_frac_is"))
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "cpu_model", "kind", "sample", "usable_cpus", "host_logical_cpus"))
+        c["operating_points_clips_per_s"] = dict((k, _sig(cb[k]["value"], 4)) for k in ("batch_1", "batch_large", "concurrent_batch_1")
+                                                 if isinstance(cb.get(k), dict))
+        line["cpu_baseline"] = c
+        line["gpu_over_cpu"] = _sig(full.get("gpu_over_cpu"))
+    for mode, key in (("f32split", "f32split_mode"), ("fp32", "fp32_pipe_mode")):
+        m = _mode_object(full, mode)
+        if m:
+            line[key] = m
+    if isinstance(full.get("max_rel_diff_between_modes"), dict):
+        d = full["max_rel_diff_between_modes"]
+        line["max_rel_diff_between_modes"] = {"logits": _sig(max(v["logits"] for v in d.values()), 3),
+                                              "sum_7": _sig(max(v["sum_7"] for v in d.values()), 3)}
+    optional = []
+    for key in ("flow_variant", "two_stream"):
+        if isinstance(full.get(key), dict):
+            line[key] = _pick(full[key], ("value", "ms_per_step", "precision"))
+            optional.append(key)
+    sm = full.get("rccl_single_rank_smoke")
+    if isinstance(sm, dict):
+        line["rccl_single_rank_smoke"] = _pick(sm, ("backend", "n_ranks_seen", "exchange_ok", "ms_per_step_without_exchange", "allgather_us_per_step",
+                                                    "allreduce_us_per_step", "form_used_by_gpus_N", "mode", "error"))
+        optional.append("rccl_single_rank_smoke")
+    for key in ("single_rank_rccl_smoke", "oversubscribed"):
+        if isinstance(full.get(key), dict):
+            line[key] = _pick(full[key], ("backend", "world_size", "ranks", "gpus_visible", "note"))
+    if detail_path:
+        line["detail"] = detail_path
+    for key in reversed(optional + ["max_rel_diff_between_modes", "mfma"]):
+        if len(json.dumps(line)) <= LINE_TARGET:
+            break
+        line.pop(key, None)
+    if len(json.dumps(line)) >= LINE_LIMIT:      # cannot happen with the fields above; never hand the driver an unparseable line
+        for key in ("roofline_in_path", "fp32_pipe_mode", "f32split_mode"):
+            line.pop(key, None)
+    return line
+
+
+def emit(full, detail_path):
+    """Rank 0: full object -> detail file + stderr, compact object -> the one stdout line (last thing written)."""
+    where = None
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(full, f, indent=1)
+        where = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s (%s); the full object follows on stderr only\n" % (detail_path, e))
+    sys.stderr.write("bench.py full result object (also %s):\n%s\n" % (where, json.dumps(full)))
+    sys.stderr.flush()
+    text = json.dumps(compact_line(full, where))
+    assert len(text) < LINE_LIMIT, len(text)
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -906,7 +1082,7 @@ def main():
             "metric": "OFF-forward clips/sec (7-seg 224x224)", "value": clips_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPES[args.precision],
+            "dtype": DTYPES[args.precision], "precision": args.precision,
             "data": "synthetic (portable counter-based generator: ReLU-like non-negative BN-Inception "
                     "feature maps, fan-in-scaled uniform weights; features resident in HBM)",
             "config": {"workload": "%s_OFF forward, batch=%d clips/GPU x %d segments, nine 224x224-geometry "
@@ -914,10 +1090,12 @@ def main():
                        "global_batch": world * B, "segments": L, "parallelism": "clip-shard x%d" % world,
                        "slice_mode": "reference_flat",
                        "arithmetic": ("fp32 MFMA products, fp32 accumulation" if args.precision == "fp32" else
-                                      "split-fp32 units kernel (three bf16 planes per fp32 operand, six exact plane products on the bf16 pipe, "
-                                      "fp32 accumulation), every other kernel fp32 MFMA products") +
+                                      "split-fp32 (three bf16 planes per fp32 operand, six exact plane products on the bf16 pipe, fp32 accumulation) in the "
+                                      "units kernel, the Winograd GEMMs and the 1x1 convs on 7x7 maps; fp32 MFMA products in the kernels without a split form") +
                                      ("; the k x k fusion convs in Winograd forms (fp32 transforms)" if wino_on else "; direct convolutions")},
             "n_ranks_seen": dist.get_world_size() if coll else 1, "collective_backend": backend,
+            "exchange": ("async_op=True on two alternating buffer sets: the timed step does not wait for its own collective, only the "
+                         "closing fence does (round 5 on; earlier rounds' multi-rank ms_per_step had it inside every step)") if coll else None,
             "roofline": {"bound": "hbm", "kernel": "sobel_tdiff_kernel (K2: temporal difference + spatial gradient + concat, "
                                                    "all nine sites, one launch; offk_sobel_tdiff_all)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -944,15 +1122,16 @@ def main():
             "mfma": {"peak_tflops": peak_tf,
                      "executed_flops_per_step": exec_flops,
                      "executed_frac_of_peak": exec_flops / (ms_step * 1e-3) / 1e12 / peak_tf,
+                     "executed_frac_is": "fp32-equivalent FLOPs the matrix pipes execute (direct-conv FLOPs minus what the Winograd forms save) / "
+                                         "wall-clock ms_per_step / the fp32 MFMA peak 157.3 TF, per GPU" +
+                                         ("; in split-fp32 mode the units kernel, the Winograd GEMMs and the 7x7-map 1x1 convs run six bf16 plane "
+                                          "products per fp32 product on the 2.5 PF bf16 pipe, so this is a throughput-equivalent there, "
+                                          "not a utilisation" if args.precision == "f32split" else ""),
                      "algorithmic_flops_per_step": algo_flops,
                      "algorithmic_flops_over_peak": algo_flops / (ms_step * 1e-3) / 1e12 / peak_tf,
                      "algorithmic_tflops_over_summed_stage_time": algo_flops / (gpu_ms * 1e-3) / 1e12 if gpu_ms > 0 else 0.0,
-                     "note": "THE fraction to quote is executed_frac_of_peak: the FLOPs the matrix pipe is actually asked for (direct-conv "
-                             "FLOPs minus what the Winograd forms save: the 3x3 / stride 1 convs on 7x7 maps run 1 / 3.64 of their multiplies, "
-                             "the polyphase 5x5 / stride 2 conv 1 / 3.06, the polyphase 7x7 / stride 2 conv 1 / 4.7, the 3x3 inside a bottleneck "
-                             "chain 1 / 2.25) / the wall-clock "
-                             "ms_per_step / the fp32 MFMA peak (157.3 TF), per GPU (in f32split mode the units kernel's products run on the bf16 "
-                             "pipe: its own row of roofline_in_path prices them there).  "
+                     "note": "the Winograd forms: the 3x3 / stride 1 convs on 7x7 maps run 1 / 3.64 of their multiplies, the polyphase 5x5 / "
+                             "stride 2 conv 1 / 3.06, the polyphase 7x7 / stride 2 conv 1 / 4.7, the 3x3 inside a bottleneck chain 1 / 2.25.  "
                              "algorithmic_flops_over_peak counts DIRECT-convolution FLOPs instead: a throughput-equivalent, NOT a "
                              "utilisation -- it can exceed 1 under Winograd."},
         }
@@ -962,6 +1141,7 @@ def main():
                 in_path["dominant"] = {"launch": dom["launch"], "avg_ms": dom["avg_ms"], "bound": dom["bound"], "frac": dom["frac"],
                                        "share_of_step": dom["avg_ms"] / ms_step}
             res["roofline_in_path"] = in_path
+            res["units_kernel"] = next((k for k in in_path["kernels"] if k["launch"].startswith("units:pw_tdiff")), None)
         if coll:
             res["exchange_ok"] = exchange_ok
             if smoke:
@@ -977,52 +1157,54 @@ def main():
             other = "f32split" if args.precision == "fp32" else "fp32"
             _h2, dt2, st2, _k2 = measure(other, args.steps, args.warmup)
             sec = {"value": B * args.steps / dt2, "unit": "clips/s", "ms_per_step": dt2 / args.steps * 1e3,
-                   "steps": args.steps, "warmup": args.warmup, "dtype": DTYPES[other],
+                   "steps": args.steps, "warmup": args.warmup, "dtype": DTYPES[other], "precision": other,
                    "stage_ms": dict((k, v[0] / max(v[1], 1)) for k, v in st2.items())}
             ip2 = roofline_in_path(_h2, _h2._feat_array(feats), out, B, L, other, min(args.steps, 20))
             sec["units_kernel"] = next((k for k in ip2["kernels"] if k["launch"].startswith("units:pw_tdiff")), None)
-            if other == "f32split" and in_path is not None:
-                # every launch that runs in split-fp32 arithmetic in that mode (the units kernel, the batched GEMMs of every conv on a
-                # Winograd path, the 1x1 convs on 7x7 maps), with the same launch's time in the fp32 mode beside it
-                fp32_ms = dict((k["launch"], k["avg_ms"]) for k in in_path["kernels"])
-                rows = []
-                for k in ip2["kernels"]:
-                    nm = k["launch"]
-                    if not (nm.startswith("units:pw_tdiff") or "GEMMs]" in nm or nm in ("merged_14a", "merged_7", "motion_conv1_trans_14b")):
-                        continue
-                    if "flops" not in k:
-                        continue
-                    rows.append({"launch": nm, "avg_ms": k["avg_ms"], "fp32_mode_avg_ms": fp32_ms.get(nm), "flops_fp32_equivalent": k["flops"],
-                                 "fp32_equivalent_tflops": k["flops"] / k["avg_ms"] / 1e9,
-                                 "frac_of_bf16_peak": 6.0 * k["flops"] / k["avg_ms"] / 1e9 / BF16_DENSE_PEAK_TFLOPS,
-                                 "fp32_equivalent_over_fp32_pipe_peak": k["flops"] / k["avg_ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS})
-                sec["split_launches"] = {"kernels": rows, "sum_ms": sum(r["avg_ms"] for r in rows),
-                                         "sum_ms_fp32_mode": sum(r["fp32_mode_avg_ms"] or 0.0 for r in rows),
-                                         "note": "frac_of_bf16_peak = six bf16 plane products per fp32 product / 2.5 PF dense bf16; "
-                                                 "everything else in the forward (transforms, bottleneck chains, what sits between two "
-                                                 "Winograd convs, heads) is the same code in both modes"}
+            sec["roofline_in_path"] = ip2
             del _h2
-            sp = sec if other == "f32split" else res
-            sp["error_vs_fp64"] = split_error_vs_fp64(L, variant, weights, dev)
-            sp["gemm_error_vs_fp64"] = split_gemm_error_vs_fp64(dev)
-            sp["max_rel_diff_vs_fp32_mode"] = split_vs_fp32_forward(B, L, variant, weights, dev)
-            sp["error_note"] = ("error_vs_fp64 / gemm_error_vs_fp64: the units kernel / the batched GEMMs of a Winograd conv in BOTH modes against an fp64 contraction of "
-                                "the same fp32 inputs -- the split mode's error is the smaller one on every input kind (asserted in "
-                                "tests/test_gpu_split.py): the operands are represented exactly, the products are exact, the running sum is "
-                                "rounded once per 32 k where the fp32 pipe's FMA chain rounds it eight times.  max_rel_diff_vs_fp32_mode: "
-                                "the whole forward, one mode against the other (budget 1e-3)")
-            res[other + "_mode"] = sec
+            ip_split, ip_f32 = (ip2, in_path) if other == "f32split" else (in_path, ip2)
+            if ip_split is not None and ip_f32 is not None:
+                # every launch that runs in split-fp32 arithmetic in that mode (the units kernel, the batched GEMMs of every conv on a
+                # Winograd path, the 1x1 convs on 7x7 maps, the bottleneck chains), with the same launch's time in the fp32 mode beside it
+                fp32_ms = dict((k["launch"], k["avg_ms"]) for k in ip_f32["kernels"])
+                rows_ = []
+                for k in ip_split["kernels"]:
+                    nm = k["launch"]
+                    if "flops" not in k or abs(k["avg_ms"] - fp32_ms.get(nm, k["avg_ms"])) < 0.02 * k["avg_ms"] and not nm.startswith("units:pw_tdiff"):
+                        continue
+                    if not (nm.startswith("units:pw_tdiff") or "GEMMs]" in nm or nm.startswith("chain_") or "between]" in nm or
+                            nm in ("merged_14a", "merged_7", "motion_conv1_trans_14b")):
+                        continue
+                    rows_.append({"launch": nm, "avg_ms": k["avg_ms"], "fp32_mode_avg_ms": fp32_ms.get(nm), "flops_fp32_equivalent": k["flops"],
+                                  "fp32_equivalent_tflops": k["flops"] / k["avg_ms"] / 1e9,
+                                  "frac_of_bf16_peak": 6.0 * k.get("executed_flops", k["flops"]) / k["avg_ms"] / 1e9 / BF16_DENSE_PEAK_TFLOPS,
+                                  "fp32_equivalent_over_fp32_pipe_peak": k["flops"] / k["avg_ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS})
+                res["split_launches"] = {"kernels": rows_, "sum_ms": sum(r["avg_ms"] for r in rows_),
+                                         "sum_ms_fp32_mode": sum(r["fp32_mode_avg_ms"] or 0.0 for r in rows_),
+                                         "note": "frac_of_bf16_peak = six bf16 plane products per fp32 product / 2.5 PF dense bf16; "
+                                                 "everything else in the forward (transforms, heads) is the same code in both modes"}
+            res["error_vs_fp64"] = split_error_vs_fp64(L, variant, weights, dev)
+            res["gemm_error_vs_fp64"] = split_gemm_error_vs_fp64(dev)
+            res["max_rel_diff_between_modes"] = split_vs_fp32_forward(B, L, variant, weights, dev)
+            res["error_note"] = ("error_vs_fp64 / gemm_error_vs_fp64: the units kernel / the batched GEMMs of a Winograd conv in BOTH modes against an fp64 contraction of "
+                                 "the same fp32 inputs -- the split mode's error is the smaller one on every input kind (asserted in "
+                                 "tests/test_gpu_split.py): the operands are represented exactly, the products are exact, the running sum is "
+                                 "rounded once per 32 k where the fp32 pipe's FMA chain rounds it eight times.  max_rel_diff_between_modes: "
+                                 "the whole forward, one mode against the other (budget 1e-3)")
+            res[("fp32_pipe" if other == "fp32" else other) + "_mode"] = sec
             # BASELINE config 3 (Flow_OFF, B = 64, fixed diagonal Sobel + SegmentConsensus) and config 5's per-GPU leg (RGB + Flow
-            # on the same clips, two HIP streams, K7 late fusion incl. both TSN scores), both in the reference's fp32
-            res["flow_variant"] = flow_variant(B, L, dev, args.steps, args.warmup, measure)
-            res["two_stream"] = two_stream_leg(B, L, dev, args.steps, args.warmup, feats, weights)
+            # on the same clips, two HIP streams, K7 late fusion incl. both TSN scores), in the headline's arithmetic
+            res["flow_variant"] = flow_variant(B, L, dev, args.steps, args.warmup, measure, args.precision)
+            res["two_stream"] = two_stream_leg(B, L, dev, args.steps, args.warmup, feats, weights, args.precision)
             res["units_training"] = [units_training(B, L, variant, weights, feats, dev, "fp32")]
             if not coll:
-                res["rccl_single_rank_smoke"] = rccl_smoke_object(B, L, variant, weights, feats, dev, min(args.steps, 20))
+                res["rccl_single_rank_smoke"] = rccl_smoke_object(B, L, variant, weights, feats, dev, min(args.steps, 20), args.precision,
+                                                                  args.collective)
             if args.cpu_clips > 0:
                 res["cpu_baseline"] = cpu_baseline(feats_np, weights, L, variant, min(args.cpu_clips, B))
                 res["gpu_over_cpu"] = clips_s / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
+        emit(res, args.detail)
     if coll:
         dist.barrier()
     if dist.is_initialized():

@@ -101,7 +101,7 @@ def check_isa(obj, code_objects):
 ASM_SCHEDULED_KERNELS = (
     ("pw_tdiff.hip", r"^offk::pw_tdiff16_kernel\(", 128, True, "four blocks per CU (4 waves / SIMD x 128 = 512; 4 x 29 KB of LDS)"),
     ("pw_tdiff_split.hip", r"^offk::pw_tdiff_split_kernel\(", 256, True,
-     "two blocks per CU (2 waves / SIMD; 52 KB of LDS each); its weight / feature loads are asm with hand-counted vmcnt waits"),
+     "two blocks per CU (2 waves / SIMD; 80 KB of LDS each); its weight loads and feature-map DMAs are asm with hand-counted vmcnt waits"),
     ("chain_fused.hip", r"^void offk::chain14_kernel<", 168, False, "three blocks per CU (52.5 KB of LDS each)"),
     ("wino_gemm.hip", r"^offk::wino_gemm_kernel\(", 128, True, "four blocks per CU (32 KB of LDS each); counts its epilogue's sixteen stores (vmcnt(16))"),
     ("conv_igemm.hip", r"^void offk::conv_igemm_kernel<\d, \d, \d, 1, 1, 2, 2, 4>", 128, False,
@@ -187,6 +187,85 @@ def check_counted_store_waits(src_name, code_objects):
     return rows
 
 
+# ---- counted waits of the split units kernel --------------------------------------------------------------------------
+# pw_tdiff_split_kernel orders its asm loads (weights -> registers, feature map -> LDS by DMA) with three counted waits per K-tile step;
+# each count rests on the step issuing EXACTLY this sequence of vector-memory instructions and nothing else (a compiler-added VMEM
+# instruction -- spill, scratch -- would make a wait cover the wrong operations):
+#     s_waitcnt vmcnt(7) | 6 register loads (Wg), 3 LDS-DMA (pieces 0-2) | s_waitcnt vmcnt(9) | 1 LDS-DMA (piece 3), 3 register loads (Wd) | s_barrier
+# Checked on the disassembly for every step body (the loop is unrolled by two + a tail step); and no v_mov / v_accvgpr may read a
+# register an in-flight load of the step writes before the wait that covers it (a copy of a load destination = stale operands).
+# (source file, regex on the mangled symbol, first wait, ops, second wait, ops)
+COUNTED_LOAD_STEPS = (("pw_tdiff_split.hip", r"pw_tdiff_split_kernel", 7, ("r",) * 6 + ("d",) * 3, 9, ("d",) + ("r",) * 3),)
+_LOAD_RE = re.compile(r"^buffer_load_dwordx4\s+(?:v\[(\d+):(\d+)\]|v(\d+)),.*?(\blds\b)?$")
+
+
+def counted_load_steps(body, w1, ops1, w2, ops2):
+    """body: instructions of one kernel.  Returns the number of step bodies found; raises on a malformed one."""
+    steps = 0
+    i = 0
+    while i < len(body):
+        if not re.match(r"s_waitcnt\b.*vmcnt\(%d\)" % w1, body[i]):
+            i += 1
+            continue
+        j, seq, inflight = i + 1, [], []
+        phase, ok = 0, False
+        while j < len(body):
+            ins = body[j]
+            if ins.startswith("s_barrier"):
+                ok = phase == 1
+                break
+            if re.match(r"s_waitcnt\b.*vmcnt\(%d\)" % w2, ins) and phase == 0:
+                if tuple(seq) != tuple(ops1):
+                    raise RuntimeError("between vmcnt(%d) and vmcnt(%d): VMEM sequence %s, expected %s" % (w1, w2, "".join(seq), "".join(ops1)))
+                phase, seq = 1, []
+            elif re.match(r"s_waitcnt\b.*vmcnt\(", ins):
+                break                                           # some other wait: not a step body (prologue / epilogue)
+            elif _VMEM_RE.match(ins):
+                m = _LOAD_RE.match(ins)
+                if not m:
+                    raise RuntimeError("unexpected vector-memory instruction inside a step: %s" % ins)
+                if ins.rstrip().endswith("lds"):
+                    seq.append("d")
+                else:
+                    seq.append("r")
+                    inflight.append((int(m.group(1)), int(m.group(2))))
+            elif re.match(r"v_(mov_b32|accvgpr_\w+)\b", ins):
+                srcs = [int(x) for x in re.findall(r"\bv(\d+)\b", ins.split(",", 1)[1] if "," in ins else "")]
+                for lo, hi in inflight:
+                    if any(lo <= r <= hi for r in srcs):
+                        raise RuntimeError("copy of an in-flight load destination inside a step: %s" % ins)
+            j += 1
+        if ok:
+            if tuple(seq) != tuple(ops2):
+                raise RuntimeError("between vmcnt(%d) and the step's barrier: VMEM sequence %s, expected %s" % (w2, "".join(seq), "".join(ops2)))
+            steps += 1
+        i = j
+    return steps
+
+
+def check_counted_load_steps(src_name, code_objects):
+    for src, pat, w1, ops1, w2, ops2 in COUNTED_LOAD_STEPS:
+        if src != src_name:
+            continue
+        found = 0
+        for path in code_objects:
+            d = subprocess.run([_llvm_objdump(), "-d", path], capture_output=True, text=True)
+            body, inside = [], False
+            for ln in d.stdout.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+                if m:
+                    inside = re.search(pat, m.group(1)) is not None
+                    continue
+                if inside and ln.strip():
+                    body.append(ln.split("//")[0].strip())
+            try:
+                found += counted_load_steps(body, w1, ops1, w2, ops2)
+            except RuntimeError as e:
+                raise RuntimeError("counted-load guard failed in %s (%s): %s" % (src_name, pat, e))
+        if found < 2:
+            raise RuntimeError("counted-load guard: %d step bodies found in %s of %s, expected >= 2 (renamed? update COUNTED_LOAD_STEPS)" % (found, pat, src_name))
+
+
 # A VALU write to a data register of a 12- / 16-byte store in the instruction directly behind the store: on MI355X the new value reached
 # memory in some lanes (wino_gemm_split.hip, round 5: lanes 12-15 of every sixteen, run-to-run varying).  LLVM's hazard recogniser
 # places the wait state only when the store has no SGPR offset; hipcc had re-used the first data register for the next address.
@@ -195,17 +274,32 @@ _VALU_DST_RE = re.compile(r"^v_(?!cmp|cmpx|readlane|readfirstlane)\w+\s+(?:v\[(\
 
 
 def store_data_hazards(disassembly):
+    """A wide store followed -- directly, or with ONE non-VALU instruction (an SALU op, an s_nop 0) in between -- by a VALU write to one
+    of its data registers.  profiles/r05/probe_store_hazard.txt: with an SGPR soffset one wait state cures it, with a constant soffset
+    (the case LLVM's recogniser handles itself) two are needed; the scan covers both distances so that neither rests on the recogniser.
+    `s_nop N` with N >= 1 between the two ends the window (that is the cure)."""
     body = [ln.split("//")[0].strip() for ln in disassembly.splitlines()]
     body = [b for b in body if b and not b.endswith(":")]
     bad = []
-    for a, b in zip(body, body[1:]):
+    for i, a in enumerate(body):
         m = _WIDE_STORE_RE.match(a)
-        d = _VALU_DST_RE.match(b) if m else None
-        if not d:
+        if not m:
             continue
-        lo, hi = (int(d.group(3)),) * 2 if d.group(3) else (int(d.group(1)), int(d.group(2)))
-        if lo <= int(m.group(2)) and hi >= int(m.group(1)):
-            bad.append("%s  ||  %s" % (a, b))
+        for dist in (1, 2):
+            if i + dist >= len(body):
+                break
+            b = body[i + dist]
+            nop = re.match(r"s_nop\s+(\d+)", b)
+            if nop and int(nop.group(1)) + 1 >= 3 - dist:      # wait states left to cover: 2 at distance 1, 1 at distance 2
+                break
+            d = _VALU_DST_RE.match(b)
+            if d:
+                lo, hi = (int(d.group(3)),) * 2 if d.group(3) else (int(d.group(1)), int(d.group(2)))
+                if lo <= int(m.group(2)) and hi >= int(m.group(1)):
+                    bad.append("%s  ||  %s" % (a, b))
+                break                                          # a VALU instruction fills the window whatever it writes... only the first one is looked at
+            if b.startswith("v_") or _WIDE_STORE_RE.match(b):
+                break
     return bad
 
 
@@ -260,6 +354,7 @@ def check_object(obj):
         kernels = [k for co in cos for k in kernel_resources(co)]
         check_resources(src, kernels)
         check_counted_store_waits(src, cos)
+        check_counted_load_steps(src, cos)
     finally:
         for path in cos:
             os.remove(path)

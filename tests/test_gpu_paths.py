@@ -24,7 +24,7 @@ import offk_amd  # noqa: F401
 from offk_amd import spec, synth
 from oracle import off_oracle as orc
 
-from .test_gpu_parity import GOLDEN, RTOL, RTOL_NORTH_STAR, dev, make_handle, rel_err, rt, signal_err  # noqa: F401
+from .test_gpu_parity import GOLDEN, HANDLE_PRECISIONS, RTOL, RTOL_NORTH_STAR, dev, make_handle, rel_err, rt, signal_err  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -56,13 +56,15 @@ def launches_of(h, feats):
     return names
 
 
+@pytest.mark.parametrize("prec", HANDLE_PRECISIONS)
 @pytest.mark.parametrize("tag", GOLDEN)
-def test_goldens_through_the_gated_kernels(rt, tag, golden_dir, monkeypatch):
+def test_goldens_through_the_gated_kernels(rt, tag, golden_dir, monkeypatch, prec):
     """All seven reference goldens with every pair-count gate forced open: the reference's own outputs (fc7 / fc14 / fc28) and the
-    oracle's stage tensors after chain14_kernel, the polyphase 5x5 and the 7x7 Winograd kernels."""
+    oracle's stage tensors after chain14_kernel, the polyphase 5x5 and the 7x7 Winograd kernels -- in both arithmetic modes (split-fp32:
+    the GEMMs of both polyphase convs and the chains' contractions on the bf16 pipe see reference-held outputs here)."""
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
     variant, B, L, cfg = (int(v) for v in g["meta"])
-    h, w = forced_handle(rt, monkeypatch, B, L, variant, consensus=False)
+    h, w = forced_handle(rt, monkeypatch, B, L, variant, consensus=False, precision=prec)
     feats_np = synth.make_features(B, L, cfg)
     feats = [dev(f) for f in feats_np]
     names = launches_of(h, feats)
@@ -78,7 +80,7 @@ def test_goldens_through_the_gated_kernels(rt, tag, golden_dir, monkeypatch):
                                    return_stages=True)
     P = B * (L - 1)
     errs = stage_errs(h, st, P)
-    print("%s gates open: stage errors %s" % (tag, " ".join("%s %.1e" % kv for kv in errs.items())))
+    print("%s %s gates open: stage errors %s" % (tag, prec, " ".join("%s %.1e" % kv for kv in errs.items())))
     assert max(errs.values()) < RTOL, errs
     if P >= 2:
         for out, key in ((out7, "fc7"), (out14, "fc14"), (out28, "fc28")):
@@ -86,17 +88,18 @@ def test_goldens_through_the_gated_kernels(rt, tag, golden_dir, monkeypatch):
             assert se < RTOL_NORTH_STAR, (key, se)
 
 
+@pytest.mark.parametrize("prec", HANDLE_PRECISIONS)
 @pytest.mark.parametrize("kind", ["full_mantissa", "heavy_tail"])
 @pytest.mark.parametrize("mode", ["gates_open_p18", "default_gates_p72"])
-def test_stress_inputs_through_the_gated_kernels(rt, kind, mode, monkeypatch):
+def test_stress_inputs_through_the_gated_kernels(rt, kind, mode, monkeypatch, prec):
     """Full-mantissa / heavy-tailed maps (synth.make_features_kind) through the chain and polyphase-Winograd kernels: at B = 3
     with the gates forced open, and at B = 12 (P = 72) where the default gates select them."""
     B, L = (3, 7) if mode == "gates_open_p18" else (12, 7)
     feats_np = synth.make_features_kind(B, L, 3, kind)
     if mode == "gates_open_p18":
-        h, w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB)
+        h, w = forced_handle(rt, monkeypatch, B, L, spec.VARIANT_RGB, precision=prec)
     else:
-        h, w = make_handle(rt, B, L, spec.VARIANT_RGB)
+        h, w = make_handle(rt, B, L, spec.VARIANT_RGB, precision=prec)
     feats = [dev(f) for f in feats_np]
     names = launches_of(h, feats)
     assert any(n.startswith("chain_28a") for n in names) and any(n.startswith("motion_conv_trans_14 [winograd") for n in names), names
@@ -108,26 +111,38 @@ def test_stress_inputs_through_the_gated_kernels(rt, kind, mode, monkeypatch):
     errs = stage_errs(h, st, P)
     lerr = [rel_err(a, b) for a, b in zip(got, want)]
     sig = signal_err(got[0], want[0])
-    print("forward fp32 on %s maps, %s: logits %.2e %.2e %.2e, stages %s, fc7 row-to-row signal %.2e"
-          % ((kind, mode) + tuple(lerr) + (" ".join("%.1e" % v for v in errs.values()), sig)))
+    print("forward %s on %s maps, %s: logits %.2e %.2e %.2e, stages %s, fc7 row-to-row signal %.2e"
+          % ((prec, kind, mode) + tuple(lerr) + (" ".join("%.1e" % v for v in errs.values()), sig)))
     assert max(lerr) < RTOL and max(errs.values()) < RTOL and sig < RTOL_NORTH_STAR
 
 
+_ORACLE_B64 = {}
+
+
+def oracle_b64(variant, feats_np, w):
+    """The oracle's B = 64 forward with stage tensors (~25 s of host time): once per variant, shared by both arithmetic modes."""
+    if variant not in _ORACLE_B64:
+        with torch.no_grad():
+            _ORACLE_B64[variant] = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, 64, 7, variant, orc.SLICE_FLAT, consensus=False,
+                                                   return_stages=True)
+    return _ORACLE_B64[variant]
+
+
+@pytest.mark.parametrize("prec", HANDLE_PRECISIONS)
 @pytest.mark.parametrize("variant", [spec.VARIANT_RGB, spec.VARIANT_FLOW])
-def test_full_size_b64_stage_tensors_vs_oracle(rt, variant):
+def test_full_size_b64_stage_tensors_vs_oracle(rt, variant, prec):
     """BASELINE configs 2 / 3 at full size (B = 64, P = 384 -- where every gated kernel runs by default): the fusion-stage tensors
-    against the oracle, beside the logit checks of test_full_size_b64_vs_oracle / test_flow_full_size_b64_vs_oracle."""
+    against the oracle, beside the logit checks of test_full_size_b64_vs_oracle / test_flow_full_size_b64_vs_oracle; both arithmetic modes
+    against the ORACLE (not against each other)."""
     B, L = 64, 7
     feats_np = synth.make_features(B, L, 2 if variant == spec.VARIANT_RGB else 3)
-    h, w = make_handle(rt, B, L, variant, consensus=False)
+    h, w = make_handle(rt, B, L, variant, consensus=False, precision=prec)
     got = h.forward([dev(f) for f in feats_np])
     torch.cuda.synchronize()
-    with torch.no_grad():
-        want, st = orc.off_forward([torch.from_numpy(f) for f in feats_np], w, B, L, variant, orc.SLICE_FLAT, consensus=False,
-                                   return_stages=True)
+    want, st = oracle_b64(variant, feats_np, w)
     P = B * (L - 1)
     errs = stage_errs(h, st, P)
-    print("full size variant %d: stage errors %s" % (variant, " ".join("%s %.1e" % kv for kv in errs.items())))
+    print("full size variant %d %s: stage errors %s" % (variant, prec, " ".join("%s %.1e" % kv for kv in errs.items())))
     assert max(errs.values()) < RTOL, errs
     for a, b in zip(got, want):
         assert rel_err(a, b) < RTOL and signal_err(a, b) < RTOL_NORTH_STAR

@@ -229,3 +229,41 @@ def test_forward_split_gemms_against_fp32_pipe_gemms(rt, monkeypatch, B):
     for name, ch in (("sum_7", 1024), ("fusion_7", 832)):
         x, y = h1.region(name, ch), h0.region(name, ch)
         assert ((x - y).abs().max() / y.abs().max()).item() < 5e-5, name
+
+
+# ---- the whole forward of both modes against an fp64 evaluation of the oracle ----
+
+@pytest.mark.parametrize("case", ["rgb_golden_inputs", "flow_golden_inputs", "rgb_heavy_tail"])
+def test_whole_forward_error_vs_fp64_oracle(rt, case):
+    """oracle/off_oracle.py evaluated in fp64 (torch CPU, the same op sequence on double tensors: RGB_OFF.py:596-847) on the inputs of the
+    B = 3 x 7 goldens (synth.make_features(3, 7, cfg) -- what gen_golden.py fed the reference) and on heavy-tailed maps: the error of
+    `sum_7` and of the three logit tensors of BOTH arithmetic modes.  The split mode may not be further from fp64 than the fp32 pipe is
+    (10 % slack: what both share -- the fp32 Winograd transforms -- dominates the whole-forward error and is the same code)."""
+    from oracle import off_oracle as orc
+    B, L = 3, 7
+    variant = spec.VARIANT_FLOW if case.startswith("flow") else spec.VARIANT_RGB
+    cfg = 2 if variant == spec.VARIANT_RGB else 3
+    feats_np = synth.make_features_kind(B, L, cfg, "heavy_tail" if case.endswith("heavy_tail") else "synth")
+    wnp = synth.make_weights(variant)
+    w64 = dict((k, v.double()) for k, v in orc.to_torch_weights(wnp).items())
+    with torch.no_grad():
+        ref, st = orc.off_forward([torch.from_numpy(f).double() for f in feats_np], w64, B, L, variant, orc.SLICE_FLAT, consensus=False,
+                                  return_stages=True)
+    P = B * (L - 1)
+    errs = {}
+    for prec in ("fp32", "f32split"):
+        h = rt.OffForward(B, L, variant, spec.SLICE_FLAT, False, precision=prec)
+        assert h.load_state_dict(wnp) == []
+        out = h.forward([dev(f) for f in feats_np])
+        torch.cuda.synchronize()
+        s7 = h.region("sum_7", 1024).view(P, 7, 7, 1024).permute(0, 3, 1, 2).double().cpu()
+        e7 = (s7 - st["sum_7"]).abs()
+        el = [(o.double().cpu() - r).abs() for o, r in zip(out, ref)]
+        sig = [(r - r.mean(0, keepdim=True)).abs().max() for r in ref]      # the logits are bias-dominated: normalise by the row-to-row signal
+        errs[prec] = {"sum_7_max": (e7.max() / st["sum_7"].abs().max()).item(), "sum_7_rms": ((e7 ** 2).mean().sqrt() / st["sum_7"].abs().max()).item(),
+                      "logit_signal_max": max((e.max() / s).item() for e, s in zip(el, sig))}
+        print("whole forward %-8s %-18s vs fp64 oracle: sum_7 max %.2e rms %.2e, logits / row-to-row signal %.2e"
+              % (prec, case, errs[prec]["sum_7_max"], errs[prec]["sum_7_rms"], errs[prec]["logit_signal_max"]))
+        assert errs[prec]["sum_7_max"] < 2e-4 and errs[prec]["logit_signal_max"] < 1e-3
+    for key in ("sum_7_max", "sum_7_rms", "logit_signal_max"):
+        assert errs["f32split"][key] <= 1.1 * errs["fp32"][key], (key, errs)
