@@ -72,10 +72,17 @@ enum offk_precision {
    *  retired in ABI v9 -- offk_create rejects it -- in favour of the exact three-plane mode below) */
   OFFK_PRECISION_F32SPLIT = 2 /* fp32 arithmetic on the bf16 matrix pipe: each fp32 operand cut into THREE bf16 planes
                                (8 + 8 + 8 significand bits = the fp32 value exactly), the six plane products above
-                               2^-24 of the leading one on v_mfma_f32_16x16x32_bf16, summed per 32-k step from zero
-                               and added to the fp32 accumulator once per step.  Measured error against fp64 no
-                               larger than the fp32 pipe's own on every parity distribution; kernels
-                               that have no split form yet run exactly as in OFFK_PRECISION_FP32. */
+                               2^-24 of the leading one on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (units kernel:
+                               the leading product and the five small ones in two running accumulators, added once; batched
+                               GEMMs: summed per 32-k step from zero and added to the accumulator once per step).  Measured
+                               error against fp64 no larger than the fp32 pipe's own on every parity distribution
+                               (DESIGN.md); kernels that have no split form run exactly as in OFFK_PRECISION_FP32.
+                               Non-finite inputs: the cut of +-Inf leaves Inf - Inf = NaN in the lower planes, so every
+                               output such an operand touches is NaN where the fp32 pipe gives +-Inf (or NaN): non-finite
+                               in both modes, but not the same non-finite value.  Tiny inputs: a plane below the bf16
+                               normal range is a bf16 subnormal, which the MFMA honours (tools/probe_split_mfma.hip part
+                               2); a plane below 2^-133 (the last bf16 subnormal) is lost -- only operands below 2^-109
+                               in magnitude have such planes (tests/test_gpu_split.py::test_split_nonfinite_and_tiny_inputs). */
 };
 
 typedef struct offk_config {

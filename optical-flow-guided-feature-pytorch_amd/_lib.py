@@ -10,7 +10,7 @@ NUM_STAGES = 6
 STAGE_NAMES = ("pw_reduce", "sobel_tdiff", "fusion_28", "fusion_14", "fusion_7", "heads")
 
 CONV_RELU_IN, CONV_RELU_PRE, CONV_RELU_POST = 1, 2, 4
-PRECISION_FP32, PRECISION_BF16X3 = 0, 1
+PRECISION_FP32, PRECISION_F32SPLIT = 0, 2
 PRECISIONS = {"fp32": 0, "f32split": 2}      # (1 was "bf16x3", retired in ABI v9)
 
 

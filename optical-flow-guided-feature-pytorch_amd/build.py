@@ -229,7 +229,7 @@ def counted_load_steps(body, w1, ops1, w2, ops2):
                 else:
                     seq.append("r")
                     inflight.append((int(m.group(1)), int(m.group(2))))
-            elif re.match(r"v_(mov_b32|accvgpr_\w+)\b", ins):
+            elif re.match(r"v_(mov_b32|accvgpr_)", ins):
                 srcs = [int(x) for x in re.findall(r"\bv(\d+)\b", ins.split(",", 1)[1] if "," in ins else "")]
                 for lo, hi in inflight:
                     if any(lo <= r <= hi for r in srcs):
@@ -269,7 +269,8 @@ def check_counted_load_steps(src_name, code_objects):
 # A VALU write to a data register of a 12- / 16-byte store in the instruction directly behind the store: on MI355X the new value reached
 # memory in some lanes (wino_gemm_split.hip, round 5: lanes 12-15 of every sixteen, run-to-run varying).  LLVM's hazard recogniser
 # places the wait state only when the store has no SGPR offset; hipcc had re-used the first data register for the next address.
-_WIDE_STORE_RE = re.compile(r"^(?:buffer|global|flat)_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
+# (the DATA registers: the first operand of a buffer store, the second of a global / flat store -- whose first is the address pair)
+_WIDE_STORE_RE = re.compile(r"^(?:buffer_store_dwordx[34]\s+|(?:global|flat)_store_dwordx[34]\s+v\[\d+:\d+\],\s*)v\[(\d+):(\d+)\]")
 _VALU_DST_RE = re.compile(r"^v_(?!cmp|cmpx|readlane|readfirstlane)\w+\s+(?:v\[(\d+):(\d+)\]|v(\d+))(?=[,\s]|$)")
 
 
@@ -400,7 +401,11 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr)
-        check_object(o)
+        try:
+            check_object(o)
+        except Exception:
+            os.remove(o)          # a refused object must not pass for a current one on the next build
+            raise
         return o
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:

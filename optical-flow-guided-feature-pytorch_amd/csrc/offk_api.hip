@@ -99,17 +99,6 @@ const ConvSpec kConvs[kNumConvs] = {
 // re-derived from the B = 42 sweep beats this table at P = 384 (5.221 vs 5.253 ms, same box) and an in-situ sweep started
 // from it finds nothing better (profiles/r03/tune_b64_fp32_from_heuristic.txt): exact fp32 has no P = 384 table any more;
 // {-1, 0} = automatic)
-// same sweep with --precision 1 (bf16x3 core)
-const int kTunedP384B3[kNumConvs][2] = {
-    {1, 6}, {1, 1}, {7, 1}, {3, 1}, {3, 1}, {1, 1}, {1, 1}, {3, 1}, {3, 1}, {1, 1}, {1, 1},   // fusion @28
-    {0, 8}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {4, 1}, {3, 1}, {7, 1},                           // fusion @14
-    {7, 4}, {4, 1}, {7, 1}, {3, 1}, {3, 1}};                                                   // fusion @7
-// tile_cfg 7 = the LDS-patch kernel (64 channels per block), 10 = its half-chunk form.  Round 2, after the generic kernel got
-// the buffer-addressed loader (tools/tune_forward.py, profiles/r02/tune_bf16x3_lean.txt): the generic tiles with split-K win
-// the 7x7 (128x64, split 6) back from the half-chunk patch kernel (5x5: 128x128, split 8); cfg 7 keeps the 3x3 convs at 7x7
-// (128->512, 832->256, 256->256: a tie with the generic tiles in the sweep, ahead in bench.py) and takes the 3x3 64->64 of block 28a
-// (re-tuned inside the whole forward with tools/tune_forward.py after the bf16x3 kernels were bounded to 128
-// VGPRs: the 128x128 tile now runs two blocks per CU and wins the 5x5 back from 64x128)
 // (main 1x1, branch 1x1) pairs whose outputs are summed: RGB_OFF.py:663-666, :768-770, :839-841
 struct MergedSpec { const char* name; int main_id, branch_id; };
 const MergedSpec kMerged[3] = {{"merged_28a", C3_28A, CB_28A}, {"merged_14a", C3_14A, CE_14A}, {"merged_7", C3_7, CB_7}};
@@ -121,14 +110,10 @@ const int kTunedP240[kNumConvs][2] = {   // round 3: the two entries an in-situ 
     {3, 2}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0},
     {4, 4}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0},
     {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}, {-1, 0}};
-const int kTunedP240B3[kNumConvs][2] = {
-    {1, 2}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {1, 1},
-    {0, 12}, {3, 1}, {3, 1}, {3, 1}, {3, 1}, {3, 2}, {3, 1}, {3, 1},
-    {7, 2}, {4, 1}, {3, 1}, {3, 1}, {3, 1}};
-// plans of the three merged 1x1 convs (kMerged order): [P == 240][bf16x3][conv] = {tile_cfg, splitk}
-const int kMergedPlan[2][2][3][2] = {
-    {{{3, 1}, {3, 1}, {3, 1}}, {{3, 1}, {4, 1}, {0, 1}}},                                         // P = 384 (and the default)
-    {{{1, 1}, {3, 1}, {3, 1}}, {{4, 1}, {1, 1}, {0, 1}}}};                                               // P = 240
+// plans of the three merged 1x1 convs (kMerged order): [P == 240][conv] = {tile_cfg, splitk}
+const int kMergedPlan[2][3][2] = {
+    {{3, 1}, {3, 1}, {3, 1}},                                         // P = 384 (and the default)
+    {{1, 1}, {3, 1}, {3, 1}}};                                        // P = 240
 struct HeadSpec { const char* key; int C; };
 const HeadSpec kHeads[3] = {{"fc_action_motion", 1024}, {"fc_action_motion_28", 256}, {"fc_action_motion_14", 512}};
 const char* kSobelKey = "sobel_edge_diagonal.conv.weight";
@@ -159,7 +144,6 @@ struct offk_handle {
   float* pw_wt16s[kNumSites] = {};  // ... as three bf16 planes for the split-fp32 form (OFFK_PRECISION_F32SPLIT; 1.5 x the floats)
   bool split_gemm = false;          // a split-fp32 handle runs the Winograd GEMMs with Co % 128 == 0 in split-fp32 too (OFFK_SPLIT_GEMM=0: fp32 pipe)
   int split_gemm_skip = 0;          // (tuning builds: OFFK_SPLIT_GEMM_SKIP, bit k = wino_u[k] stays on the fp32 pipe)
-  int split_pc = 0;                 // OFFK_SPLIT_PC=2 in builds with -DOFFK_WITH_PC (tools): the producer / consumer experiment
   bool f32split = false;            // created with OFFK_PRECISION_F32SPLIT: cfg.precision is OFFK_PRECISION_FP32 inside the library, the
                                     // kernels that have a split form take it
   bool pw_dirty = true;
@@ -563,7 +547,6 @@ int run_off_units_fused(offk_handle* h, hipStream_t st, const offk_feat_parts fe
   // the operand-order weight image is the library's own copy: not with contraction weights bound in place
   pt.bdirect = 1;
   pt.f32split = h->f32split;
-  pt.split_pc = h->split_pc;
   for (int s = 0; s < kNumSites; ++s)
     if (h->bnd_gen_w[s] || h->bnd_down_w[s]) pt.bdirect = 0;
   const char* fus[3] = {"fusion_28", "fusion_14", "fusion_7"};
@@ -736,13 +719,12 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   h->N = cfg->batch * cfg->length;
   h->P = cfg->batch * (cfg->length - 1);
   for (int c = 0; c < kNumConvs; ++c) {
-    const bool b3 = false;
-    const int (*tab)[2] = h->P == 384 ? (b3 ? kTunedP384B3 : nullptr) : h->P == 240 ? (b3 ? kTunedP240B3 : kTunedP240) : nullptr;
+    const int (*tab)[2] = h->P == 240 ? kTunedP240 : nullptr;      // (P = 384: the automatic plans, see above)
     h->conv_cfg[c] = tab ? tab[c][0] : -1;
     h->conv_splitk[c] = tab ? tab[c][1] : 0;
   }
   for (int m = 0; m < 3; ++m) {
-    const int (*mp)[2] = kMergedPlan[h->P == 240][0];
+    const int (*mp)[2] = kMergedPlan[h->P == 240];
     h->merged_cfg[m] = mp[m][0];
     h->merged_sk[m] = mp[m][1];
   }
@@ -814,7 +796,6 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   //   OFFK_WINO_GEMM     the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); 0: one block of the generic 1x1 kernel per
   //                      tile (bit-identical).  The handle-less stage entry points read it once per process.
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
-  { const char* e = getenv("OFFK_SPLIT_PC"); if (e && *e >= '0' && *e <= '2') h->split_pc = *e - '0'; }
   { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINO_MID"); h->wino_mid = !(e && *e == '0'); }
@@ -1223,7 +1204,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   };
   // 3x3 / stride 1 conv on 7x7 maps (phases = 1) or the 5x5 / stride 2 conv on 14x14 maps in polyphase form (phases = 4) on the
   // Winograd path: input transform, batched GEMMs, output transform with the conv's epilogue (winograd.hip)
-  const bool wino = h->winograd && h->cfg.precision == OFFK_PRECISION_FP32;
+  const bool wino = h->winograd;
   float* const wino_V = wino ? region(h, ws, "wino_v") : nullptr;
   float* const wino_M = wino ? region(h, ws, "wino_m") : nullptr;
   // the three steps of a conv on that path: V = B^T x B (wino_V), M = V U per point (wino_M), y = epilogue(A^T M A)
@@ -1309,7 +1290,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   };
   // (from P = 72 pairs: a chain block walks its three convs alone -- 45 us per launch however few blocks there are; B = 8: three
   //  convs per chain 0.885 ms per forward against 0.90, B = 16: 1.37 against 1.345; OFFK_CHAIN=<pairs> moves the gate)
-  const bool chained = h->chain && P >= h->chain_min_p && h->cfg.precision == OFFK_PRECISION_FP32 && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
+  const bool chained = h->chain && P >= h->chain_min_p && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
   if (chained) {
     TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
               nullptr, sa, 256, 0));                                                              // :658-667

@@ -18,7 +18,7 @@ constexpr int kGenCh = 128, kDownCh = 32, kUnitCh = 160;
 struct ConvDesc {
   const float* x; int x_cs, x_coff;
   int n_img, H, W, Ci;
-  const float* w;     // precision 0: fp32 [Co][K] in the library K order; precision 1: bf16 hi plane then lo plane
+  const float* w;     // fp32 [Co][K] in the library K order
   const float* bias;
   int Co, KH, KW, stride, pad;
   const float* res; int res_cs, res_coff;
@@ -27,7 +27,7 @@ struct ConvDesc {
   int tile_cfg = -1, splitk = 0;          // < 0 / < 1: pick automatically
   float* partial = nullptr;               // split-K slab scratch
   size_t partial_floats = 0;
-  int precision = 0;                      // 0 = exact fp32 MFMA, 1 = bf16x3
+  int precision = 0;                      // 0 = the fp32 MFMA pipe (the only value since ABI v9; split-fp32 is a handle property)
   int co_limit = 0;                       // > 0: store only output channels < co_limit (weights padded to Co); needs splitk == 1
   int batch = 1;                          // > 1: that many independent problems of this shape in one launch (1x1 only): problem b
   long long x_bstride = 0, w_bstride = 0, y_bstride = 0;   //   reads x + b * x_bstride, w + b * w_bstride, writes y + b * y_bstride (floats)
@@ -128,7 +128,7 @@ struct PwSite {
   const float* xp[4];
   int cp[4];
   int nparts;
-  const float* w;     // motion_conv_gen rows [128][C] (fp32), or the same rows pre-split for bf16x3: [128][C/32][hi 32 | lo 32] bf16
+  const float* w;     // motion_conv_gen rows [128][C] (fp32)
   const float* w_down;   // motion_spatial_down rows [32][C], same format as w (the library's packed copy keeps them adjacent;
                          // weights bound with offk_bind_weight live wherever the caller's parameters do)
   const float* bias;  // [128]
@@ -155,7 +155,7 @@ struct PtSite {
   const float* xp[4];   // feature map parts, NCHW (as PwSite)
   int cp[4];
   int nparts;
-  const float* w;       // gen rows [128][C] fp32, or pre-split for bf16x3 (as PwSite)
+  const float* w;       // gen rows [128][C] fp32
   const float* w_down;  // down rows [32][C]
   const float* wt;      // (kernel-local: the image the kernel reads -- wt16 or wt16s)
   const float* wt16;    // PtParams.bdirect: all 160 rows in the operand order of the 16-pixel form (pw_pack_direct16_launch), read straight into registers
@@ -183,7 +183,6 @@ struct PtParams {
   int nsites, total_blocks;
   int B, L, P, slice_mode, tgroups;
   int f32split;              // with bdirect: the split-fp32 form (pw_tdiff_split.hip) instead of pw_tdiff16_kernel
-  int split_pc;              // builds with -DOFFK_WITH_PC only (tools/experiments/pw_tdiff_pc.hip): 2 = the producer / consumer form (OFFK_SPLIT_PC=2)
   int bdirect;               // every site carries wt16 (/ wt16s): the weight operand bypasses LDS -- the 16-pixel forms (pw_tdiff16_kernel,
                              // pw_tdiff_split_kernel); 0 (weights bound in the caller's tensors): the fallback pw_tdiff_kernel
   const float* zeros;
@@ -198,12 +197,6 @@ hipError_t pw_pack_direct16_launch(const float* w160, int C, float* out, hipStre
 // pw_tdiff_split.hip: out = 160 * C * 6 bytes; p with the 16-pixel form's block layout (pw_tdiff_launch fills it and calls this)
 hipError_t pw_pack_split16_launch(const float* w160, int C, void* out, hipStream_t st);
 hipError_t pw_tdiff_split_launch(const PtParams& p, hipStream_t st);
-#ifdef OFFK_WITH_PC
-// tools/experiments/pw_tdiff_pc.hip (NOT in the product build): the same arithmetic and tile as ONE persistent block of eight waves per CU
-// (four producer waves stream and cut the feature map, four consumer waves multiply); n_cu = the grid.  Measured 1.07 ms against the
-// two-blocks-per-CU form's 0.90 ms (profiles/r05/split_units_producer_consumer.txt): recorded and dropped.
-hipError_t pw_tdiff_pc_launch(const PtParams& p, int n_cu, hipStream_t st);
-#endif
 
 // ---- K2 ------------------------------------------------------------------------
 struct StSite {
@@ -283,7 +276,7 @@ struct WgSite {
 struct WgParams {
   WgSite s[kNumSites];
   int nsites, total_blocks, L, P, slice_mode, kt_per_blk;
-  int precision;        // 0 = exact fp32 MFMA, 1 = bf16x3
+  int precision;        // 0 = the fp32 MFMA pipe
   int dbg;              // ablation bits for tools (1: no X loads, 2: no dG loads)
   const float* zeros;   // >= 16 bytes of zeros in device memory: what a masked-out load reads
 };

@@ -736,10 +736,6 @@ hipError_t pw_tdiff_launch(const PtParams& p_in, hipStream_t st) {
   else hipLaunchKernelGGL((pw_tdiff_kernel<kNT, 0>), dim3(p.total_blocks), dim3(256), LDS, st, p);
 #endif
   if (form16 && p.f32split) {
-#ifdef OFFK_WITH_PC
-    static const int n_cu = [] { int d = 0; hipDeviceProp_t pr; return hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
-    if (p.split_pc == 2) return pw_tdiff_pc_launch(p, n_cu, st);
-#endif
     return pw_tdiff_split_launch(p, st);
   }
   OFFK_PT_LAUNCH(kStage32)

@@ -64,3 +64,33 @@ def test_store_data_hazard_scanner(build_mod):
     assert build_mod.store_data_hazards(hit.replace("v_add_u32_e32 v42,", "v_cmp_le_i32_e32 vcc,")) == []
     assert build_mod.store_data_hazards(hit.replace("\n  v_add", "\n  s_nop 1\n  v_add")) == []
     assert build_mod.store_data_hazards(hit.replace("dwordx4 v[42:45]", "dwordx2 v[42:43]")) == []
+    # one SALU instruction between the store and the VALU write is still inside the window; an `s_nop 1` is the cure
+    assert len(build_mod.store_data_hazards(hit.replace("\n  v_add", "\n  s_mov_b32 s4, s5\n  v_add"))) == 1
+    assert build_mod.store_data_hazards(hit.replace("\n  v_add", "\n  s_mov_b32 s4, s5\n  s_nop 0\n  v_add")) == []
+
+
+def test_counted_load_guard_of_the_split_units_kernel(build_mod):
+    """pw_tdiff_split_kernel's three counted waits per K-tile step rest on the step issuing exactly 6 register loads + 3 LDS-DMAs, then
+    1 LDS-DMA + 3 register loads: the guard accepts that sequence and refuses an extra VMEM instruction, a missing one, and
+    a copy of a register an in-flight load writes."""
+    wg = ["buffer_load_dwordx4 v[%d:%d], v204, s[44:47], s94 offen" % (52 + 4 * i, 55 + 4 * i) for i in range(6)]
+    dma = ["buffer_load_dwordx4 v240, s[52:55], s94 offen lds"] * 4
+    wd = ["buffer_load_dwordx4 v[%d:%d], v204, s[44:47], s52 offen" % (36 + 4 * i, 39 + 4 * i) for i in range(3)]
+    mf = "v_mfma_f32_16x16x32_bf16 v[188:191], v[12:15], v[218:221], v[188:191]"
+    step = ["s_waitcnt vmcnt(7)"] + [x for w in wg for x in (mf, w)] + [x for d in dma[:3] for x in (mf, d)] + ["s_waitcnt vmcnt(9)", mf, dma[3], mf] + wd + ["s_barrier"]
+    args = (7, ("r",) * 6 + ("d",) * 3, 9, ("d",) + ("r",) * 3)
+    assert build_mod.counted_load_steps(step + step, *args) == 2
+    with pytest.raises(RuntimeError, match="VMEM sequence"):
+        build_mod.counted_load_steps(step[:5] + ["buffer_load_dwordx4 v[4:7], v1, s[0:3], 0 offen"] + step[5:], *args)
+    with pytest.raises(RuntimeError, match="VMEM sequence"):
+        build_mod.counted_load_steps([s for s in step if s != wd[0]], *args)
+    with pytest.raises(RuntimeError, match="unexpected vector-memory"):
+        build_mod.counted_load_steps(step[:5] + ["scratch_store_dword off, v3, s32"] + step[5:], *args)
+    with pytest.raises(RuntimeError, match="in-flight load destination"):
+        build_mod.counted_load_steps(step[:4] + ["v_mov_b32_e32 v9, v53"] + step[4:], *args)
+
+
+def test_store_data_hazard_scanner_reads_the_data_operand_of_global_stores(build_mod):
+    g = "  global_store_dwordx4 v[18:19], v[52:55], off offset:192\n  v_pk_add_f32 v[18:19], v[122:123], v[146:147]\n"
+    assert build_mod.store_data_hazards(g) == []                      # the ADDRESS pair is free once the store has issued
+    assert len(build_mod.store_data_hazards(g.replace("v_pk_add_f32 v[18:19]", "v_pk_add_f32 v[54:55]"))) == 1

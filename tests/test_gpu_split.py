@@ -34,13 +34,6 @@ def dev(x):
     return torch.as_tensor(x).to("cuda").contiguous()
 
 
-@pytest.fixture
-def split_form():
-    """(Round 5 also ran these tests on a producer / consumer form of the kernel, OFFK_SPLIT_PC=2 -- tools/experiments/pw_tdiff_pc.hip,
-    bit-identical and slower; it is no longer in the product build.)"""
-    return "0"
-
-
 def make_handle(rt, B, L, precision, weights=None, variant=spec.VARIANT_RGB):
     h = rt.OffForward(B, L, variant, spec.SLICE_FLAT, None, precision=precision)
     w = synth.make_weights(variant) if weights is None else weights
@@ -106,7 +99,7 @@ def run_units(rt, B, L, precision, feats_np, weights=None):
 
 
 @pytest.mark.parametrize("kind", KINDS)
-def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind, split_form):
+def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind):
     B, L = 2, 7
     feats_np = synth.make_features_kind(B, L, 4, kind)
     stats = {}
@@ -126,7 +119,7 @@ def test_units_split_error_is_no_larger_than_the_fp32_pipes(rt, kind, split_form
     assert stats["f32split"]["max_over_max"] < 2e-6 and stats["f32split"]["c_max"] < 16.0
 
 
-def test_units_split_cancellation_case(rt, split_form):
+def test_units_split_cancellation_case(rt):
     """tests/test_gpu_parity.py::test_pw_reduce_cancellation_case on the fused kernels: every channel of a pixel carries the
     same value and every weight row sums to zero -- the exact G is relu(bias), the exact T is 0, the exact D is the bias."""
     B, L = 2, 7
@@ -152,7 +145,7 @@ def test_units_split_cancellation_case(rt, split_form):
 
 
 @pytest.mark.parametrize("B,L", [(1, 2), (3, 3), (2, 9), (5, 7)])
-def test_units_split_shapes(rt, B, L, split_form):
+def test_units_split_shapes(rt, B, L):
     """Short clips (frames past the group read zeros), two temporal groups (L = 9), odd batches (packed 14x14 leftovers, the 7x7
     quad stream crossing clip boundaries): every T and D element against fp64."""
     feats_np = synth.make_features(B, L, 5)
@@ -267,3 +260,27 @@ def test_whole_forward_error_vs_fp64_oracle(rt, case):
         assert errs[prec]["sum_7_max"] < 2e-4 and errs[prec]["logit_signal_max"] < 1e-3
     for key in ("sum_7_max", "sum_7_rms", "logit_signal_max"):
         assert errs["f32split"][key] <= 1.1 * errs["fp32"][key], (key, errs)
+
+
+def test_split_nonfinite_and_tiny_inputs(rt):
+    """what include/offk.h states next to OFFK_PRECISION_F32SPLIT.  +-Inf in an operand: NaN in every output it touches (the
+    fp32 pipe: +-Inf or NaN) and nowhere else; operands down to 2^-100 (all three planes still bf16 normals or subnormals): the same result
+    as the fp32 pipe to the usual error."""
+    batch, M, K, Co = 2, 64, 128, 64
+    x, w = gemm_inputs(batch, M, K, Co, "normal", 3)
+    x[0, 5, 17] = float("inf")
+    x[1, 9, 3] = float("-inf")
+    y = rt.batched_gemm_nt(dev(x), dev(w), "f32split").cpu()
+    y32 = rt.batched_gemm_nt(dev(x), dev(w), "fp32").cpu()
+    bad = torch.zeros(batch, M, dtype=torch.bool)
+    bad[0, 5] = bad[1, 9] = True
+    assert torch.isnan(y[bad]).all() and not torch.isfinite(y32[bad]).any()
+    assert torch.isfinite(y[~bad]).all() and torch.isfinite(y32[~bad]).all()
+    ref = torch.einsum("bmk,bnk->bmn", x.double(), w.double())
+    assert ((y[~bad].double() - ref[~bad]).abs().max() / ref[~bad].abs().max()).item() < 1e-6
+    # tiny operands: x scaled by 2^-100 (planes down to 2^-116: bf16 normals), w by 2^-20 -- products ~2^-120, sums fp32 normals
+    xs, ws = gemm_inputs(batch, M, K, Co, "normal", 4)
+    xs, ws = xs * 2.0 ** -100, ws * 2.0 ** -20
+    yt = rt.batched_gemm_nt(dev(xs), dev(ws), "f32split").double().cpu()
+    reft = torch.einsum("bmk,bnk->bmn", xs.double(), ws.double())
+    assert ((yt - reft).abs().max() / reft.abs().max()).item() < 1e-6
