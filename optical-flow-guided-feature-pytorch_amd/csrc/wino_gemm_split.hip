@@ -1,7 +1,9 @@
 // K4gs: the batched GEMMs of a convolution on a Winograd path (wino_gemm.hip: M[point] = V[point] . U[point]^T) in split-fp32
 // arithmetic on the bf16 matrix pipe -- the arithmetic of pw_tdiff_split.hip: every fp32 operand as three bf16 planes (h + m + l = the
-// value, exactly), six plane products per multiply on v_mfma_f32_16x16x32_bf16, the six products of a 32-k step summed from ZERO in a
-// scratch tile that is added to the running accumulator once per step.  Reference arithmetic: the fp32 contractions of
+// value, exactly), six plane products per multiply on v_mfma_f32_16x16x32_bf16 into TWO running accumulators per tile (round 6: the leading
+// product w_h x_h in one, the five small ones in the other, added once per item -- tools/probe_split_mfma.hip mode 6; round 5 summed the
+// six products of a 32-k step from zero in a scratch tile and folded it into one accumulator per step: the same registers, 4 NT more
+// vector adds per step).  Reference arithmetic: the fp32 contractions of
 // RGB_OFF.py:762, 766, 775-777, 833, 837 in their Winograd forms (winograd.hip).
 //
 // Structure.  One persistent launch (as wino_gemm.hip: a block works through its items (point, m-tile, n-tile) as one stream of
@@ -25,7 +27,7 @@
 #include "offk_internal.h"
 
 #ifndef OFFK_GS_EXP
-#define OFFK_GS_EXP 0      /* timing experiments (tools/build_one.py -DOFFK_GS_EXP=mask): 1 no cut, 2 no folds, 4 no U loads, 8 no V loads, 16 U from one K-tile */
+#define OFFK_GS_EXP 0      /* timing experiments (tools/build_one.py -DOFFK_GS_EXP=mask): 1 no cut, 4 no U loads, 8 no V loads, 16 U from one K-tile */
 #endif
 
 namespace offk {
@@ -188,9 +190,9 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
   };
   constexpr int CUT_SLICES = 7;
 
-  f32x4 acc[NT];
+  f32x4 acc[NT], acs[NT];          // acc: sum w_h x_h (and, in store_item, the item's result); acs: the five small products
 #pragma unroll
-  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NT; ++i) { acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   auto mf = [&](f32x4 c, const u32x4& a, const u32x4& b) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   };
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
   const int st_voff = (li * y_rs + CT * wave * 16 + 4 * lg) * 4;
   auto store_item = [&]() {
     const int ybase = c_ysoff + (c_m0 * y_rs + c_n0) * 4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] += acs[i];
     if (EPI) {
       // + bias, ReLU
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
       OFFK_SB;
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; ++i) { acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   };
 
   // ---- prologue: V(0) cut into stage 0, V(1) in registers, U(0) in registers ----
@@ -283,7 +287,6 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
   // set ST ^ 1) into plane stage ST ^ 1; V two tiles ahead into register set ST; U of the next tile into set ST ^ 1.
   auto step = [&](const int ST) -> bool {
     u32x4 xb[4][3];
-    f32x4 t[NT];
     const char* const rd = xrd + ST * GS_STAGE;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) xb[rt][0] = *reinterpret_cast<const u32x4*>(rd + rt * GS_RT);
@@ -292,11 +295,10 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) xb[rt][1] = *reinterpret_cast<const u32x4*>(rd + rt * GS_RT + GS_PLANE);
     OFFK_SB;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // planes 0 = h, 1 = m, 2 = l; smallest products first: w_l x_h, w_h x_l, w_m x_m, w_m x_h, w_h x_m, w_h x_h
     constexpr int WP[6] = {2, 0, 1, 1, 0, 0}, XP[6] = {0, 2, 1, 0, 1, 0};
     // the step's side jobs -- V loads [2], cut slices [14], U loads [3 CT] -- go out behind the MFMAs of the first five products, in
-    // that order, job j behind MFMA j * NS / NJ; the last product's MFMAs are followed by the folds (NT / 2 tiles behind)
+    // that order, job j behind MFMA j * NS / NJ
     constexpr int NJ = 2 + 3 * CT + 2 * CUT_SLICES, NS = 5 * NT;
 // (the U loads LAST, planes l, m, h: the registers of the current tile's planes come free in that order -- w_l behind the first
     //  product, w_m behind the fourth -- which keeps the kernel at 162 VGPRs = three blocks per CU; with the loads at the top of the step
@@ -306,26 +308,20 @@ __global__ __launch_bounds__(256, OFFK_GS_BLOCKS) void wino_gemm_split_kernel(Wi
       else if (j < 2 + 2 * CUT_SLICES) { if (!(OFFK_GS_EXP & 1)) { const int c = j - 2; cut_slice(c % CUT_SLICES, ST ^ 1, c / CUT_SLICES, ST ^ 1); } }
       else if (!(OFFK_GS_EXP & 4)) { const int u = j - 2 - 2 * CUT_SLICES; load_u(ST ^ 1, (u % CT) * 3 + 2 - u / CT); }
     };
-    auto fold = [&](const int i) {
-      if (OFFK_GS_EXP & 2) acc[i] = t[i]; else acc[i] += t[i];
-      asm volatile("" : "+v"(acc[i]));
-    };
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int n = q * NT + i, rt = i / CT, ct = i % CT;
-        t[i] = mf(q == 0 ? z : t[i], wr[ST][ct][WP[q]], xb[rt][XP[q]]);
+        if (q < 5) acs[i] = mf(acs[i], wr[ST][ct][WP[q]], xb[rt][XP[q]]);
+        else acc[i] = mf(acc[i], wr[ST][ct][WP[q]], xb[rt][XP[q]]);
         if (n < NS) {
 #pragma unroll
           for (int j = (n * NJ + NS - 1) / NS; j < ((n + 1) * NJ + NS - 1) / NS; ++j) job(j);
-        } else if (i >= NT / 2) fold(i - NT / 2);
+        }
         OFFK_SB;
       }
     }
-#pragma unroll
-    for (int i = NT / 2; i < NT; ++i) fold(i);
-    OFFK_SB;
     // cursors: the multiply, then U, then V (an item's descriptors are handed down in that order)
     ++c_t;
     bool go_on = true;
