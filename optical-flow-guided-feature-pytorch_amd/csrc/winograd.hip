@@ -84,10 +84,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
                                                          float* __restrict__ V) {
   constexpr int W = NPH == 1 ? 7 : 14;
   const int cw = (Ci + 63) >> 6;
-  // a contiguous range of waves (= whole images) per XCD (blocks b, b + 8, ... share one): see wino7_input_kernel
-  const int wid = __builtin_amdgcn_readfirstlane((int)(((unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 256u + threadIdx.x) >> 6));
+  const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
   if (wid >= 4 * n_img * NPH * cw) return;
-  // image-major: the four classes (and phases) of an image read overlapping windows -- close in time and on one XCD, the second read hits L2
+  // image-major: the four classes (and phases) of an image read overlapping windows -- close in time, the second read hits L2
   const int img = wid / (4 * NPH * cw), r0 = wid - img * (4 * NPH * cw);
   const int cls = r0 / (NPH * cw), r1 = r0 - cls * (NPH * cw), ph = r1 / cw, pa = ph >> 1, pb = ph & 1;
   const unsigned c = (unsigned)(r1 - ph * cw) * 64u + (threadIdx.x & 63u);
