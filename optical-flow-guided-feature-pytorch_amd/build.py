@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "liboffk.so")
 SOURCES = ("offk_api.hip", "pw_reduce.hip", "sobel_tdiff.hip", "conv_igemm.hip", "heads.hip", "units_bwd.hip", "pw_tdiff.hip",
-           "pw_tdiff_split.hip", "chain_fused.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "wino_gemm_split.hip")
+           "pw_tdiff_split.hip", "chain_fused.hip", "chain_split.hip", "winograd.hip", "winograd7.hip", "wino_mid.hip", "wino_gemm.hip", "wino_gemm_split.hip")
 HEADERS = ("offk_common.h", "offk_internal.h", "winograd_common.h", os.path.join("..", "..", "include", "offk.h"))
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-ffp-contract=fast"]
@@ -29,7 +29,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # of its own survives the statement); clang answers every such statement with "clobber list contains reserved registers".
 EXTRA_FLAGS = {"heads.hip": ["-fno-slp-vectorize"], "units_bwd.hip": ["-fno-slp-vectorize"],
                "conv_igemm.hip": ["-Wno-inline-asm"], "pw_tdiff.hip": ["-Wno-inline-asm"], "pw_tdiff_split.hip": ["-Wno-inline-asm", "-fno-slp-vectorize"],
-               "chain_fused.hip": ["-Wno-inline-asm"], "wino_gemm_split.hip": ["-fno-slp-vectorize"]}
+               "chain_fused.hip": ["-Wno-inline-asm"], "wino_gemm_split.hip": ["-fno-slp-vectorize"], "chain_split.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

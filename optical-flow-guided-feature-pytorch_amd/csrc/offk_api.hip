@@ -182,6 +182,9 @@ struct offk_handle {
   float* wino_us[6] = {};        // split-fp32 handles: the plane images of wino_u (wino_gemm_split.hip), 6 bytes per element; nullptr: fp32 GEMMs
   float* wino_u[6] = {};         // transformed weights [121][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; 400 x Co x Ci floats of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
+  float* chain_ws[3][4] = {};    // split-fp32 handles (OFFK_SPLIT_CHAIN=0: off): plane images of the chains' c1 / c2 (packed K order) / c3 weights
+                                 // (chain_split.hip), [chain 28a, 28b, 28c][conv]; [0][3]: motion_conv_branch_28a, which such a handle runs as a
+                                 // 1x1 conv of its own in front of chain 28a (its output is the chain's residual)
   float* chain_u2[3] = {};       // F(2x2, 3x3) weights [16][64][64] of the chains' 3x3 convs C2_28A / B / C (chain_fused.hip, OFFK_CHAIN_WINO)
   bool chain_wino = false;
   int wino5_min_p = 40;          // ... from this many pairs (OFFK_WINOGRAD_5X5=<n> with n > 1 at offk_create: tools)
@@ -674,6 +677,14 @@ int finalize_wino(offk_handle* h, hipStream_t st) {
     const ConvId c2[3] = {C2_28A, C2_28B, C2_28C};
     for (int k = 0; k < 3; ++k)
       if (h->chain_u2[k]) HIP_TRY(h, chain_wino_weight_launch(h->conv_w[c2[k]], h->chain_u2[k], st));
+    const ConvId c1[3] = {C1_28A, C1_28B, C1_28C}, c3[3] = {C3_28A, C3_28B, C3_28C};
+    for (int k = 0; k < 3; ++k) {
+      if (!h->chain_ws[k][0]) continue;
+      HIP_TRY(h, wino_pack_split_launch(h->conv_w[c1[k]], h->chain_ws[k][0], 64, kConvs[c1[k]].Ci, 1, st));
+      HIP_TRY(h, wino_pack_split_launch(h->conv_w[c2[k]], h->chain_ws[k][1], 64, 576, 1, st));
+      HIP_TRY(h, wino_pack_split_launch(h->conv_w[c3[k]], h->chain_ws[k][2], 256, 64, 1, st));
+    }
+    if (h->chain_ws[0][3]) HIP_TRY(h, wino_pack_split_launch(h->conv_w[CB_28A], h->chain_ws[0][3], 256, 64, 1, st));
   }
   h->wino_dirty = false;
   return OFFK_OK;
@@ -831,6 +842,12 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
     if (h->chain_wino)
       for (int k = 0; k < 3; ++k)
         if (dev_alloc(h, &h->chain_u2[k], (size_t)16 * 64 * 64) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    { const char* e = getenv("OFFK_SPLIT_CHAIN"); if (h->chain && h->winograd && h->f32split && !(e && *e == '0')) {      // (h->winograd: finalize_wino packs them)
+      const size_t elems[4] = {(size_t)64 * 256, (size_t)64 * 576, (size_t)256 * 64, (size_t)256 * 64};
+      for (int k = 0; k < 3; ++k)
+        for (int q = 0; q < (k == 0 ? 4 : 3); ++q)
+          if (dev_alloc(h, &h->chain_ws[k][q], (elems[q] * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    } }
   }
   plan_workspace(h);
   *out = h;
@@ -1284,7 +1301,9 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     a.x_bytes = xb < 0x7fffffffull ? (unsigned)xb : 0u;
     { int rc = trace_mark(h, s, name); if (rc != OFFK_OK) return rc; }
     const char* why = nullptr;
-    hipError_t e = chain14_launch(a, s, &why);
+    const int ck = c2 == C2_28A ? 0 : c2 == C2_28B ? 1 : 2;
+    a.w1p = h->chain_ws[ck][0]; a.w2p = h->chain_ws[ck][1]; a.w3p = h->chain_ws[ck][2];
+    hipError_t e = chain14_split_supported(a) ? chain14_split_launch(a, s, &why) : chain14_launch(a, s, &why);
     if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
     return OFFK_OK;
   };
@@ -1292,8 +1311,18 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   //  convs per chain 0.885 ms per forward against 0.90, B = 16: 1.37 against 1.345; OFFK_CHAIN=<pairs> moves the gate)
   const bool chained = h->chain && P >= h->chain_min_p && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
   if (chained) {
-    TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
-              nullptr, sa, 256, 0));                                                              // :658-667
+    if (h->chain_ws[0][3]) {
+      // split-fp32: the branch 1x1 on the pre-ReLU chain input as a launch of its own (wino_gemm_split.hip's conv epilogue) into sb, which
+      // chain 28a then adds as its residual: sa = relu(c3(t2) + b3 + (branch(x0) + b_branch)) -- RGB_OFF.py:663-667 (in the fp32 kernel the
+      // branch is merged into c3's K; its operand is the chain input BEFORE the ReLU, whose planes a split block would have to cut four times)
+      TRY(conv_raw(h, s, kConvs[CB_28A].key, 256, 64, 1, 1, 0, h->conv_w[CB_28A], h->conv_b[CB_28A], -1, 0, n, 14, View{xt, 128, 64}, nullptr, 0, 0, 0,
+                   sb, 256, 0, h->chain_ws[0][3]));
+      TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + motion_conv3_trans_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->conv_w[C3_28A],
+                h->conv_b[C3_28A], 64, sb, sa, 256, 0));
+    } else {
+      TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
+                nullptr, sa, 256, 0));                                                              // :658-667
+    }
     TRY(chain("chain_28b = motion_conv1_trans_28b + motion_conv2_trans_28b + motion_conv3_trans_28b", sa, 256, 0, 256, 0, C1_28B, C2_28B, h->conv_w[C3_28B], h->conv_b[C3_28B], 64, sa, sb, 256, 0));   // :670-676
     TRY(chain("chain_28c = motion_conv1_trans_28c + motion_conv2_trans_28c + motion_conv3_trans_28c", sb, 256, 0, 256, 0, C1_28C, C2_28C, h->conv_w[C3_28C], h->conv_b[C3_28C], 64, sb, F14, 1056, 800)); // :679-685 -> cat at :760
   } else {

@@ -56,11 +56,16 @@ struct ChainArgs {
   float* y; int y_cs, y_coff;             // output, 256 channels at y_coff
   int n_img, relu_out;
   unsigned x_bytes;                       // bytes behind x + x_coff (< 2^31, else 0: not launchable)
+  // chain_split.hip (split-fp32 arithmetic): the plane images of c1 [64][Cin], c2 [64][576] (the packed K order) and c3 [256][64] --
+  // wino_pack_split_launch(w, img, Co, K, 1): 6 bytes per element; nullptr: the chain runs on chain_fused.hip
+  const void* w1p = nullptr; const void* w2p = nullptr; const void* w3p = nullptr;
 #ifdef OFFK_CHAIN_TIMING
   unsigned long long* dbg;                // cycle sums per phase (tools only)
 #endif
 };
 hipError_t chain14_launch(const ChainArgs& a, hipStream_t st, const char** why);
+bool chain14_split_supported(const ChainArgs& a);      // chain_split.hip: the residual chains (K3 = 64) with their plane images
+hipError_t chain14_split_launch(const ChainArgs& a, hipStream_t st, const char** why);
 // U[4 p + q][co][ci] = sum_ab G[p][a] G[q][b] w[co][ci][a][b] from the packed 3x3 weights [64][2][9][32] (16 * 64 * 64 floats)
 hipError_t chain_wino_weight_launch(const float* w2_packed, float* U, hipStream_t st);
 
