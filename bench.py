@@ -282,22 +282,33 @@ def winograd_gemm_flops(P, key):
     return 2.0 * P * (400 * ci if k == 5 else 121 * ci) * co
 
 
-def winograd_saved_flops(P):
-    """Direct-conv FLOPs minus the FLOPs of the batched GEMMs for the convs the fp32 path runs in a Winograd form
-    (csrc/winograd.hip, csrc/winograd7.hip)."""
+def winograd_saved_flops(P, precision="fp32"):
+    """Direct-conv FLOPs minus the FLOPs of the batched GEMMs for the convs the forward runs in a Winograd form
+    (csrc/winograd.hip, csrc/winograd7.hip; the 3x3 convs inside the bottleneck chains only in the fp32 kernel, chain_fused.hip --
+    a split-fp32 handle runs them direct on the bf16 pipe, chain_split.hip)."""
     w = launch_work(P)
     on = [k for k in WINOGRAD_CONVS if not (k == "motion_conv_trans_28" and os.environ.get("OFFK_WINOGRAD_7X7", "1") == "0")
           and not (k == "motion_conv_trans_14" and os.environ.get("OFFK_WINOGRAD_5X5", "1") == "0")
           and not P < POLYPHASE_MIN_PAIRS.get(k, 0)]
     saved = sum(w[k] - winograd_gemm_flops(P, k) for k in on)
-    return saved + sum(w[k] - chain_winograd_flops(P) for k in chain_winograd_convs(P))
+    return saved + sum(w[k] - chain_winograd_flops(P) for k in chain_winograd_convs(P, precision))
 
 
 CHAIN_MIN_PAIRS = 72      # one launch per bottleneck chain of fusion@28 from this many pairs (offk_api.hip, OFFK_CHAIN)
 
 
-def chain_winograd_convs(P):
+def split_chains(P, precision):
+    """A split-fp32 handle runs the bottleneck chains on chain_split.hip (offk_api.hip: OFFK_SPLIT_CHAIN, from the chain gate on)."""
+    e = os.environ
+    gate = int(e["OFFK_CHAIN"]) if e.get("OFFK_CHAIN", "").isdigit() and int(e["OFFK_CHAIN"]) > 1 else CHAIN_MIN_PAIRS
+    return (precision == "f32split" and e.get("OFFK_SPLIT_CHAIN", "1") != "0" and e.get("OFFK_CHAIN", "1") != "0" and
+            e.get("OFFK_WINOGRAD", "1") != "0" and P >= gate)
+
+
+def chain_winograd_convs(P, precision="fp32"):
     """The 3x3 convs that run in Winograd F(2x2, 3x3) form inside chain14_kernel (chain_fused.hip): the default from the chain gate on."""
+    if split_chains(P, precision):
+        return ()
     e = os.environ
     gate = int(e["OFFK_CHAIN"]) if e.get("OFFK_CHAIN", "").isdigit() and int(e["OFFK_CHAIN"]) > 1 else CHAIN_MIN_PAIRS
     if e.get("OFFK_CHAIN", "1") == "0" or e.get("OFFK_CHAIN_WINO", "1") == "0" or e.get("OFFK_WINOGRAD", "1") == "0" or P < gate:
@@ -312,7 +323,7 @@ def chain_winograd_flops(P):
 
 
 SPLIT_FRAC_OF = "six bf16 products per fp32 product / 2.5 PF dense bf16"
-SPLIT_1X1_LAUNCHES = ("merged_14a", "merged_7", "motion_conv1_trans_14b")
+SPLIT_1X1_LAUNCHES = ("merged_14a", "merged_7", "motion_conv1_trans_14b", "motion_conv_branch_28a")
 
 
 def roofline_in_path(h, arr, out, B, L, precision, steps):
@@ -398,14 +409,15 @@ def roofline_in_path(h, arr, out, B, L, precision, steps):
             if fl is None:      # a fused bottleneck chain: "chain_<tag> = convA + convB + ..." (offk_api.hip)
                 parts = [k.strip() for k in name.split("=", 1)[1].split("+")]
                 fl = sum(work[k] for k in parts)
-                cw = [k for k in parts if k in chain_winograd_convs(P)]
+                cw = [k for k in parts if k in chain_winograd_convs(P, precision)]
                 if cw:      # its 3x3 conv runs in Winograd form: frac stays on the direct-conv FLOPs (comparable across rounds), the executed ones beside it
                     rec["direct_conv_flops"] = fl
                     rec["executed_flops"] = fl - sum(work[k] - chain_winograd_flops(P) for k in cw)
             rec.update(bound="mfma", flops=fl, achieved_tflops=fl / avg / 1e9, frac=fl / avg / 1e9 / peak)
             if "executed_flops" in rec:
                 rec["executed_frac"] = rec["executed_flops"] / avg / 1e9 / peak
-            if precision == "f32split" and name in SPLIT_1X1_LAUNCHES:      # the 1x1 convs on 7x7 maps run in wino_gemm_split_kernel too
+            if precision == "f32split" and (name in SPLIT_1X1_LAUNCHES or (name.startswith("chain_") and split_chains(P, precision))):
+                # the 1x1 convs on 7x7 maps (and chain 28a's branch conv) run in wino_gemm_split_kernel, the chains in chain14_split_kernel
                 rec.update(frac=6.0 * fl / avg / 1e9 / BF16_DENSE_PEAK_TFLOPS, frac_of=SPLIT_FRAC_OF,
                            fp32_equivalent_over_fp32_pipe_peak=fl / avg / 1e9 / MFMA_F32_PEAK_TFLOPS)
             if name not in big:
@@ -1076,7 +1088,7 @@ def main():
         peak_tf = MFMA_F32_PEAK_TFLOPS
         algo_flops = (unit_f + fus_f) * B                  # per rank; ms_step is a rank's time: the fractions below are per GPU
         wino_on = os.environ.get("OFFK_WINOGRAD", "1") != "0"
-        exec_flops = algo_flops - winograd_saved_flops(B * (L - 1)) if wino_on else algo_flops
+        exec_flops = algo_flops - winograd_saved_flops(B * (L - 1), args.precision) if wino_on else algo_flops
         s_blocks = next((k for k in (in_path or {}).get("kernels", []) if k["launch"].startswith("units:sobel S-blocks")), None)
         res = {
             "metric": "OFF-forward clips/sec (7-seg 224x224)", "value": clips_s, "unit": "clips/s",
@@ -1091,7 +1103,8 @@ def main():
                        "slice_mode": "reference_flat",
                        "arithmetic": ("fp32 MFMA products, fp32 accumulation" if args.precision == "fp32" else
                                       "split-fp32 (three bf16 planes per fp32 operand, six exact plane products on the bf16 pipe, fp32 accumulation) in the "
-                                      "units kernel, the Winograd GEMMs and the 1x1 convs on 7x7 maps; fp32 MFMA products in the kernels without a split form") +
+                                      "units kernel, the Winograd GEMMs, the bottleneck chains and the 1x1 convs on 7x7 maps; fp32 MFMA products in the kernels "
+                                      "without a split form (the 1x1 convs inside wino_mid)") +
                                      ("; the k x k fusion convs in Winograd forms (fp32 transforms)" if wino_on else "; direct convolutions")},
             "n_ranks_seen": dist.get_world_size() if coll else 1, "collective_backend": backend,
             "exchange": ("async_op=True on two alternating buffer sets: the timed step does not wait for its own collective, only the "
@@ -1173,8 +1186,7 @@ def main():
                     nm = k["launch"]
                     if "flops" not in k or abs(k["avg_ms"] - fp32_ms.get(nm, k["avg_ms"])) < 0.02 * k["avg_ms"] and not nm.startswith("units:pw_tdiff"):
                         continue
-                    if not (nm.startswith("units:pw_tdiff") or "GEMMs]" in nm or nm.startswith("chain_") or "between]" in nm or
-                            nm in ("merged_14a", "merged_7", "motion_conv1_trans_14b")):
+                    if not (nm.startswith("units:pw_tdiff") or "GEMMs]" in nm or nm.startswith("chain_") or "between]" in nm or nm in SPLIT_1X1_LAUNCHES):
                         continue
                     rows_.append({"launch": nm, "avg_ms": k["avg_ms"], "fp32_mode_avg_ms": fp32_ms.get(nm), "flops_fp32_equivalent": k["flops"],
                                   "fp32_equivalent_tflops": k["flops"] / k["avg_ms"] / 1e9,
