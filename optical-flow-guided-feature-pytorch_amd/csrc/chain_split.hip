@@ -18,8 +18,11 @@
 //   phase 2  c2 (3x3, 64 -> 64) direct: 18 K-steps (tap, channel half), per step the seven output rows with the tap's shifted t1 tiles;
 //            the one (row, dy) pair that reads outside the image is masked to zero; t2 = relu(. + b2) -> planes [row][K-step][plane][k group][slot]
 //   phase 3  c3 (1x1, 64 -> 256) + bias + residual + ReLU -> global, one channel tile of 16 at a time
-// The merged chain 28a (c3 contracts [t2 | x0]) stays on chain_fused.hip: its second operand is the PRE-ReLU chain input, whose planes
-// would have to be cut four times per block.
+// Chain 28a (RGB_OFF.py:658-667: sa = relu(c3(t2) + branch(x0)), c1 reads relu(x0), the branch the PRE-ReLU x0; BR = true): phase 1 cuts x0
+// itself into planes -- both K-steps of its 64 channels stay in LDS -- and c1 applies the ReLU to the operand as it reads it (a negative
+// value's three planes are all <= 0: v_pk_max_i16 with 0 on the packed bf16 words IS relu on all three); the branch 1x1 (64 -> 256) runs
+// off the same planes in front of c1, as a pass of the phase-3 item loop that stores branch(x0) + b_branch into y, where phase 3 finds it as
+// its residual (every lane reads back exactly the 16 bytes it stored).
 #include <cstdio>
 #include <cstdlib>
 
@@ -32,6 +35,20 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// relu on a packed-bf16 operand whose values' planes share their sign (truncating cut): per 16-bit word max(x, 0) as a signed integer.
+// (inline asm: hipcc 7.2 compiled the same thing written with __builtin_elementwise_max on the four bit-cast short2 words to ONE
+// v_pk_max_i16 of the first word, selected into all four -- found by tools/debug_chain_br.py)
+__device__ __forceinline__ u32x4 relu_planes(const u32x4& v) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v[e]));
+    o[e] = r;
+  }
+  return o;
+}
 
 constexpr int CS_XTILE = 3 * 1024;             // phase 1: one image row (16 slots) of a K-step: planes h, m, l x [4 k groups][16 slots] x 16 B
 constexpr int CS_XSTAGE = 8 * CS_XTILE;        // 8 rows: 24 KB
@@ -90,9 +107,10 @@ __device__ __forceinline__ void cut4(const f32x4& v, u32x2& ph, u32x2& pm, u32x2
 }
 }  // namespace
 
-// NK1 = Cin / 32 (2 or 8)
-template <int NK1>
+// NK1 = Cin / 32 (2 or 8); BR: chain 28a (NK1 = 2) with its branch conv inside
+template <int NK1, bool BR>
 __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
+  static_assert(!BR || NK1 == 2, "the branch form keeps the whole chain input in the two plane stages");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,6 +127,63 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
   f32x4 acc1[8], acc2[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) { acc1[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // ---- the 1x1 conv 64 -> 256 as 28 items (channel tile n of the wave's four, row r), software-pipelined: the residual of item i + 3 and
+  //      the activation tiles of item i + 1 are requested behind the MFMAs of item i, the epilogue of item i - 1 (its accumulators have
+  //      landed by then) behind those.  rd(x, r): the two K-steps' planes of row r.  Output channels 64 wave + 16 n + 4 kq .. + 3. ----
+  const bool px_ok = li >= 1 && li <= 14;
+  const int pix0 = img * 196 + R0 * 14 + (px_ok ? li - 1 : 0);                // + row * 14
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_coff, 0, (int)(((size_t)a.n_img * 196 * a.y_cs - a.y_coff) * 4), 0x00020000);
+  auto item_loop = [&](const __amdgpu_buffer_rsrc_t wrs, auto rd, const float* bias, const float* res, const int res_cs, const int res_coff,
+                       const bool res_is_y, const bool relu) {
+    u32x4 w3[2][2][3];                    // [set][K-step][plane]
+    auto load_w3 = [&](const int set, const int n) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          w3[set][s][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, ((s * 16 + 4 * wave + n) * 3 + pl) * 1024, 0));
+    };
+    auto res_load = [&](const int i) {
+      const int n = i / 7, r = i % 7;
+      const int ch = 64 * wave + 16 * n + 4 * kq;
+#if defined(OFFK_CS_EXP) && OFFK_CS_EXP == 3
+      if (res_is_y) return px_ok ? *reinterpret_cast<const volatile f32x4*>(a.y + (size_t)(pix0 + r * 14) * a.y_cs + a.y_coff + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+      if (res_is_y)       // what this lane stored there in the branch pass (glc: past the L1)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, px_ok ? ((pix0 + r * 14) * a.y_cs + ch) * 4 : CS_OOB, 0, 1));
+      return res ? *reinterpret_cast<const f32x4*>(res + (size_t)(pix0 + r * 14) * res_cs + res_coff + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    u32x4 xb[2][2][3];                    // [item parity][K-step][plane]
+    f32x4 rv[4], bb[2], pc[4];
+    auto finish = [&](const int i) {      // item i: pc = its four accumulators
+      const int n = i / 7, r = i % 7;
+      const int ch = 64 * wave + 16 * n + 4 * kq;
+      f32x4 v = ((pc[0] + pc[2]) + (pc[1] + pc[3])) + bb[n & 1] + rv[i & 3];
+      if (relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+      if (px_ok) *reinterpret_cast<f32x4*>(a.y + (size_t)(pix0 + r * 14) * a.y_cs + a.y_coff + ch) = v;
+    };
+    load_w3(0, 0);
+    bb[0] = *reinterpret_cast<const f32x4*>(bias + 64 * wave + 4 * kq);
+    rv[0] = res_load(0); rv[1] = res_load(1); rv[2] = res_load(2);
+    rd(xb[0], 0);
+#pragma unroll
+    for (int i = 0; i < 28; ++i) {
+      const int n = i / 7, r = i % 7;
+      if (r == 0 && n + 1 < 4) load_w3((n + 1) & 1, n + 1);
+      // (the next tile's bias one item later: finish(i - 1) of the tile before still reads its own at r == 0)
+      if (r == 1 && n + 1 < 4) bb[(n + 1) & 1] = *reinterpret_cast<const f32x4*>(bias + 64 * wave + 16 * (n + 1) + 4 * kq);
+      if (i + 1 < 28) rd(xb[(i + 1) & 1], (i + 1) % 7);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+      mul6ab(c1, c2, d1, d2, w3[n & 1][0], xb[i & 1][0], w3[n & 1][1], xb[i & 1][1]);      // the two K-steps as two interleaved chains
+      if (i > 0) finish(i - 1);
+      if (i + 3 < 28) rv[(i + 3) & 3] = res_load(i + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      pc[0] = c1; pc[1] = c2; pc[2] = d1; pc[3] = d2;
+    }
+    finish(27);
+  };
 
   // ================= phase 1: t1 = relu(W1 . x + b1) for 8 rows x 16 slots =================
   {
@@ -133,7 +208,7 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
           f32x4 v = __builtin_bit_cast(f32x4, xr[2 * g + hq]);
-          if (a.relu_in) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+          if (!BR && a.relu_in) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};      // (BR: c1 applies it as it reads)
           u32x2 h2, m2, l2;
           cut4(v, h2, m2, l2);
           ph[2 * hq] = h2.x; ph[2 * hq + 1] = h2.y; pm[2 * hq] = m2.x; pm[2 * hq + 1] = m2.y; pl[2 * hq] = l2.x; pl[2 * hq + 1] = l2.y;
@@ -154,8 +229,20 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
     if (NK1 > 1) load_x(1);
     load_w1(0, 0);
     cut_x(0);
+    if (BR) cut_x(1);
     if (NK1 > 2) load_x(2);
     __syncthreads();
+    if constexpr (BR) {
+      // the branch 1x1 off the planes of the PRE-ReLU chain input: y = W_b x0 + b_b, to be read back as phase 3's residual
+      const __amdgpu_buffer_rsrc_t wbrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wbp), 0, 256 * 64 * 6, 0x00020000);
+      const char* const brd = xrd + hf * CS_XTILE;        // output row r = t1 row r + hf
+      item_loop(wbrs, [&](u32x4 (&x)[2][3], const int r) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) x[sx][pl] = *reinterpret_cast<const u32x4*>(brd + sx * CS_XSTAGE + r * CS_XTILE + pl * 1024);
+      }, a.bbr, nullptr, 0, 0, false, false);
+    }
 #pragma unroll
     for (int kt = 0; kt < NK1; ++kt) {
       const int st = kt & 1;
@@ -163,7 +250,10 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
       u32x4 xb[2][3];
       auto rdx = [&](u32x4 (&x)[3], const int m) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) x[q] = *reinterpret_cast<const u32x4*>(xrd + st * CS_XSTAGE + m * CS_XTILE + q * 1024);
+        for (int q = 0; q < 3; ++q) {
+          x[q] = *reinterpret_cast<const u32x4*>(xrd + st * CS_XSTAGE + m * CS_XTILE + q * 1024);
+          if (BR && a.relu_in) x[q] = relu_planes(x[q]);
+        }
       };
       rdx(xb[0], 0);
       rdx(xb[1], 1);
@@ -174,7 +264,7 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (mp + 1 < 4) { rdx(xb[0], 2 * mp + 2); rdx(xb[1], 2 * mp + 3); }
         // the cut of the next K-step's values (loaded two steps ago) rides behind the first tile pair; its register set is re-loaded behind the second
-        if (mp == 0 && kt + 1 < NK1) cut_x(st ^ 1);
+        if (!BR && mp == 0 && kt + 1 < NK1) cut_x(st ^ 1);
         if (mp == 1 && kt + 3 < NK1) load_x(kt + 3);
       }
       __syncthreads();
@@ -267,86 +357,43 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
   return;
 #endif
 
-  // ================= phase 3: y = post(W3 . t2 + b3 + res), output channels 64 wave + 16 n + 4 kq .. + 3 =================
+  // ================= phase 3: y = post(W3 . t2 + b3 + res) =================
   {
     const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3p), 0, 256 * 64 * 6, 0x00020000);
     const char* const trd = lds + kq * 256 + li * 16;                                 // + row, + K-step * CS_XTILE, + plane * 1024
-    const bool px_ok = li >= 1 && li <= 14;
-    const int pix0 = img * 196 + R0 * 14 + (px_ok ? li - 1 : 0);                // + row * 14
-    u32x4 w3[2][2][3];                    // [set][K-step][plane]
-    auto load_w3 = [&](const int set, const int n) {
+    item_loop(w3rs, [&](u32x4 (&x)[2][3], const int r) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          w3[set][s][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w3rs, wlane, ((s * 16 + 4 * wave + n) * 3 + pl) * 1024, 0));
-    };
-    // 28 items (channel tile n, row r), software-pipelined: the residual of item i + 3 and the t2 tiles of item i + 1 are requested behind
-    // the MFMAs of item i, the epilogue of item i - 1 (its accumulators have landed by then) behind those
-    auto res_load = [&](const int i) {
-      const int n = i / 7, r = i % 7;
-      const int ch = 64 * wave + 16 * n + 4 * kq;
-      return a.res ? *reinterpret_cast<const f32x4*>(a.res + (size_t)(pix0 + r * 14) * a.res_cs + a.res_coff + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    u32x4 xb[2][2][3];                    // [item parity][K-step][plane]
-    auto rd2 = [&](u32x4 (&x)[2][3], const int r) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) x[s][pl] = *reinterpret_cast<const u32x4*>(trd + r * CS_T2ROW + s * CS_XTILE + pl * 1024);
-    };
-    f32x4 rv[4], bb[2], pc[4];
-    auto finish = [&](const int i) {      // item i: pc = its four accumulators
-      const int n = i / 7, r = i % 7;
-      const int ch = 64 * wave + 16 * n + 4 * kq;
-      f32x4 v = ((pc[0] + pc[2]) + (pc[1] + pc[3])) + bb[n & 1] + rv[i & 3];
-      if (a.relu_out) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-      if (px_ok) *reinterpret_cast<f32x4*>(a.y + (size_t)(pix0 + r * 14) * a.y_cs + a.y_coff + ch) = v;
-    };
-    load_w3(0, 0);
-    bb[0] = *reinterpret_cast<const f32x4*>(a.b3 + 64 * wave + 4 * kq);
-    rv[0] = res_load(0); rv[1] = res_load(1); rv[2] = res_load(2);
-    rd2(xb[0], 0);
-#pragma unroll
-    for (int i = 0; i < 28; ++i) {
-      const int n = i / 7, r = i % 7;
-      if (r == 0 && n + 1 < 4) load_w3((n + 1) & 1, n + 1);
-      // (the next tile's bias one item later: finish(i - 1) of the tile before still reads its own at r == 0)
-      if (r == 1 && n + 1 < 4) bb[(n + 1) & 1] = *reinterpret_cast<const f32x4*>(a.b3 + 64 * wave + 16 * (n + 1) + 4 * kq);
-      if (i + 1 < 28) rd2(xb[(i + 1) & 1], (i + 1) % 7);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
-      mul6ab(c1, c2, d1, d2, w3[n & 1][0], xb[i & 1][0], w3[n & 1][1], xb[i & 1][1]);      // the two K-steps as two interleaved chains
-      if (i > 0) finish(i - 1);
-      if (i + 3 < 28) rv[(i + 3) & 3] = res_load(i + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      pc[0] = c1; pc[1] = c2; pc[2] = d1; pc[3] = d2;
-    }
-    finish(27);
+        for (int pl = 0; pl < 3; ++pl) x[sx][pl] = *reinterpret_cast<const u32x4*>(trd + r * CS_T2ROW + sx * CS_XTILE + pl * 1024);
+    }, a.b3, BR ? nullptr : a.res, a.res_cs, a.res_coff, BR, a.relu_out != 0);
   }
 }
 
 bool chain14_split_supported(const ChainArgs& a) {
+  if (a.wbp && (a.Cin != 64 || a.res || !a.bbr)) return false;       // the branch form: chain 28a
   return a.w1p && a.w2p && a.w3p && (a.Cin == 64 || a.Cin == 256) && a.K3 == 64 && a.n_img >= 1 && a.x_bytes && !(a.x_cs % 4) && !(a.x_coff % 4) &&
-         !(a.y_cs % 4) && !(a.y_coff % 4) && !(a.res && (a.res_cs % 4 || a.res_coff % 4));
+         !(a.y_cs % 4) && !(a.y_coff % 4) && !(a.res && (a.res_cs % 4 || a.res_coff % 4)) && (size_t)a.n_img * 196 * a.y_cs * 4 < 0x7fffff00ull;
 }
 
 hipError_t chain14_split_launch(const ChainArgs& a, hipStream_t st, const char** why) {
   *why = nullptr;
   if (!chain14_split_supported(a)) {
-    *why = "chain14 (split-fp32): need the three plane images, Cin in {64, 256}, K3 = 64, 16-byte aligned channel slices, input below 2^31 bytes";
+    *why = "chain14 (split-fp32): need the three plane images, Cin in {64, 256}, K3 = 64 (the branch form: its plane image and bias, Cin 64, no residual), "
+           "16-byte aligned channel slices, input and output below 2^31 bytes";
     return hipErrorInvalidValue;
   }
   const int blocks = (a.n_img + 7) / 8 * 16;
-  if (a.Cin == 64) {
-    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(chain14_split_kernel<2>), CS_LDS);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chain14_split_kernel<2>, dim3(blocks), dim3(256), CS_LDS, st, a);
-  } else {
-    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(chain14_split_kernel<8>), CS_LDS);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chain14_split_kernel<8>, dim3(blocks), dim3(256), CS_LDS, st, a);
+#define OFFK_CS_LAUNCH(NK, BRV)                                                                                \
+  {                                                                                                            \
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(chain14_split_kernel<NK, BRV>), CS_LDS);        \
+    if (e != hipSuccess) return e;                                                                             \
+    hipLaunchKernelGGL((chain14_split_kernel<NK, BRV>), dim3(blocks), dim3(256), CS_LDS, st, a);               \
   }
+  if (a.wbp) OFFK_CS_LAUNCH(2, true)
+  else if (a.Cin == 64) OFFK_CS_LAUNCH(2, false)
+  else OFFK_CS_LAUNCH(8, false)
+#undef OFFK_CS_LAUNCH
   return hipGetLastError();
 }
 

@@ -1286,7 +1286,8 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   } else {
     TRY(conv(h, s, C_T28, n, 28, View{F28, 320, 0}, nullptr, 0, 0, 0, xt, 128, 64));
   }
-  // 1x1 -> 3x3 -> 1x1 (+ residual) as ONE launch per chain (exact fp32; a block owns half an image, t1 / t2 stay in LDS)
+  // 1x1 -> 3x3 -> 1x1 (+ residual) as ONE launch per chain (a block owns half an image, t1 / t2 stay in LDS)
+  bool split_branch = false;
   auto chain = [&](const char* name, const float* x, int x_cs, int x_coff, int Cin, int relu_in, ConvId c1, ConvId c2,
                    const float* w3, const float* b3, int K3, const float* res, float* y, int y_cs, int y_coff) -> int {
     ChainArgs a;
@@ -1303,6 +1304,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     const char* why = nullptr;
     const int ck = c2 == C2_28A ? 0 : c2 == C2_28B ? 1 : 2;
     a.w1p = h->chain_ws[ck][0]; a.w2p = h->chain_ws[ck][1]; a.w3p = h->chain_ws[ck][2];
+    if (split_branch) { a.wbp = h->chain_ws[0][3]; a.bbr = h->conv_b[CB_28A]; }
     hipError_t e = chain14_split_supported(a) ? chain14_split_launch(a, s, &why) : chain14_launch(a, s, &why);
     if (e != hipSuccess) return fail(h, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(name) + ": " + (why ? why : hipGetErrorString(e)));
     return OFFK_OK;
@@ -1312,13 +1314,12 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
   const bool chained = h->chain && P >= h->chain_min_p && (unsigned long long)n * 196 * 256 * 4ull < 0x7fffffffull;
   if (chained) {
     if (h->chain_ws[0][3]) {
-      // split-fp32: the branch 1x1 on the pre-ReLU chain input as a launch of its own (wino_gemm_split.hip's conv epilogue) into sb, which
-      // chain 28a then adds as its residual: sa = relu(c3(t2) + b3 + (branch(x0) + b_branch)) -- RGB_OFF.py:663-667 (in the fp32 kernel the
-      // branch is merged into c3's K; its operand is the chain input BEFORE the ReLU, whose planes a split block would have to cut four times)
-      TRY(conv_raw(h, s, kConvs[CB_28A].key, 256, 64, 1, 1, 0, h->conv_w[CB_28A], h->conv_b[CB_28A], -1, 0, n, 14, View{xt, 128, 64}, nullptr, 0, 0, 0,
-                   sb, 256, 0, h->chain_ws[0][3]));
-      TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + motion_conv3_trans_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->conv_w[C3_28A],
-                h->conv_b[C3_28A], 64, sb, sa, 256, 0));
+      // split-fp32 (chain_split.hip, BR form): c3 with K3 = 64, the branch 1x1 on the pre-ReLU chain input inside the kernel (its output
+      // passes through y as the chain's residual) -- RGB_OFF.py:663-667; in the fp32 kernel the branch is merged into c3's K
+      split_branch = true;
+      TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->conv_w[C3_28A],
+                h->conv_b[C3_28A], 64, nullptr, sa, 256, 0));
+      split_branch = false;
     } else {
       TRY(chain("chain_28a = motion_conv1_trans_28a + motion_conv2_trans_28a + merged_28a", xt, 128, 64, 64, 1, C1_28A, C2_28A, h->merged_w[0], h->merged_b[0], 128,
                 nullptr, sa, 256, 0));                                                              // :658-667

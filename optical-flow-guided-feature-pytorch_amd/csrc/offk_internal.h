@@ -59,6 +59,8 @@ struct ChainArgs {
   // chain_split.hip (split-fp32 arithmetic): the plane images of c1 [64][Cin], c2 [64][576] (the packed K order) and c3 [256][64] --
   // wino_pack_split_launch(w, img, Co, K, 1): 6 bytes per element; nullptr: the chain runs on chain_fused.hip
   const void* w1p = nullptr; const void* w2p = nullptr; const void* w3p = nullptr;
+  const void* wbp = nullptr; const float* bbr = nullptr;      // chain 28a on chain_split.hip: the branch 1x1 [256][64] on the PRE-ReLU chain input (its
+                                                              // plane image and bias) inside the kernel; K3 = 64, no residual
 #ifdef OFFK_CHAIN_TIMING
   unsigned long long* dbg;                // cycle sums per phase (tools only)
 #endif
