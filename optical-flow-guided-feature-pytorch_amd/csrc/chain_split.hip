@@ -10,8 +10,9 @@
 // Block = half an image (7 of the 14 rows), 256 threads, 48 KB of LDS (three blocks per CU), as chain_fused.hip; an image row is one 16-wide
 // MFMA tile (slots 0 and 15 = the zero padding of the 3x3).  Weights = A operand: the library's plane images [K-tile][channel tile][plane][lane]
 // x 16 B (wino_pack_split_launch) straight from L2 into registers; activations = B operand from plane images in LDS:
-//   phase 1  c1 (1x1, Cin -> 64) for 8 rows (one halo row): thread (slot, 16-channel half, row) loads 64 B of x per K-step, cuts them in
-//            registers and writes 16 B per plane and k group into the K-step's plane image [row][plane][k group][slot] (two stages);
+//   phase 1  c1 (1x1, Cin -> 64) for 8 rows (one halo row): thread (16-byte chunk, pixel) loads 4 x 16 B of x per K-step (eight lanes = one
+//            pixel's 128-byte line), cuts them in registers and writes 8 B per plane into the K-step's plane image [row][plane][k group]
+//            [slot ^ 2 g] (two stages);
 //            t1 = relu(. + b1) is cut in the epilogue and written as planes [plane][k group 0..7][128 slots] x 16 B, slot index
 //            15 row + slot + 1 (a row's slot 15 IS the next row's slot 0: both are zero padding), 2 KB per k group: the sixteen-lane
 //            groups of a ds_read_b128 cover one 256-byte bank row for all three tap columns
@@ -189,34 +190,36 @@ __global__ __launch_bounds__(256, 3) void chain14_split_kernel(ChainArgs a) {
   {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + a.x_coff), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w1p), 0, 64 * NK1 * 32 * 6, 0x00020000);
-    // loader: thread = (slot ls, channel half lhk, row lm): 16 channels = 64 B of one pixel per K-step; padding slots read zeros
-    const int ls = tid & 15, lhk = (tid >> 4) & 1, lm = tid >> 5;
-    const int icol = ls - 1;
-    const int xvoff = (unsigned)icol < 14u ? ((img * 196 + (Rf + lm) * 14 + icol) * a.x_cs + 16 * lhk) * 4 : CS_OOB;
-    char* const xwr = lds + lm * CS_XTILE + 2 * lhk * 256 + ls * 16;                    // + stage, + plane * 1024, + g * 256
-    const char* const xrd = lds + kq * 256 + li * 16;                                  // + stage, + m * CS_XTILE, + plane * 1024
-    u32x4 xr2[2][4];                      // [set = K-step parity]: loaded two K-steps ahead of the multiply, cut one step ahead
+    // loader: thread = (16-byte chunk lc of the K-step's 128 B, pixel slot tid >> 3 (+ 32 q)): eight lanes fetch one pixel's whole 128-byte
+    // line, an instruction eight lines (one lane per pixel and 64 B of it, the first form, touched 64 lines per instruction: the vector-memory
+    // path was as loaded as the matrix pipe); padding slots read zeros.  Plane image of a row: [plane][k group g][position = slot ^ 2 g] x 16 B
+    // (wino_gemm_split.hip's layout: conflict-free for the cut's ds_write_b64 and for the operand's ds_read_b128)
+    const int lc = tid & 7, lkg = lc >> 1;
+    int xvoff[4];
+    char* xwr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sl = (tid >> 3) + 32 * q, lm = sl >> 4, ls = sl & 15, icol = ls - 1;
+      xvoff[q] = (unsigned)icol < 14u ? ((img * 196 + (Rf + lm) * 14 + icol) * a.x_cs + 4 * lc) * 4 : CS_OOB;
+      xwr[q] = lds + lm * CS_XTILE + lkg * 256 + ((ls ^ (2 * lkg)) << 4) + (lc & 1) * 8;            // + stage, + plane * 1024
+    }
+    const char* const xrd = lds + kq * 256 + ((li ^ (2 * kq)) << 4);                   // + stage, + m * CS_XTILE, + plane * 1024
+    u32x4 xr2[2][4];                      // [set = K-step parity][q]: loaded two K-steps ahead of the multiply, cut one step ahead
     auto load_x = [&](const int kt) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xr2[kt & 1][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, kt * 128 + q * 16, 0));
+      for (int q = 0; q < 4; ++q) xr2[kt & 1][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[q], kt * 128, 0));
     };
     auto cut_x = [&](const int stage) {
-      const u32x4 (&xr)[4] = xr2[stage];
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-          f32x4 v = __builtin_bit_cast(f32x4, xr[2 * g + hq]);
-          if (!BR && a.relu_in) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};      // (BR: c1 applies it as it reads)
-          u32x2 h2, m2, l2;
-          cut4(v, h2, m2, l2);
-          ph[2 * hq] = h2.x; ph[2 * hq + 1] = h2.y; pm[2 * hq] = m2.x; pm[2 * hq + 1] = m2.y; pl[2 * hq] = l2.x; pl[2 * hq + 1] = l2.y;
-        }
-        char* d = xwr + stage * CS_XSTAGE + g * 256;
-        *reinterpret_cast<u32x4*>(d) = ph;
-        *reinterpret_cast<u32x4*>(d + 1024) = pm;
-        *reinterpret_cast<u32x4*>(d + 2048) = pl;
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = __builtin_bit_cast(f32x4, xr2[stage][q]);
+        if (!BR && a.relu_in) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};      // (BR: c1 applies it as it reads)
+        u32x2 h2, m2, l2;
+        cut4(v, h2, m2, l2);
+        char* d = xwr[q] + stage * CS_XSTAGE;
+        *reinterpret_cast<u32x2*>(d) = h2;
+        *reinterpret_cast<u32x2*>(d + 1024) = m2;
+        *reinterpret_cast<u32x2*>(d + 2048) = l2;
       }
     };
     u32x4 w1[2][3];
