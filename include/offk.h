@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define OFFK_ABI_VERSION 9
+#define OFFK_ABI_VERSION 10
 #define OFFK_NUM_SITES 9 /* 3a 3b 3c 4a 4b 4c 4d 5a 5b */
 
 enum offk_status {
@@ -246,6 +246,17 @@ int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_c
                             const float* w1, const float* b1, const float* w2_packed, const float* b2,
                             const float* w3, const float* b3, int K3,
                             const float* res, int res_cstride, int res_coff, float* y, int y_cstride, int y_coff);
+/* K4cs (ABI v10). The same chain in split-fp32 arithmetic on the bf16 matrix pipe (csrc/chain_split.hip: what an OFFK_PRECISION_F32SPLIT handle
+ * runs in offk_forward; the 3x3 direct, every contraction as six bf16 plane products into two fp32 accumulators): c3 over t2 only (K3 = 64).
+ * branch_w == NULL: the residual chains 28b / 28c (Cin = 256 or 64; res may be NULL).  branch_w != NULL (Cin = 64, res must be NULL): chain 28a --
+ * y = relu(c3(t2) + b3 + branch_w . x + branch_b) with the branch 1x1 [256][64] on the chain input BEFORE relu_in's ReLU, RGB_OFF.py:657-667.
+ * Weights as for offk_bottleneck_chain14 (fp32, device); scratch: device memory for their plane images, at least
+ * 6 * (64 * Cin + 64 * 576 + 2 * 256 * 64) bytes (cut on every call: a stage entry point, not a fast path). */
+int offk_bottleneck_chain14_split(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Cin, int relu_in,
+                                  const float* w1, const float* b1, const float* w2_packed, const float* b2,
+                                  const float* w3, const float* b3, const float* branch_w, const float* branch_b,
+                                  const float* res, int res_cstride, int res_coff, float* y, int y_cstride, int y_coff,
+                                  void* scratch, size_t scratch_bytes);
 /* K4w. 3x3 / stride 1 / pad 1 convolution on 7x7 maps in Winograd form, fp32 arithmetic (csrc/winograd.hip: a map = four tiles,
  * F(4, 3) x F(3, 3) per axis, 121 points): the five such
  * convs of fusion@14 / @7 (RGB_OFF.py:766-767, 775-780, 833-834, 837-838).  Same epilogue and views as offk_conv2d (flags without

@@ -63,6 +63,7 @@ SIGNATURES = {
     "offk_conv2d_ex": (_I, [_P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _I, _I,
                             _I, _I, _F, _c.c_size_t, _I]),
     "offk_bottleneck_chain14": (_I, [_P, _F, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _I, _F, _I, _I, _F, _I, _I]),
+    "offk_bottleneck_chain14_split": (_I, [_P, _F, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _F, _I, _I, _P, ctypes.c_size_t]),
     "offk_winograd_conv3x3": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t, _F]),
     "offk_winograd_conv5x5s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_winograd_conv7x7s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
@@ -103,7 +104,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.offk_abi_version() != 9:
+    if lib.offk_abi_version() != 10:
         raise OffkError("liboffk.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1614,6 +1614,40 @@ int offk_bottleneck_chain14(void* stream, const float* x, int x_cstride, int x_c
   return OFFK_OK;
 }
 
+int offk_bottleneck_chain14_split(void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Cin, int relu_in,
+                                  const float* w1, const float* b1, const float* w2_packed, const float* b2, const float* w3,
+                                  const float* b3, const float* branch_w, const float* branch_b, const float* res, int res_cstride,
+                                  int res_coff, float* y, int y_cstride, int y_coff, void* scratch, size_t scratch_bytes) {
+  const char* who = "offk_bottleneck_chain14_split";
+  if (!x || !w1 || !b1 || !w2_packed || !b2 || !w3 || !b3 || !y || !scratch || n_img < 1 || (Cin != 64 && Cin != 256) || (branch_w && !branch_b))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument");
+  const size_t e1 = (size_t)64 * Cin, e2 = (size_t)64 * 576, e3 = (size_t)256 * 64;
+  if (scratch_bytes < 6 * (e1 + e2 + 2 * e3)) return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": scratch too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* sp = static_cast<char*>(scratch);
+  ChainArgs a;
+  a.u2 = nullptr;
+  a.x = x; a.x_cs = x_cstride; a.x_coff = x_coff; a.Cin = Cin; a.relu_in = relu_in ? 1 : 0;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2_packed; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.K3 = 64;
+  a.res = res; a.res_cs = res_cstride; a.res_coff = res_coff; a.y = y; a.y_cs = y_cstride; a.y_coff = y_coff;
+  a.n_img = n_img; a.relu_out = 1;
+  const unsigned long long xb = ((unsigned long long)n_img * 196 * x_cstride - x_coff) * 4ull;
+  a.x_bytes = xb < 0x7fffffffull ? (unsigned)xb : 0u;
+  a.w1p = sp; a.w2p = sp + 6 * e1; a.w3p = sp + 6 * (e1 + e2);
+  hipError_t e = wino_pack_split_launch(w1, const_cast<void*>(a.w1p), 64, Cin, 1, st);
+  if (e == hipSuccess) e = wino_pack_split_launch(w2_packed, const_cast<void*>(a.w2p), 64, 576, 1, st);
+  if (e == hipSuccess) e = wino_pack_split_launch(w3, const_cast<void*>(a.w3p), 256, 64, 1, st);
+  if (e == hipSuccess && branch_w) {
+    a.wbp = sp + 6 * (e1 + e2 + e3); a.bbr = branch_b;
+    e = wino_pack_split_launch(branch_w, const_cast<void*>(a.wbp), 256, 64, 1, st);
+  }
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  const char* why = nullptr;
+  e = chain14_split_launch(a, st, &why);
+  if (e != hipSuccess) return fail(nullptr, why ? OFFK_ERR_INVALID : OFFK_ERR_HIP, std::string(who) + ": " + (why ? why : hipGetErrorString(e)));
+  return OFFK_OK;
+}
+
 namespace {
 // shared body of the two Winograd entry points: phases = 1 (3x3 / stride 1 on 7x7) or 4 (polyphase 5x5 / stride 2 on 14x14)
 int winograd_entry(const char* who, void* stream, const float* x, int x_cstride, int x_coff, int n_img, int Ci, int phases,

@@ -352,6 +352,25 @@ def bottleneck_chain14(x, w1, b1, w2_oihw, b2, w3, b3, res=None, relu_in=False, 
     return y
 
 
+def bottleneck_chain14_split(x, w1, b1, w2_oihw, b2, w3, b3, res=None, branch=None, relu_in=False, x_coff=0, y=None, y_coff=0):
+    """offk_bottleneck_chain14_split: the chain in split-fp32 arithmetic (chain_split.hip).  w3 [256, 64]; branch = (w [256, 64], b [256]):
+    chain 28a's branch 1x1 on the chain input before relu_in's ReLU (then Cin = 64 and no res)."""
+    lib = _lib.load()
+    n, H, W, cs = x.shape
+    assert H == 14 and W == 14 and w3.shape[1] == 64
+    Cin = w1.shape[1]
+    if y is None:
+        y = torch.empty(n, 14, 14, 256, dtype=torch.float32, device=x.device)
+    w2p = pack_conv_weight(w2_oihw)
+    scratch = torch.empty(6 * (64 * Cin + 64 * 576 + 2 * 256 * 64), dtype=torch.uint8, device=x.device)
+    bw, bb = (branch[0].contiguous(), branch[1].contiguous()) if branch is not None else (None, None)
+    _lib.check(lib.offk_bottleneck_chain14_split(_stream(x.device), _ptr(x), cs, x_coff, n, Cin, int(relu_in), _ptr(w1.contiguous()), _ptr(b1),
+                                                 _ptr(w2p), _ptr(b2), _ptr(w3.contiguous()), _ptr(b3), _ptr(bw), _ptr(bb), _ptr(res),
+                                                 res.shape[-1] if res is not None else 0, 0, _ptr(y), y.shape[-1], y_coff,
+                                                 _ptr(scratch), scratch.numel()))
+    return y
+
+
 def winograd_conv3x3(x, w_oihw, bias, res=None, flags=0, x_coff=0, y=None, y_coff=0, want_pool=False):
     """3x3 / stride 1 / pad 1 conv on 7x7 maps as Winograd F(4x4, 3x3) (offk_winograd_conv3x3).  x: [n, 7, 7, Cs]; returns y
     [n, 7, 7, Co] (and, want_pool, the per-tile sums [4 n, Co])."""

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for s in header_symbols():
         assert hasattr(raw, s), s
-    assert built.offk_abi_version() == 9
+    assert built.offk_abi_version() == 10
 
 
 def test_handleless_errors_are_reported(built):

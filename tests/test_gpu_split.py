@@ -284,3 +284,67 @@ def test_split_nonfinite_and_tiny_inputs(rt):
     yt = rt.batched_gemm_nt(dev(xs), dev(ws), "f32split").double().cpu()
     reft = torch.einsum("bmk,bnk->bmn", xs.double(), ws.double())
     assert ((yt - reft).abs().max() / reft.abs().max()).item() < 1e-6
+
+
+# ---- the bottleneck chains of fusion@28 in split-fp32 arithmetic (chain_split.hip) through their C-ABI entry point (ABI v10) ----
+
+def _chain_inputs(case, n, kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    branch = case == "28a_branch"
+    Cin = 64 if branch else 256
+    x = torch.randn(n, 14, 14, Cin + (64 if branch else 0), generator=g) * (1.0 if branch else 0.5)
+    if kind == "heavy_tail":
+        x = x * torch.exp(1.5 * torch.randn(n, 14, 14, 1, generator=g))
+    if not branch:
+        x = x.clamp_min(0)                               # sa / sb are post-ReLU
+    k1 = 1.0 / Cin ** 0.5
+    w1 = (torch.rand(64, Cin, generator=g) * 2 - 1) * k1
+    b1 = (torch.rand(64, generator=g) * 2 - 1) * k1
+    w2 = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    b2 = (torch.rand(64, generator=g) * 2 - 1) / 24.0
+    w3 = (torch.rand(256, 64, generator=g) * 2 - 1) / 8.0
+    b3 = (torch.rand(256, generator=g) * 2 - 1) / 8.0
+    wb = (torch.rand(256, 64, generator=g) * 2 - 1) / 8.0
+    bb = (torch.rand(256, generator=g) * 2 - 1) / 8.0
+    return x.float().contiguous(), w1, b1, w2, b2, w3, b3, wb, bb
+
+
+@pytest.mark.parametrize("kind", ["normal", "heavy_tail"])
+@pytest.mark.parametrize("case", ["28a_branch", "28b_residual", "28c_into_slice"])
+@pytest.mark.parametrize("n", [1, 5, 11])
+def test_bottleneck_chain14_split_vs_fp64(rt, case, n, kind):
+    """offk_bottleneck_chain14_split (RGB_OFF.py:658-667 / :670-685) against an fp64 chain: the branch form of block 28a (c1 on relu(x0), the
+    branch conv on the pre-ReLU x0, inside the kernel), the residual form, output into a channel slice; odd image counts exercise the grid
+    rounding.  Beside it the fp32-pipe kernel (offk_bottleneck_chain14, direct 3x3): the split chain may not be further from fp64."""
+    branch = case == "28a_branch"
+    x, w1, b1, w2, b2, w3, b3, wb, bb = _chain_inputs(case, n, kind, 300 + n)
+    Cin, x_coff = (64, 64) if branch else (256, 0)
+    xin = x[..., x_coff:x_coff + Cin].permute(0, 3, 1, 2).double()
+    t1 = F.relu(F.conv2d(F.relu(xin) if branch else xin, w1.double()[:, :, None, None], b1.double()))
+    t2 = F.relu(F.conv2d(t1, w2.double(), b2.double(), padding=1))
+    want = F.conv2d(t2, w3.double()[:, :, None, None], b3.double())
+    want = want + (F.conv2d(xin, wb.double()[:, :, None, None], bb.double()) if branch else xin)
+    want = F.relu(want).permute(0, 2, 3, 1)
+    res = None if branch else dev(x)
+    kw = dict(res=res, branch=(dev(wb), dev(bb)) if branch else None, relu_in=branch, x_coff=x_coff)
+    if case == "28c_into_slice":
+        ybuf = torch.full((n, 14, 14, 352), -3.0, device="cuda")
+        rt.bottleneck_chain14_split(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), y=ybuf, y_coff=64, **kw)
+        got = ybuf[..., 64:320]
+        assert torch.all(ybuf[..., :64] == -3.0) and torch.all(ybuf[..., 320:] == -3.0)
+    else:
+        got = rt.bottleneck_chain14_split(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), **kw)
+    # the fp32-pipe kernel on the same chain (28a: its merged form, c3 over [t2 | x0] with K3 = 128)
+    if branch:
+        w3m = torch.cat([w3, wb], 1).contiguous()
+        got32 = rt.bottleneck_chain14(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3m), dev(b3 + bb), relu_in=True, x_coff=x_coff)
+    else:
+        got32 = rt.bottleneck_chain14(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(w3), dev(b3), res=res)
+    torch.cuda.synchronize()
+    s = want.abs().max()
+    e = ((got.double().cpu() - want).abs().max() / s).item()
+    e32 = ((got32.double().cpu() - want).abs().max() / s).item()
+    rms = (((got.double().cpu() - want) ** 2).mean().sqrt() / s).item()
+    rms32 = (((got32.double().cpu() - want) ** 2).mean().sqrt() / s).item()
+    print("chain %-15s n = %2d %-10s vs fp64: split max %.2e rms %.2e | fp32 pipe max %.2e rms %.2e" % (case, n, kind, e, rms, e32, rms32))
+    assert e < 2e-6 and e <= 1.05 * e32 and rms <= 1.05 * rms32
