@@ -297,6 +297,12 @@ int offk_winograd_conv7x7s2(void* stream, const float* x, int x_cstride, int x_c
  * Shapes built: (Cin, Cmid) = (128, 128) and (256, 256); without w1 also Cin = 128 / 256. */
 int offk_winograd_between(void* stream, const float* M, const float* bias_in, int phases_in, int n_img, int Cin,
                           float* x, int x_cstride, int x_coff, const float* w1, const float* b1, int Cmid, float* V);
+/* (ABI v10) The same with the 1x1 conv in the handle's arithmetic: precision OFFK_PRECISION_F32SPLIT runs stage B in split-fp32 on the bf16
+ * matrix pipe (what a split-fp32 handle does in offk_forward; needs w1) -- scratch: Cmid * Cin * 6 bytes of device memory for w1's plane image;
+ * OFFK_PRECISION_FP32 = offk_winograd_between. */
+int offk_winograd_between_ex(void* stream, const float* M, const float* bias_in, int phases_in, int n_img, int Cin, float* x,
+                             int x_cstride, int x_coff, const float* w1, const float* b1, int Cmid, float* V, int precision,
+                             void* scratch, size_t scratch_bytes);
 
 /* The batched GEMMs of a convolution on a Winograd path as a stage of their own (wino_gemm.hip / wino_gemm_split.hip; ABI v9):
  *   y[b] = x[b] . w[b]^T,  x [batch][M][K], w [batch][Co][K], y [batch][M][Co], all contiguous fp32; K % 32 == 0, Co % 64 == 0.

@@ -68,6 +68,7 @@ SIGNATURES = {
     "offk_winograd_conv5x5s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _F, _I, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_winograd_conv7x7s2": (_I, [_P, _F, _I, _I, _I, _I, _F, _F, _I, _I, _F, _I, _I, _F, _c.c_size_t]),
     "offk_winograd_between": (_I, [_P, _F, _F, _I, _I, _I, _F, _I, _I, _F, _F, _I, _F]),
+    "offk_winograd_between_ex": (_I, [_P, _F, _F, _I, _I, _I, _F, _I, _I, _F, _F, _I, _F, _I, _P, ctypes.c_size_t]),
     "offk_batched_gemm_nt": (_I, [_P, _F, _F, _F, _I, _I, _I, _I, _I, _P, _c.c_size_t]),
     "offk_pack_conv_weight": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "offk_set_conv_plan": (_I, [_P, _c.c_char_p, _I, _I]),

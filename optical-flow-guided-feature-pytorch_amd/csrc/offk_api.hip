@@ -182,6 +182,7 @@ struct offk_handle {
   float* wino_us[6] = {};        // split-fp32 handles: the plane images of wino_u (wino_gemm_split.hip), 6 bytes per element; nullptr: fp32 GEMMs
   float* wino_u[6] = {};         // transformed weights [121][Co][Ci] of C3_14B, C_T7, C2_7, C2_14A, C2_14B; 400 x Co x Ci floats of C_T14 (polyphase 5x5 / 2)
   bool wino_dirty = true;
+  float* mid_ws[2] = {};         // split-fp32 handles (OFFK_SPLIT_MID=0: off): plane images of the 1x1 convs inside wino_mid (motion_conv1_trans_14a, motion_conv1_trans)
   float* chain_ws[3][4] = {};    // split-fp32 handles (OFFK_SPLIT_CHAIN=0: off): plane images of the chains' c1 / c2 (packed K order) / c3 weights
                                  // (chain_split.hip), [chain 28a, 28b, 28c][conv]; [0][3]: motion_conv_branch_28a, which such a handle runs as a
                                  // 1x1 conv of its own in front of chain 28a (its output is the chain's residual)
@@ -685,6 +686,9 @@ int finalize_wino(offk_handle* h, hipStream_t st) {
       HIP_TRY(h, wino_pack_split_launch(h->conv_w[c3[k]], h->chain_ws[k][2], 256, 64, 1, st));
     }
     if (h->chain_ws[0][3]) HIP_TRY(h, wino_pack_split_launch(h->conv_w[CB_28A], h->chain_ws[0][3], 256, 64, 1, st));
+    const ConvId midc[2] = {C1_14A, C1_7};
+    for (int k = 0; k < 2; ++k)
+      if (h->mid_ws[k]) HIP_TRY(h, wino_pack_split_launch(h->conv_w[midc[k]], h->mid_ws[k], kConvs[midc[k]].Co, kConvs[midc[k]].Ci, 1, st));
   }
   h->wino_dirty = false;
   return OFFK_OK;
@@ -847,6 +851,11 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
       for (int k = 0; k < 3; ++k)
         for (int q = 0; q < (k == 0 ? 4 : 3); ++q)
           if (dev_alloc(h, &h->chain_ws[k][q], (elems[q] * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
+    } }
+    { const char* e = getenv("OFFK_SPLIT_MID"); if (h->wino_mid && h->winograd && h->f32split && !(e && *e == '0')) {
+      const ConvId midc[2] = {C1_14A, C1_7};
+      for (int k = 0; k < 2; ++k)
+        if (dev_alloc(h, &h->mid_ws[k], ((size_t)kConvs[midc[k]].Co * kConvs[midc[k]].Ci * 3 + 1) / 2) != OFFK_OK) { g_err = h->err; offk_destroy(h); return OFFK_ERR_HIP; }
     } }
   }
   plan_workspace(h);
@@ -1260,6 +1269,7 @@ int offk_forward_parts(offk_handle* h, void* stream, const offk_feat_parts feats
     m.w1 = mid ? h->conv_w[*mid] : nullptr; m.b1 = mid ? h->conv_b[*mid] : nullptr;
     m.Cin = kConvs[a].Co; m.Cmid = mid ? kConvs[*mid].Co : kConvs[a].Co; m.n_img = n;
     m.V = wino_V;
+    if (mid) m.w1p = *mid == C1_14A ? h->mid_ws[0] : *mid == C1_7 ? h->mid_ws[1] : nullptr;
     TRY(trace_mark(h, s, name));
     HIP_TRY(h, wino_mid_launch(m, s));
     return OFFK_OK;
@@ -1729,6 +1739,28 @@ int offk_winograd_between(void* stream, const float* M, const float* bias_in, in
   m.M = M; m.bias_in = bias_in; m.phases_in = phases_in; m.x = x; m.x_cs = x_cstride; m.x_coff = x_coff;
   m.w1 = w1; m.b1 = b1; m.Cin = Cin; m.Cmid = Cmid; m.n_img = n_img; m.V = V;
   hipError_t e = wino_mid_launch(m, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  return OFFK_OK;
+}
+
+int offk_winograd_between_ex(void* stream, const float* M, const float* bias_in, int phases_in, int n_img, int Cin, float* x,
+                             int x_cstride, int x_coff, const float* w1, const float* b1, int Cmid, float* V, int precision,
+                             void* scratch, size_t scratch_bytes) {
+  const char* who = "offk_winograd_between_ex";
+  if (precision == OFFK_PRECISION_FP32) return offk_winograd_between(stream, M, bias_in, phases_in, n_img, Cin, x, x_cstride, x_coff, w1, b1, Cmid, V);
+  if (precision != OFFK_PRECISION_F32SPLIT || !w1 || !b1 || !scratch || scratch_bytes < (size_t)Cmid * Cin * 6)
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": split-fp32 needs the 1x1 conv and Cmid * Cin * 6 bytes of scratch");
+  if (!M || !V || n_img < 1 || (x && (x_cstride < x_coff + Cin || (x_cstride & 3) || (x_coff & 3) || x_coff < 0)))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": bad argument");
+  if (!wino_mid_supported(Cin, Cmid, true, phases_in))
+    return fail(nullptr, OFFK_ERR_INVALID, std::string(who) + ": shape not built ((Cin, Cmid) = (128, 128) / (256, 256); phases_in 1, or 4 with Cin 128)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = wino_pack_split_launch(w1, scratch, Cmid, Cin, 1, st);
+  if (e != hipSuccess) return fail_hip(nullptr, e, who);
+  WinoMidArgs m;
+  m.M = M; m.bias_in = bias_in; m.phases_in = phases_in; m.x = x; m.x_cs = x_cstride; m.x_coff = x_coff;
+  m.w1 = w1; m.b1 = b1; m.Cin = Cin; m.Cmid = Cmid; m.n_img = n_img; m.V = V; m.w1p = scratch;
+  e = wino_mid_launch(m, st);
   if (e != hipSuccess) return fail_hip(nullptr, e, who);
   return OFFK_OK;
 }

@@ -117,6 +117,7 @@ struct WinoMidArgs {
   int Cin, Cmid, n_img;
   float* V;                // GEMM input of the conv behind: [121][n_img][Cmid] (3x3 / stride 1 point order)
   int nsplit = 0;          // blocks per image the 1x1 conv's output channels are split over (0: the default of the shape; tools)
+  const void* w1p = nullptr;   // != nullptr: the plane image of w1 (wino_pack_split_launch(w1, img, Cmid, Cin, 1)): stage B in split-fp32 arithmetic
 };
 bool wino_mid_supported(int Cin, int Cmid, bool gemm, int phases_in);
 hipError_t wino_mid_launch(const WinoMidArgs& a, hipStream_t st);

@@ -11,6 +11,10 @@
 //   stage B  t = relu(W1 x + b1)           the 1x1 conv: v_mfma_f32_16x16x4_f32, weights = A operand straight from L2 (a lane ends
 //                                          with four consecutive channels of one pixel), pixels = B operand from LDS; t -> LDS
 //   stage C  V = B^T t B                   the input transform of the conv behind, to its GEMM input V [121][P][CMID]
+// SPL (round 6; split-fp32 handles): stage B in the split arithmetic of wino_gemm_split.hip -- stage A cuts every activation into its three
+// bf16 planes as it stores it (2-byte stores into the plane image [pixel tile][plane][k group g][position = slot ^ 2 g] x 16 B, the layout of
+// wino_gemm_split.hip), the weights come as the library's plane image, six v_mfma_f32_16x16x32_bf16 per (pixel tile, channel tile, 32 k) into two
+// running accumulators: 384 16-cycle MFMAs per wave of the 256 -> 256 form instead of 512 32-cycle ones.
 // GEMM = false drops stage B: output transform + ReLU + input transform between two 3x3 convs that follow each other
 // (motion_conv2_trans_14b -> motion_conv3_trans_14b).
 // The transforms are the arithmetic of wino_output_kernel / wino_input_kernel element for element; only the 1x1 conv's summation
@@ -32,11 +36,33 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int C>
 __device__ __forceinline__ int tile_off(int px, int c) { return px * (C * 4) + ((((c >> 2) ^ (px & 15))) << 4) + (c & 3) * 4; }
 
+// split-fp32 stage B: the x tile as plane images.  Byte offset of channel c (of the tile's LC) of pixel slot px in plane 0; planes are
+// kPlaneStride<LC> apart.  [pixel tile px >> 4][plane][k group c >> 3][position (px & 15) ^ 2 (g & 7)] x 16 B + (c & 7) x 2 B
+template <int LC> constexpr int kPlaneStride = (LC / 8) * 256;
+template <int LC> constexpr int kPtStride = 3 * kPlaneStride<LC>;
+template <int LC>
+__device__ __forceinline__ int plane_off(int px, int c) {
+  const int g = c >> 3;
+  return (px >> 4) * kPtStride<LC> + g * 256 + ((((px & 15) ^ (2 * (g & 7)))) << 4) + (c & 7) * 2;
+}
+// one activation -> its three bf16 planes (truncating cut, as everywhere), 2-byte stores
+template <int LC>
+__device__ __forceinline__ void store_planes(char* xt, int px, int c, float v) {
+  const unsigned h = __float_as_uint(v) & 0xffff0000u;
+  const float r = v - __uint_as_float(h);
+  const unsigned m = __float_as_uint(r) & 0xffff0000u;
+  const float l = r - __uint_as_float(m);
+  char* d = xt + plane_off<LC>(px, c);
+  *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h >> 16);
+  *reinterpret_cast<unsigned short*>(d + kPlaneStride<LC>) = (unsigned short)(m >> 16);
+  *reinterpret_cast<unsigned short*>(d + 2 * kPlaneStride<LC>) = (unsigned short)(__float_as_uint(l) >> 16);
+}
+
 // stage A for one class: M -> relu(A^T M A + bias) -> LDS tile (+ HBM), lane = channel within a group of 64.  TWO channel groups at
 // a time: their 2 x NY x NX loads -- every one a 256-byte row of a different point plane -- are in flight together (one group at a
 // time, the four groups of a 256-channel image were four exposed HBM latencies per block: the first version's 60 us at P = 384).
 // (G0 .. G1: the channel groups of 64 this call covers; LC: channels per row of the LDS tile, which starts at channel 64 G0)
-template <int NPH, int CY, int CX, int CIN, int G0 = 0, int G1 = CIN / 64, int LC = CIN>
+template <int NPH, int CY, int CX, int CIN, int G0 = 0, int G1 = CIN / 64, int LC = CIN, bool SPL = false>
 __device__ __forceinline__ void mid_out_class(const WinoMidArgs& a, int img, int lane, char* xt, float* xg) {
   constexpr int NY = CY ? 5 : 6, NX = CX ? 5 : 6, OY = CY ? 3 : 4, OX = CX ? 3 : 4, oy = CY ? 4 : 0, ox = CX ? 4 : 0;
   const size_t pstride = (size_t)a.n_img * CIN;
@@ -73,7 +99,8 @@ __device__ __forceinline__ void mid_out_class(const WinoMidArgs& a, int img, int
         for (int j = 0; j < OX; ++j) {
           const int px = (oy + i) * 7 + ox + j;
           const float v = fmaxf(yv[j] + bv, 0.f);
-          *reinterpret_cast<float*>(xt + tile_off<LC>(px, c - 64 * G0)) = v;
+          if constexpr (SPL) store_planes<LC>(xt, px, c - 64 * G0, v);
+          else *reinterpret_cast<float*>(xt + tile_off<LC>(px, c - 64 * G0)) = v;
           if (xg) xg[((size_t)img * 49 + px) * a.x_cs + a.x_coff + c] = v;
         }
       }
@@ -125,8 +152,9 @@ __device__ __forceinline__ void mid_in_class(const WinoMidArgs& a, int img, int 
 // KH = 2 (CIN = 256, NS = 2): the x tile in two k halves of 128 channels -- stage A and stage B alternate per half, the
 // accumulators stay in registers -- so that x, and t behind it, take 32 KB instead of 64 KB and three blocks fit a CU.  Same k order:
 // bit-identical to KH = 1.
-template <int CIN, int CMID, bool GEMM, int NPH, int NS, int KH = 1>
-__global__ __launch_bounds__(256, KH == 2 ? 3 : 2) void wino_mid_kernel(WinoMidArgs a) {
+template <int CIN, int CMID, bool GEMM, int NPH, int NS, int KH = 1, bool SPL = false>
+__global__ __launch_bounds__(256, (KH == 2 || SPL) ? 3 : 2) void wino_mid_kernel(WinoMidArgs a) {
+  static_assert(!SPL || (GEMM && CIN / KH == 128), "split stage B: x tiles of 128 channels (48 KB of planes: three blocks per CU)");
   // (CIN % 128: mid_out_class walks the channel groups of 64 two at a time)
   static_assert(CIN % 128 == 0 && CMID % (64 * NS) == 0 && (GEMM || (CIN == CMID && NS == 1)), "whole waves of channels");
   static_assert(KH == 1 || (KH == 2 && GEMM && CIN == 256), "k halves: the 256 -> 256 form");
@@ -144,16 +172,21 @@ __global__ __launch_bounds__(256, KH == 2 ? 3 : 2) void wino_mid_kernel(WinoMidA
   auto zero_tail = [&]() {
     // pixel slots 49 .. 63 of the x tile: stage A never writes them and stage B multiplies them (MFMA columns that are dropped behind
     // it) -- zeroed so that no uninitialised LDS word is ever read
-    for (int i = tid; i < 15 * XC / 4; i += 256) reinterpret_cast<f32x4*>(lds + 49 * (XC * 4))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (SPL) {      // the whole fourth pixel tile of the plane image (pixel 48 is written behind the barrier that follows)
+      for (int i = tid; i < kPtStride<XC> / 16; i += 256) reinterpret_cast<f32x4*>(lds + 3 * kPtStride<XC>)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __syncthreads();
+    } else {
+      for (int i = tid; i < 15 * XC / 4; i += 256) reinterpret_cast<f32x4*>(lds + 49 * (XC * 4))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
   auto stage_a = [&](auto half) {
     constexpr int H = decltype(half)::value;
     constexpr int G0 = KH == 2 ? 2 * H : 0, G1 = KH == 2 ? 2 * H + 2 : CIN / 64;
     switch (wave) {
-      case 0: mid_out_class<NPH, 0, 0, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
-      case 1: mid_out_class<NPH, 0, 1, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
-      case 2: mid_out_class<NPH, 1, 0, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
-      default: mid_out_class<NPH, 1, 1, CIN, G0, G1, XC>(a, img, lane, lds, xg); break;
+      case 0: mid_out_class<NPH, 0, 0, CIN, G0, G1, XC, SPL>(a, img, lane, lds, xg); break;
+      case 1: mid_out_class<NPH, 0, 1, CIN, G0, G1, XC, SPL>(a, img, lane, lds, xg); break;
+      case 2: mid_out_class<NPH, 1, 0, CIN, G0, G1, XC, SPL>(a, img, lane, lds, xg); break;
+      default: mid_out_class<NPH, 1, 1, CIN, G0, G1, XC, SPL>(a, img, lane, lds, xg); break;
     }
   };
   if constexpr (GEMM) zero_tail();
@@ -179,13 +212,68 @@ __global__ __launch_bounds__(256, KH == 2 ? 3 : 2) void wino_mid_kernel(WinoMidA
       for (int pt = 0; pt < PT; ++pt)
         x[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * (XC * 4) + (((4 * s + kq) ^ li) << 4));
     };
-    f32x4 acc[PT][CT];
+    f32x4 acc[PT][CT], acs[SPL ? PT : 1][SPL ? CT : 1];      // (split: acc = sum w_h x_h, acs = the five small products)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < CT; ++ct) { acc[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (SPL) acs[pt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // split-fp32: the K-steps of 32 channels [t0, t0 + XC / 32) of the conv out of the plane image in LDS (which holds the channels from 32 t0 on)
+    auto stage_b_split = [&](const int t0) {
+      if constexpr (SPL) {
+        constexpr int NT = XC / 32, NCT = CMID / 16;
+        const __amdgpu_buffer_rsrc_t wps = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w1p), 0, CMID * CIN * 6, 0x00020000);
+        const int ct0 = (c_first + wave * (CM / 4)) >> 4;
+        const char* const prd = lds + kq * 256;          // + pt, + plane, + 4 t k groups; position li ^ 2 (g & 7)
+        auto mfs = [&](f32x4 c, const u32x4& w, const u32x4& x) {
+          return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+        };
+        u32x4 wq[2][CT][3];
+        auto wl = [&](const int set, const int t) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              wq[set][ct][pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wps, lane * 16, (((t0 + t) * NCT + ct0 + ct) * 3 + pl) * 1024, 0));
+        };
+        u32x4 xq[2][3];
+        auto xl = [&](u32x4 (&x)[3], const int t, const int pt) {
+          const int g = 4 * t + kq;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            x[pl] = *reinterpret_cast<const u32x4*>(prd + pt * kPtStride<XC> + pl * kPlaneStride<XC> + 4 * t * 256 + ((li ^ (2 * (g & 7))) << 4));
+        };
+        wl(0, 0);
+        xl(xq[0], 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t + 1 < NT) wl((t + 1) & 1, t + 1);
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            const int nx = t * PT + pt + 1;
+            if (nx < NT * PT) xl(xq[nx & 1], nx / PT, nx % PT);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 (&x)[3] = xq[(t * PT + pt) & 1];
+            // planes 0 = h, 1 = m, 2 = l; the channel tiles' chains interleaved
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acs[pt][ct] = mfs(acs[pt][ct], wq[t & 1][ct][2], x[0]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acs[pt][ct] = mfs(acs[pt][ct], wq[t & 1][ct][0], x[2]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = mfs(acc[pt][ct], wq[t & 1][ct][0], x[0]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acs[pt][ct] = mfs(acs[pt][ct], wq[t & 1][ct][1], x[1]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acs[pt][ct] = mfs(acs[pt][ct], wq[t & 1][ct][1], x[0]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acs[pt][ct] = mfs(acs[pt][ct], wq[t & 1][ct][0], x[1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
     // the k steps [s0, s0 + KSH) out of the tile in LDS (which holds the channels from 16 s0 on)
     auto stage_b = [&](const int s0) {
+      if constexpr (SPL) { stage_b_split(s0 / 2); return; }
       f32x4 wq[3][CT], xv[2][PT];
       w_load(wq[0], s0);
       if (KSH > 1) w_load(wq[1], s0 + 1);
@@ -233,7 +321,8 @@ __global__ __launch_bounds__(256, KH == 2 ? 3 : 2) void wino_mid_kernel(WinoMidA
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
         const int px = 16 * pt + li;
-        const f32x4 v = acc[pt][ct] + bb;
+        f32x4 v = acc[pt][ct] + bb;
+        if constexpr (SPL) v = (acc[pt][ct] + acs[pt][ct]) + bb;
         if (px < 49)
           *reinterpret_cast<f32x4*>(lds + tile_off<CM>(px, ch)) = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
       }
@@ -267,6 +356,22 @@ hipError_t wino_mid_launch(const WinoMidArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;                                                                                 \
     hipLaunchKernelGGL((wino_mid_kernel<CI, CM, G, PH, NSP, KHV>), dim3(a.n_img, NSP), dim3(256), kLds, st, a);    \
   }
+  // split-fp32 stage B: two blocks per image, x tiles of 128 channels as plane images (48 KB; t behind them is smaller)
+#define OFFK_MID_LAUNCH_SPL(CI, CM, PH, KHV)                                                                                  \
+  {                                                                                                                           \
+    constexpr int kLds = 4 * kPtStride<CI / KHV>;                                                                             \
+    static_assert(kLds >= 64 * (CM / 2) * 4, "t tile behind the planes");                                                     \
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(wino_mid_kernel<CI, CM, true, PH, 2, KHV, true>), kLds);       \
+    if (e != hipSuccess) return e;                                                                                            \
+    hipLaunchKernelGGL((wino_mid_kernel<CI, CM, true, PH, 2, KHV, true>), dim3(a.n_img, 2), dim3(256), kLds, st, a);          \
+    return hipGetLastError();                                                                                                 \
+  }
+  if (gemm && a.w1p && a.nsplit <= 0) {
+    if (a.Cin == 128 && a.phases_in == 4) OFFK_MID_LAUNCH_SPL(128, 128, 4, 1)
+    else if (a.Cin == 128) OFFK_MID_LAUNCH_SPL(128, 128, 1, 1)
+    else OFFK_MID_LAUNCH_SPL(256, 256, 1, 2)
+  }
+#undef OFFK_MID_LAUNCH_SPL
 #define OFFK_MID_LAUNCH(CI, CM, G, PH, NSP) OFFK_MID_LAUNCH_KH(CI, CM, G, PH, NSP, 1)
   // blocks per image (tools/bench_between.py, P = 384, device time): 128 -> 128: 20.8 us with one block per image, 18.7 with two;
   // 256 -> 256: 56.8 / 60.1 / 61.3 us with 1 / 2 / 4 (its x tile is 64 KB whatever the split: two blocks per CU either way); [r5] two

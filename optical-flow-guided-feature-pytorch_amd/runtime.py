@@ -421,7 +421,7 @@ def winograd_conv7x7s2(x, w_oihw, bias, flags=0, x_coff=0, y=None, y_coff=0):
     return y
 
 
-def winograd_between(M, bias_in, phases_in, w1=None, b1=None, x=None, x_coff=0):
+def winograd_between(M, bias_in, phases_in, w1=None, b1=None, x=None, x_coff=0, precision="fp32"):
     """offk_winograd_between: M [121, n, Cin] (Winograd-domain GEMM output of the conv in front) -> V [121, n, Cmid] (GEMM input of
     the conv behind), through relu(A^T M A + bias_in), optionally a 1x1 conv w1 [Cmid, Cin] + b1 + ReLU, and B^T . B.  x: optional
     [n, 7, 7, Cs] buffer that also receives relu(A^T M A + bias_in) at channels [x_coff, x_coff + Cin)."""
@@ -430,6 +430,12 @@ def winograd_between(M, bias_in, phases_in, w1=None, b1=None, x=None, x_coff=0):
     assert pts == 121
     cmid = w1.shape[0] if w1 is not None else cin
     V = torch.empty(121, n, cmid, dtype=torch.float32, device=M.device)
+    if precision == "f32split":      # offk_winograd_between_ex: stage B (the 1x1 conv) in split-fp32 arithmetic
+        scratch = torch.empty(cmid * cin * 6, dtype=torch.uint8, device=M.device)
+        _lib.check(lib.offk_winograd_between_ex(_stream(M.device), _ptr(M.contiguous()), _ptr(bias_in), int(phases_in), n, cin, _ptr(x),
+                                                x.shape[-1] if x is not None else 0, x_coff, _ptr(w1.contiguous()), _ptr(b1), cmid, _ptr(V),
+                                                _lib.PRECISIONS[precision], _ptr(scratch), scratch.numel()))
+        return V
     _lib.check(lib.offk_winograd_between(_stream(M.device), _ptr(M.contiguous()), _ptr(bias_in), int(phases_in), n, cin, _ptr(x),
                                          x.shape[-1] if x is not None else 0, x_coff, _ptr(w1.contiguous() if w1 is not None else None),
                                          _ptr(b1), cmid, _ptr(V)))

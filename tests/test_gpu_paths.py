@@ -373,9 +373,11 @@ def _between_reference(M, bias, phases, w1, b1):
     return x, V
 
 
-@pytest.mark.parametrize("cin,phases,gemm", [(128, 4, True), (128, 1, True), (256, 1, True), (128, 1, False), (256, 1, False)])
+# (the forms with a 1x1 conv in both arithmetic modes -- stage B is what runs in split arithmetic; the forms without one have no such mode)
+@pytest.mark.parametrize("cin,phases,gemm,prec", [(128, 4, True, "fp32"), (128, 1, True, "fp32"), (256, 1, True, "fp32"), (128, 1, False, "fp32"),
+                                                  (256, 1, False, "fp32"), (128, 4, True, "f32split"), (128, 1, True, "f32split"), (256, 1, True, "f32split")])
 @pytest.mark.parametrize("n", [1, 5])
-def test_winograd_between_vs_fp64(rt, cin, phases, gemm, n):
+def test_winograd_between_vs_fp64(rt, cin, phases, gemm, n, prec):
     """offk_winograd_between (wino_mid.hip: output transform + ReLU [+ 1x1 conv + ReLU] + input transform in one launch) against an
     fp64 restatement with the transform matrices written out, for the five instantiations the forward uses
     (RGB_OFF.py:762-767, :775-780, :833-838), including the store of the first conv's activation into a channel slice."""
@@ -385,16 +387,16 @@ def test_winograd_between_vs_fp64(rt, cin, phases, gemm, n):
     w1 = (g.standard_normal((cin, cin)) / cin ** 0.5).astype(np.float32) if gemm else None
     b1 = (g.standard_normal(cin) * 0.1).astype(np.float32) if gemm else None
     xbuf = torch.full((n, 7, 7, cin + 64), -3.0, device="cuda")
-    V = rt.winograd_between(dev(M), dev(bias), phases, dev(w1) if gemm else None, dev(b1) if gemm else None, x=xbuf, x_coff=32)
+    V = rt.winograd_between(dev(M), dev(bias), phases, dev(w1) if gemm else None, dev(b1) if gemm else None, x=xbuf, x_coff=32, precision=prec)
     torch.cuda.synchronize()
     x_ref, v_ref = _between_reference(M.astype(np.float64), bias.astype(np.float64), phases,
                                       w1.astype(np.float64) if gemm else None, b1.astype(np.float64) if gemm else None)
     ex = rel_err(xbuf[..., 32:32 + cin], x_ref)
     ev = rel_err(V, v_ref)
-    print("winograd between Cin %d phases %d gemm %d n %d: x %.2e V %.2e" % (cin, phases, gemm, n, ex, ev))
+    print("winograd between Cin %d phases %d gemm %d n %d %s: x %.2e V %.2e" % (cin, phases, gemm, n, prec, ex, ev))
     assert ex < 1e-5 and ev < 2e-5
     assert torch.all(xbuf[..., :32] == -3.0) and torch.all(xbuf[..., 32 + cin:] == -3.0)
-    V2 = rt.winograd_between(dev(M), dev(bias), phases, dev(w1) if gemm else None, dev(b1) if gemm else None)     # no x store
+    V2 = rt.winograd_between(dev(M), dev(bias), phases, dev(w1) if gemm else None, dev(b1) if gemm else None, precision=prec)     # no x store
     assert torch.equal(V, V2)
 
 
