@@ -110,7 +110,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA peak
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (measured on these operands: ~2.1 PF, profiles/r05/probe_split_mfma.txt)
 DTYPES = {"fp32": "f32",
           "f32split": "f32 (split-fp32: every fp32 operand as three bf16 planes = the fp32 value exactly, six exact plane products "
-                      "on the bf16 MFMA pipe, f32 accumulate; kernels without a split form run the fp32 pipe)"}
+                      "on the bf16 MFMA pipe, f32 accumulate)"}
 
 
 def cpu_baseline(feats_np, weights, length, variant, clips_large):
@@ -1103,8 +1103,8 @@ def main():
                        "slice_mode": "reference_flat",
                        "arithmetic": ("fp32 MFMA products, fp32 accumulation" if args.precision == "fp32" else
                                       "split-fp32 (three bf16 planes per fp32 operand, six exact plane products on the bf16 pipe, fp32 accumulation) in the "
-                                      "units kernel, the Winograd GEMMs, the bottleneck chains and the 1x1 convs on 7x7 maps; fp32 MFMA products in the kernels "
-                                      "without a split form (the 1x1 convs inside wino_mid)") +
+                                      "units kernel, the Winograd GEMMs, the bottleneck chains and every 1x1 conv on 7x7 maps (no MFMA-bound launch of this mode is left "
+                                      "on the fp32 pipe)") +
                                      ("; the k x k fusion convs in Winograd forms (fp32 transforms)" if wino_on else "; direct convolutions")},
             "n_ranks_seen": dist.get_world_size() if coll else 1, "collective_backend": backend,
             "exchange": ("async_op=True on two alternating buffer sets: the timed step does not wait for its own collective, only the "
