@@ -300,7 +300,7 @@ CHAIN_MIN_PAIRS = 72      # one launch per bottleneck chain of fusion@28 from th
 def split_chains(P, precision):
     """A split-fp32 handle runs the bottleneck chains on chain_split.hip (offk_api.hip: OFFK_SPLIT_CHAIN, from the chain gate on)."""
     e = os.environ
-    gate = int(e["OFFK_CHAIN"]) if e.get("OFFK_CHAIN", "").isdigit() and int(e["OFFK_CHAIN"]) > 1 else CHAIN_MIN_PAIRS
+    gate = int(e["OFFK_CHAIN"]) if e.get("OFFK_CHAIN", "").isdigit() and int(e["OFFK_CHAIN"]) > 1 else 1      # (split handles: from the first pair on)
     return (precision == "f32split" and e.get("OFFK_SPLIT_CHAIN", "1") != "0" and e.get("OFFK_CHAIN", "1") != "0" and
             e.get("OFFK_WINOGRAD", "1") != "0" and P >= gate)
 

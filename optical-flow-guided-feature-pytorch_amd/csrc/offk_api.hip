@@ -811,7 +811,10 @@ int offk_create(const offk_config* cfg, offk_handle** out) {
   //   OFFK_WINO_GEMM     the batched GEMMs of a Winograd conv as one persistent launch (wino_gemm.hip); 0: one block of the generic 1x1 kernel per
   //                      tile (bit-identical).  The handle-less stage entry points read it once per process.
   { const char* e = getenv("OFFK_FUSED_UNITS"); h->fused_units = !(e && *e == '0'); }
-  { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e); }
+  { const char* e = getenv("OFFK_CHAIN"); h->chain = !(e && *e == '0'); if (e && atoi(e) > 1) h->chain_min_p = atoi(e);
+    // split-fp32 handles: chain14_split_kernel from the first pair on (a block of it alone on a CU is ~25 us per chain where the fp32 kernel's
+    // sixteen phases are 45 us: B = 1 .. 4 0.432 / 0.482 / 0.565 -> 0.425 / 0.477 / 0.555 ms, B = 8 level; profiles/r06/small_batch_gates.txt)
+    else if (h->f32split) { const char* c = getenv("OFFK_SPLIT_CHAIN"); if (!(c && *c == '0')) h->chain_min_p = 1; } }
   { const char* e = getenv("OFFK_FOLD_POOL"); h->fold_pool = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINO_MID"); h->wino_mid = !(e && *e == '0'); }
   { const char* e = getenv("OFFK_WINO_GEMM"); h->wino_gemm = !(e && *e == '0'); }
